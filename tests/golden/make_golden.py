@@ -1,0 +1,208 @@
+"""Golden-vector generator.  RUN ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+Imports the real reference (seorim0/DNN-based-Speech-Enhancement-in-the-frequency-domain) through the
+import shim of SURVEY.md Appendix C, fills its modules with the formula weights of
+oracle/weights.py, runs forward / loss / backward / Adam on closed-form signals and writes small
+.npz fixtures next to this file.  Only *data* (inputs are closed-form, outputs are stored) is committed;
+no reference source travels.
+
+    python tests/golden/make_golden.py
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+from oracle.weights import fill_state_dict_, test_signals  # noqa: E402
+
+
+def import_reference(perceptual=False):
+    class _Stub(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    al = types.ModuleType("asteroid.losses")
+    al.SingleSrcPMSQE = al.PITLossWrapper = _Stub
+    a = types.ModuleType("asteroid")
+    a.losses = al
+    af = types.ModuleType("asteroid_filterbanks")
+    af.STFTFB = af.Encoder = _Stub
+    af.transforms = types.SimpleNamespace(mag=None)
+    sys.modules.update({"asteroid": a, "asteroid.losses": al, "asteroid_filterbanks": af})
+    with contextlib.redirect_stdout(io.StringIO()):
+        import config as cfg
+    cfg.DEVICE = "cpu"
+    cfg.window = "hann"
+    cfg.perceptual = "LMS"          # so that MEL_SCALES is defined at import of tools_for_loss
+    import models
+    import tools_for_loss
+    import tools_for_model
+    cfg.perceptual = False
+    return cfg, models, tools_for_model, tools_for_loss
+
+
+def sample(t: torch.Tensor, stride=97):
+    f = t.detach().reshape(-1).double()
+    return dict(sum=float(f.sum()), asum=float(f.abs().sum()), n=f.numel(),
+                samp=t.detach().reshape(-1)[::stride].float().numpy().copy())
+
+
+def flat(d, prefix):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(flat(v, f"{prefix}/{k}"))
+        else:
+            out[f"{prefix}/{k}"] = np.asarray(v)
+    return out
+
+
+SMALL_PARAMS = lambda name: (name.startswith("encoder.0.0.") or name.endswith(".2.weight") or ".1.weight" in name
+                             or ".1.bias" in name or name.endswith("r_trans.bias") or name.endswith("i_trans.bias")
+                             or name.startswith("decoder.5.0.") or name.endswith("bias_hh_l0"))
+
+
+def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True):
+    cfg.dccrn_kernel_num = list(kernel_num)
+    cfg.masking_mode = mask
+    cfg.loss = loss
+    cfg.perceptual = perceptual
+    cfg.lstm = "complex"
+    cfg.skip_type = True
+    torch.manual_seed(0)
+    m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask)
+    fill_state_dict_(m)
+    m.train()
+    x, y = test_signals(B, L)
+    taps = {}
+    hooks = []
+    if store_taps:
+        def mk(key):
+            return lambda mod, inp, out: taps.__setitem__(key, sample(out if torch.is_tensor(out) else out[0]))
+        hooks.append(m.stft.register_forward_hook(mk("spec")))
+        for i, layer in enumerate(m.encoder):
+            hooks.append(layer[0].register_forward_hook(mk(f"enc{i}.conv")))
+            hooks.append(layer.register_forward_hook(mk(f"enc{i}.out")))
+        for i, layer in enumerate(m.decoder):
+            hooks.append(layer[0].register_forward_hook(mk(f"dec{i}.conv")))
+        for l, layer in enumerate(m.enhance):
+            hooks.append(layer.register_forward_hook(
+                lambda mod, inp, out, l=l: (taps.__setitem__(f"lstm{l}.r", sample(out[0])),
+                                            taps.__setitem__(f"lstm{l}.i", sample(out[1])))[0]))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    if perceptual:
+        o_r, o_i, wav = m(x)
+        main = m.loss(wav, y)
+        perc = m.loss(wav, y, o_r, o_i, perceptual=True)
+        lossv = (main + perc) / 2
+    else:
+        o_r, o_i, wav = m(x, y)
+        lossv = m.loss(wav, y)
+        main = lossv
+        perc = torch.zeros(())
+    for h in hooks:
+        h.remove()
+    opt.zero_grad()
+    lossv.backward()
+    g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    opt.step()
+    sd = m.state_dict()
+    rec = dict(
+        meta=dict(B=B, L=L, kernel_num=np.array(kernel_num), rnn_units=rnn_units,
+                  mask=np.array(mask), loss=np.array(loss), perceptual=np.array(str(perceptual))),
+        out_real=o_r.detach().numpy(), out_imag=o_i.detach().numpy(), out_wav=wav.detach().numpy(),
+        loss=float(lossv), main_loss=float(main), perc_loss=float(perc),
+        taps=taps,
+        grad_norm={k: float(v.double().norm()) for k, v in g.items()},
+        grad={k: v.numpy() for k, v in g.items() if SMALL_PARAMS(k)},
+        grad_samp={k: sample(v, 53)["samp"] for k, v in g.items() if not SMALL_PARAMS(k)},
+        after_adam={k: sd[k].numpy().copy() for k in g if SMALL_PARAMS(k)},
+        running={k: v.numpy().copy() for k, v in sd.items() if "running_" in k},
+    )
+    np.savez_compressed(os.path.join(HERE, f"dccrn_{name}.npz"), **flat(rec, "g"))
+    print(f"dccrn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
+
+
+def frontend_and_losses(cfg, models, tfm, tfl):
+    out = {}
+    K, _ = tfm.init_kernels(400, 100, 512, "hann")
+    Kinv, win = tfm.init_kernels(400, 100, 512, "hann", invers=True)
+    out["stft_weight_rows"] = K[::37, 0].numpy()
+    out["stft_weight_asum"] = float(K.double().abs().sum())
+    out["istft_weight_rows"] = Kinv[::37, 0].numpy()
+    out["istft_weight_asum"] = float(Kinv.double().abs().sum())
+    out["window"] = win[0, :, 0].numpy()
+    x, y = test_signals(2, 4000)
+    stft = tfm.ConvSTFT(400, 100, 512, "hann", "complex")
+    istft = tfm.ConviSTFT(400, 100, 512, "hann", "complex")
+    S = stft(x)
+    out["stft_out"] = S.numpy()
+    out["istft_consistent"] = istft(S).numpy()
+    S2 = S.clone()
+    S2[:, 257] = 1.0
+    S2[:, 0] *= 0.5
+    S2[:, 100:140] *= 1.7
+    out["istft_inconsistent"] = istft(S2).numpy()
+    mags, phase = tfm.ConvSTFT(400, 100, 512, "hann", "real")(x)
+    out["stft_mags"] = mags.numpy()
+    # losses on fixed pairs (est = noisy, target = clean)
+    out["loss_sdr"] = float(tfl.sdr(y, x))
+    out["loss_si_snr"] = float(tfl.si_snr(x, y))
+    out["loss_si_sdr"] = float(tfl.si_sdr(y, x))
+    out["loss_mse"] = float(torch.nn.functional.mse_loss(x, y))
+    # si_sdr docstring known answers (tools_for_loss.py:57-74)
+    np.random.seed(0)
+    ref = torch.from_numpy(np.random.randn(100))
+    out["si_sdr_doc"] = np.array([float(tfl.si_sdr(ref, torch.flip(ref, [0]))),
+                                  float(tfl.si_sdr(ref, ref + torch.flip(ref, [0]))),
+                                  float(tfl.si_sdr(ref, ref + 0.5)),
+                                  float(tfl.si_sdr(ref, ref * 2 + 1))])
+    # LMS pieces
+    for nb in (16, 32, 64):
+        out[f"mel_{nb}"] = tfl.melFilterBank(nb, 512).astype(np.float32)
+    cm = torch.sqrt(S[:, :257] ** 2 + S[:, 257:] ** 2 + 1e-7)
+    Sy = stft(y)
+    em = torch.sqrt(Sy[:, :257] ** 2 + Sy[:, 257:] ** 2 + 1e-7)
+    out["lms_loss"] = float(tfl.get_array_lms_loss(cm, em))
+    # FullSubNet front end known answers
+    n = torch.arange(48000, dtype=torch.float64)
+    xx = (0.5 * torch.sin(2 * np.pi * 440 * n / 16000) + 0.1 * torch.sin(2 * np.pi * 3000 * n / 16000 + 0.7)).float()[None]
+    yy = (0.5 * torch.sin(2 * np.pi * 440 * n / 16000)).float()[None]
+    out["q4"] = np.array([float(tfl.si_snr(xx, yy)), float(tfl.sdr(yy, xx)), float(tfl.si_sdr(yy, xx)),
+                          float(torch.nn.functional.mse_loss(xx, yy))])
+    Sx = stft(xx)
+    out["q15"] = np.array([float(Sx[0, 0, 0]), float(Sx[0, 14, 10]), float(Sx[0, 14, 240]), float(Sx[0, 96, 240]),
+                           float(Sx[0, 271, 240]), float(Sx[0, 353, 240]), float(Sx[0, 256, 482]), float(Sx.abs().sum())])
+    cx = tfm.stft(xx)
+    cy = tfm.stft(yy)
+    out["fsn_stft_samp"] = torch.view_as_real(cx)[0, ::8, ::10].numpy()
+    out["fsn_cirm_samp"] = tfm.build_complex_ideal_ratio_mask(cx, cy)[0, ::8, ::10].numpy()
+    np.savez_compressed(os.path.join(HERE, "frontend_losses.npz"), **out)
+    print("frontend_losses: q4", out["q4"], "lms", out["lms_loss"])
+
+
+def main():
+    cfg, models, tfm, tfl = import_reference()
+    frontend_and_losses(cfg, models, tfm, tfl)
+    small = (16, 32, 32, 64, 64, 64)
+    dflt = (32, 64, 128, 256, 256, 256)
+    dccrn_case(cfg, models, "small_E_sisnr", small, 128, "E", "SI-SNR", False, 2, 4000)
+    dccrn_case(cfg, models, "small_C_sdr", small, 128, "C", "SDR", False, 2, 4000, store_taps=False)
+    dccrn_case(cfg, models, "small_R_mse", small, 128, "R", "MSE", False, 2, 4000, store_taps=False)
+    dccrn_case(cfg, models, "small_E_sisdr", small, 128, "E", "SI-SDR", False, 2, 4000, store_taps=False)
+    dccrn_case(cfg, models, "small_E_sisnr_lms", small, 128, "E", "SI-SNR", "LMS", 2, 4000, store_taps=False)
+    dccrn_case(cfg, models, "default_E_sisnr", dflt, 256, "E", "SI-SNR", False, 2, 4000)
+    dccrn_case(cfg, models, "default_C_sisnr_full", dflt, 256, "C", "SI-SNR", False, 1, 48000, store_taps=False)
+
+
+if __name__ == "__main__":
+    main()
