@@ -1,0 +1,68 @@
+"""ctypes binding of include/sefd.h.  There is NO CPU fallback: a missing library is a hard error."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsefd_hip.so")
+
+
+class ModelConfig(C.Structure):
+    """Mirror of `sefd_model_config` (include/sefd.h)."""
+    _fields_ = [("model", C.c_int32), ("B", C.c_int32), ("L", C.c_int32),
+                ("win_len", C.c_int32), ("hop", C.c_int32), ("fft_len", C.c_int32),
+                ("n_layers", C.c_int32), ("kernel_num", C.c_int32 * 8),
+                ("rnn_layers", C.c_int32), ("rnn_units", C.c_int32), ("mask_mode", C.c_int32),
+                ("lstm_complex", C.c_int32), ("skip", C.c_int32), ("act_dtype", C.c_int32),
+                ("kernel_size", C.c_int32), ("training", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
+    sig = {
+        "sefd_plan_create": (vp, [C.POINTER(ModelConfig)]),
+        "sefd_plan_destroy": (None, [vp]),
+        "sefd_plan_error": (cp, [vp]),
+        "sefd_plan_arena_bytes": (i64, [vp, i32]),
+        "sefd_plan_frames": (i32, [vp]),
+        "sefd_plan_num_params": (i32, [vp, i32]),
+        "sefd_plan_param_name": (cp, [vp, i32, i32]),
+        "sefd_plan_param_offset": (i64, [vp, i32, i32]),
+        "sefd_plan_param_numel": (i64, [vp, i32, i32]),
+        "sefd_plan_param_shape": (i32, [vp, i32, i32, C.POINTER(i64)]),
+        "sefd_plan_buffer": (i32, [vp, cp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
+        "sefd_plan_num_buffers": (i32, [vp]),
+        "sefd_plan_buffer_name": (cp, [vp, i32]),
+        "sefd_plan_const_data": (vp, [vp]),
+        "sefd_plan_num_ops": (i32, [vp, i32]),
+        "sefd_plan_ops": (vp, [vp, i32]),
+        "sefd_op_size": (i32, []),
+        "sefd_plan_run": (i32, [vp, i32, i32, i32, C.POINTER(vp), vp]),
+        "sefd_loss_ws_floats": (i64, [i32]),
+        "sefd_loss_forward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp]),
+        "sefd_loss_backward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp]),
+        "sefd_adam_step": (i32, [vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_plan_arena_bytes", "sefd_plan_frames",
+            "sefd_plan_num_params", "sefd_plan_param_name", "sefd_plan_param_offset", "sefd_plan_param_numel",
+            "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
+            "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_run",
+            "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_adam_step"]

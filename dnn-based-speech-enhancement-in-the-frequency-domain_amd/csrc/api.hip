@@ -1,0 +1,218 @@
+// extern "C" surface (include/sefd.h): plan life cycle, op execution, fused losses, Adam.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include "../../include/sefd.h"
+#include "dev_common.h"
+#include "plan.h"
+
+using namespace sefd;
+
+struct sefd_plan { Plan* p; std::vector<std::string> names; };
+
+static_assert(sizeof(sefd_model_config) == sizeof(ModelConfig), "config mirror out of sync");
+
+extern "C" {
+
+sefd_plan* sefd_plan_create(const sefd_model_config* cfg) {
+  ModelConfig mc;
+  std::memcpy(&mc, cfg, sizeof(mc));
+  sefd_plan* h = new sefd_plan();
+  h->p = build_dccrn_plan(mc);
+  for (auto& kv : h->p->bufs) h->names.push_back(kv.first);
+  return h;
+}
+void sefd_plan_destroy(sefd_plan* h) { if (h) { delete h->p; delete h; } }
+const char* sefd_plan_error(const sefd_plan* h) { return h->p->error.c_str(); }
+int64_t sefd_plan_arena_bytes(const sefd_plan* h, int a) { return (a >= 0 && a < A_COUNT) ? h->p->arena_bytes[a] : -1; }
+int32_t sefd_plan_frames(const sefd_plan* h) { return h->p->T; }
+static const std::vector<ParamInfo>& pv(const sefd_plan* h, int kind) { return kind == 0 ? h->p->params : h->p->state; }
+int32_t sefd_plan_num_params(const sefd_plan* h, int kind) { return (int32_t)pv(h, kind).size(); }
+const char* sefd_plan_param_name(const sefd_plan* h, int kind, int i) { return pv(h, kind)[i].name.c_str(); }
+int64_t sefd_plan_param_offset(const sefd_plan* h, int kind, int i) { return pv(h, kind)[i].off; }
+int64_t sefd_plan_param_numel(const sefd_plan* h, int kind, int i) { return pv(h, kind)[i].numel; }
+int32_t sefd_plan_param_shape(const sefd_plan* h, int kind, int i, int64_t* s4) {
+  const auto& sh = pv(h, kind)[i].shape;
+  for (size_t k = 0; k < sh.size() && k < 4; ++k) s4[k] = sh[k];
+  return (int32_t)sh.size();
+}
+int32_t sefd_plan_buffer(const sefd_plan* h, const char* name, int32_t* arena, int64_t* off, int64_t* bytes, int32_t* dtype) {
+  auto it = h->p->bufs.find(name);
+  if (it == h->p->bufs.end()) return -1;
+  *arena = std::strncmp(name, "io.", 3) == 0 ? A_IO : A_WS;
+  *off = it->second.off; *bytes = it->second.bytes; *dtype = it->second.dtype;
+  return 0;
+}
+int32_t sefd_plan_num_buffers(const sefd_plan* h) { return (int32_t)h->names.size(); }
+const char* sefd_plan_buffer_name(const sefd_plan* h, int i) { return h->names[i].c_str(); }
+const void* sefd_plan_const_data(const sefd_plan* h) { return h->p->consts.data(); }
+int32_t sefd_plan_num_ops(const sefd_plan* h, int phase) { return (int32_t)(phase == 0 ? h->p->fwd.size() : h->p->bwd.size()); }
+const void* sefd_plan_ops(const sefd_plan* h, int phase) { return phase == 0 ? h->p->fwd.data() : h->p->bwd.data(); }
+int32_t sefd_op_size(void) { return (int32_t)sizeof(Op); }
+
+int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream) {
+  if (!h || !h->p->error.empty()) return -1;
+  const std::vector<Op>& ops = phase == 0 ? h->p->fwd : h->p->bwd;
+  if (first < 0) first = 0;
+  if (last < 0 || last > (int)ops.size()) last = (int)ops.size();
+  ArenaBases ab;
+  for (int a = 0; a < A_COUNT; ++a) ab.p[a] = reinterpret_cast<char*>(arenas[a]);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int i = first; i < last; ++i) {
+    const Op& op = ops[i];
+    if (op.kind == OP_RUNGEMM) launch_rungemm(op.g, ab, st);
+    else if (op.kind == OP_WGRAD) launch_wgrad(op.g, ab, st);
+    else launch_misc(op, ab, st);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"
+
+// =============================================================================================== losses
+// Per-utterance inner products in one pass over est/tgt (HBM-bound: 2 x 4 x L bytes per utterance), then a
+// one-workgroup finalize that turns them into the scalar loss AND the two coefficients (ca, cb) of the analytic
+// gradient  d loss / d est[b][n] = ca[b] * est[b][n] + cb[b] * tgt[b][n]  (every loss of tools_for_loss.py:17-94 has this form).
+namespace {
+constexpr int kLossBlk = 16;     // workgroups per utterance
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* est, const float* tgt, int L, float* part) {
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const float4* e4 = reinterpret_cast<const float4*>(est + (int64_t)b * L);
+  const float4* t4 = reinterpret_cast<const float4*>(tgt + (int64_t)b * L);
+  const int n4 = L / 4;
+  float see = 0.f, set = 0.f, stt = 0.f;
+  for (int i = blk * 256 + threadIdx.x; i < n4; i += kLossBlk * 256) {
+    const float4 e = e4[i], t = t4[i];
+    see += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+    set += e.x * t.x + e.y * t.y + e.z * t.z + e.w * t.w;
+    stt += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+  }
+  if (blk == 0)
+    for (int i = n4 * 4 + threadIdx.x; i < L; i += 256) {
+      const float e = est[(int64_t)b * L + i], t = tgt[(int64_t)b * L + i];
+      see += e * e; set += e * t; stt += t * t;
+    }
+  __shared__ float r[3][4];
+  see = wave_sum(see); set = wave_sum(set); stt = wave_sum(stt);
+  if ((threadIdx.x & 63) == 0) { r[0][threadIdx.x >> 6] = see; r[1][threadIdx.x >> 6] = set; r[2][threadIdx.x >> 6] = stt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = part + ((int64_t)b * kLossBlk + blk) * 3;
+    o[0] = r[0][0] + r[0][1] + r[0][2] + r[0][3];
+    o[1] = r[1][0] + r[1][1] + r[1][2] + r[1][3];
+    o[2] = r[2][0] + r[2][1] + r[2][2] + r[2][3];
+  }
+}
+
+// ws layout: part [B][kLossBlk][3] | coef [B][2] | terms[B]
+__global__ void loss_finalize_kernel(int kind, int B, int L, float* ws, float* loss_out) {
+  float* part = ws;
+  float* coef = ws + (int64_t)B * kLossBlk * 3;
+  float* term = coef + 2 * B;
+  const float eps = 1e-8f;
+  const float k10 = 4.342944819032518f;          // 10 / ln(10)
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float see = 0.f, set = 0.f, stt = 0.f;
+    for (int k = 0; k < kLossBlk; ++k) { see += part[(b * kLossBlk + k) * 3]; set += part[(b * kLossBlk + k) * 3 + 1]; stt += part[(b * kLossBlk + k) * 3 + 2]; }
+    float v = 0.f, ca = 0.f, cb = 0.f;
+    if (kind == SEFD_LOSS_MSE) {                 // F.mse_loss(est, tgt)
+      v = (see - 2.f * set + stt) / ((float)B * (float)L);
+      ca = 2.f / ((float)B * (float)L); cb = -ca;
+    } else if (kind == SEFD_LOSS_SDR) {          // -mean 10 log10(stt^2 / (D^2 + eps)), D = |t - e|^2   (tools_for_loss.py:29-33)
+      const float Dn = see - 2.f * set + stt;
+      v = -k10 * logf(stt * stt / (Dn * Dn + eps)) / B;
+      const float kk = k10 / B * 4.f * Dn / (Dn * Dn + eps);
+      ca = kk; cb = -kk;
+    } else if (kind == SEFD_LOSS_SISNR) {        // -mean 10 log10(|a t|^2 / (|e - a t|^2 + eps) + eps), a = <e,t>/(<t,t>+eps)  (:36-44)
+      const float den = stt + eps;
+      const float a = set / den;
+      const float Tn = a * a * stt;
+      const float Nn = see - 2.f * a * set + a * a * stt;
+      const float Rr = Tn / (Nn + eps) + eps;
+      v = -k10 * logf(Rr) / B;
+      const float A1 = 1.f / (Nn + eps), A2 = Tn / ((Nn + eps) * (Nn + eps));
+      const float g = -k10 / (B * Rr);
+      ca = g * (-2.f * A2);
+      cb = g * (A1 * 2.f * a * stt / den - A2 * (-2.f * a + 2.f * (a * stt - set) / den));
+    } else {                                     // SI-SDR: ratio_b = P/N + eps; loss = -10 log10(mean_b ratio_b + eps)   (:47-94)
+      const float a = set / stt + eps;
+      const float Pn = a * a * stt;
+      const float Nn = see - 2.f * a * set + a * a * stt;
+      v = Pn / Nn + eps;                         // ratio_b ; the log is applied after the batch mean
+      // d ratio / d e = (2 a t) / N - P/N^2 * (2(e - a t) + 2 t (a stt - set)/stt)
+      ca = -Pn / (Nn * Nn) * 2.f;
+      cb = 2.f * a / Nn - Pn / (Nn * Nn) * (-2.f * a + 2.f * (a * stt - set) / stt);
+    }
+    term[b] = v; coef[2 * b] = ca; coef[2 * b + 1] = cb;
+    acc += v;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float total = red[0];
+  if (kind == SEFD_LOSS_SISDR) {
+    const float m = total / B;
+    const float g = -k10 / (m + eps) / B;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { coef[2 * b] *= g; coef[2 * b + 1] *= g; }
+    if (threadIdx.x == 0) loss_out[0] = -k10 * logf(m + eps);
+  } else if (threadIdx.x == 0) {
+    loss_out[0] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* est, const float* tgt, int B, int L, const float* ws,
+                                                       const float* gscale, float* g) {
+  const float* coef = ws + (int64_t)B * kLossBlk * 3;
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t n = (int64_t)B * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L);
+    g[i] = gs * (coef[2 * b] * est[i] + coef[2 * b + 1] * tgt[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
+                                                  float b1, float b2, float eps, float gscale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+}  // namespace
+
+extern "C" {
+int64_t sefd_loss_ws_floats(int32_t B) { return (int64_t)B * kLossBlk * 3 + 3 * (int64_t)B + 16; }
+
+int32_t sefd_loss_forward(int kind, const float* est, const float* tgt, int32_t B, int32_t L, float* ws, float* loss_out, void* stream) {
+  if (kind < 0 || kind > 3 || B < 1 || L < 1) return -1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(kLossBlk, B), dim3(256), 0, st, est, tgt, L, ws);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, kind, B, L, ws, loss_out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int32_t sefd_loss_backward(int kind, const float* est, const float* tgt, int32_t B, int32_t L, const float* ws,
+                           const float* grad_scale, float* grad_est, void* stream) {
+  (void)kind;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)B * L;
+  int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(grid), dim3(256), 0, st, est, tgt, B, L, ws, grad_scale, grad_est);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                       float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  if (n < 1 || step < 1) return -1;
+  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1), (float)std::sqrt(bc2),
+                     beta1, beta2, eps, grad_scale);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+}

@@ -1,0 +1,66 @@
+// Device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sefd_desc.h"
+
+namespace sefd {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct bf16_t { uint16_t v; };          // storage-only 16-bit type (sizeof == 2) used as the template tag of bf16 paths
+
+struct ArenaBases { char* p[A_COUNT]; };
+
+__host__ __device__ __forceinline__ char* rp(const ArenaBases& ab, const Ptr& q) { return ab.p[q.arena] + q.off; }
+
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+template <int DT> struct Elem;
+__device__ __forceinline__ float ld_elem(const char* base, int dt, int64_t i) {
+  return dt == DT_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(base)[i]) : reinterpret_cast<const float*>(base)[i];
+}
+__device__ __forceinline__ void st_elem(char* base, int dt, int64_t i, float v) {
+  if (dt == DT_BF16) reinterpret_cast<uint16_t*>(base)[i] = f2bf(v);
+  else reinterpret_cast<float*>(base)[i] = v;
+}
+
+// 4 consecutive elements (i multiple of 4)
+__device__ __forceinline__ float4 ld4(const char* base, int dt, int64_t i) {
+  if (dt == DT_BF16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(base + i * 2);
+    return make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16));
+  }
+  return *reinterpret_cast<const float4*>(base + i * 4);
+}
+__device__ __forceinline__ void st4(char* base, int dt, int64_t i, float4 v) {
+  if (dt == DT_BF16) {
+    uint2 r;
+    r.x = f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    r.y = f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(base + i * 2) = r;
+  } else {
+    *reinterpret_cast<float4*>(base + i * 4) = v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
+void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
+void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
+
+}  // namespace sefd

@@ -1,0 +1,882 @@
+// Planner: DCCRN (models.py:15-284 of the reference) -> op list over channels-last buffers.
+//
+// Layout decisions (MI355X-first, not the reference's NCHW):
+//   * every activation is channels-last  [B][T(+1)][F][C]  so that each A-row of the implicit GEMM is a few contiguous
+//     runs (all 5 frequency taps x C channels of one frame are ONE run) -> 16-byte coalesced loads, no im2col;
+//   * a complex conv is one real GEMM with the block weight [[Wr,-Wi],[Wi,Wr]] (same MACs as the reference's 4 convs);
+//   * the transposed conv is two dense sub-pixel GEMMs (even / odd output rows), never a scatter;
+//   * complex_cat / chunk / permute / reshape glue of the reference (23 % of its CPU step) is index arithmetic in the
+//     run descriptors: the skip connection is a second source pointer, the LSTM feature order c*D+d is a weight permutation;
+//   * decoder buffers keep the extra frame that `out[..., 1:]` drops, because BatchNorm statistics include it.
+#include "plan.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+namespace sefd {
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+inline int64_t rup(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+struct Builder {
+  Plan* P;
+  ModelConfig c;
+  int64_t ws_off = 0;
+  int64_t io_off = 0;
+  std::map<std::string, int> pidx, sidx;
+
+  // gradient partial region (allocated at the end) and the inverse (unpack) table
+  int64_t gp_off = 0;                                     // floats
+  struct Fix { int op; int64_t rel; int which; };         // which: 0 -> op.g.w, 1 -> op.unpack.part
+  std::vector<Fix> fixes;
+  std::vector<std::vector<int32_t>> inv;                  // per trainable element: signed (gp-relative position + 1)
+
+  Ptr mk(int arena, int64_t off) { Ptr p; p.arena = arena; p.pad_ = 0; p.off = off; return p; }
+  Ptr none() { return mk(A_NONE, 0); }
+
+  Ptr ws(const std::string& name, int64_t elems, int dt) {
+    const int64_t bytes = rup(elems * esize(dt), 256);
+    Ptr p = mk(A_WS, ws_off);
+    P->bufs[name] = BufInfo{ws_off, elems * esize(dt), dt};
+    ws_off += bytes;
+    return p;
+  }
+  Ptr io(const std::string& name, int64_t elems) {
+    Ptr p = mk(A_IO, io_off);
+    P->bufs["io." + name] = BufInfo{io_off, elems * 4, DT_F32};
+    io_off += rup(elems * 4, 256);
+    return p;
+  }
+  Ptr cst(const void* data, int64_t bytes) {
+    const int64_t off = rup((int64_t)P->consts.size(), 256);
+    P->consts.resize(off + bytes);
+    std::memcpy(P->consts.data() + off, data, bytes);
+    return mk(A_CONST, off);
+  }
+  void add_param(const std::string& name, std::vector<int64_t> shape, bool trainable) {
+    ParamInfo pi;
+    pi.name = name;
+    pi.shape = shape;
+    pi.numel = 1;
+    for (auto s : shape) pi.numel *= s;
+    auto& vec = trainable ? P->params : P->state;
+    pi.arena = trainable ? A_PARAM : A_STATE;
+    pi.off = vec.empty() ? 0 : vec.back().off + vec.back().numel;
+    (trainable ? pidx : sidx)[name] = (int)vec.size();
+    vec.push_back(pi);
+  }
+  const ParamInfo& par(const std::string& n) const {
+    auto it = pidx.find(n);
+    if (it == pidx.end()) { P->error = "missing param " + n; static ParamInfo z; return z; }
+    return P->params[it->second];
+  }
+  Ptr pptr(const std::string& n, int arena = A_PARAM) { return mk(arena, par(n).off * 4); }
+  Ptr sptr(const std::string& n) { return mk(A_STATE, P->state[sidx.at(n)].off * 4); }
+
+  Op& push(std::vector<Op>& v, int kind, int tag) {
+    Op op;
+    std::memset(&op, 0, sizeof(op));
+    op.kind = kind;
+    op.tag = tag;
+    v.push_back(op);
+    return v.back();
+  }
+
+  static RunGemm gemm0() {
+    RunGemm g;
+    std::memset(&g, 0, sizeof(g));
+    g.x[0].arena = g.x[1].arena = g.w.arena = g.bias.arena = g.y.arena = g.stats.arena = A_NONE;
+    g.nsplit = 1;
+    return g;
+  }
+  // lay out run segments: assigns koff (padded to the K-tile of the operand dtype) and ldw
+  static void layout_segs(RunGemm& g) {
+    const int bk = bk_of(g.xdt);
+    int k = 0;
+    for (int s = 0; s < g.nseg; ++s) { g.seg[s].koff = k; k += (int)rup(g.seg[s].len, bk); }
+    g.ldw = k;
+    g.Npad = (int)rup(g.N, bn_of(g.N));
+  }
+
+  using Coef = std::function<int32_t(int n, int seg, int j)>;   // signed 1-based flat param element, 0 = structural zero
+
+  // PACK op for the weights of `g` (fills g.w), optional bias table (width 2) -> g.bias
+  void pack_weights(std::vector<Op>& ops, RunGemm& g, const Coef& coef, const std::string& name, int tag,
+                    const std::function<void(int n, int32_t out[2])>* bias = nullptr) {
+    std::vector<int32_t> tab((size_t)g.Npad * g.ldw, 0);
+    for (int n = 0; n < g.N; ++n)
+      for (int s = 0; s < g.nseg; ++s)
+        if (g.seg[s].src >= 0)
+          for (int j = 0; j < g.seg[s].len; ++j) tab[(size_t)n * g.ldw + g.seg[s].koff + j] = coef(n, s, j);
+    g.w = ws("w." + name, (int64_t)tab.size(), g.xdt);
+    Op& op = push(ops, OP_PACK, tag);
+    op.pack.tab = cst(tab.data(), (int64_t)tab.size() * 4);
+    op.pack.src = mk(A_PARAM, 0);
+    op.pack.dst = g.w;
+    op.pack.n = (int64_t)tab.size();
+    op.pack.ddt = g.xdt;
+    op.pack.width = 1;
+    if (bias) {
+      std::vector<int32_t> bt((size_t)g.N * 2, 0);
+      for (int n = 0; n < g.N; ++n) (*bias)(n, &bt[(size_t)n * 2]);
+      g.bias = ws("b." + name, g.N, DT_F32);
+      Op& ob = push(ops, OP_PACK, tag);
+      ob.pack.tab = cst(bt.data(), (int64_t)bt.size() * 4);
+      ob.pack.src = mk(A_PARAM, 0);
+      ob.pack.dst = g.bias;
+      ob.pack.n = g.N;
+      ob.pack.ddt = DT_F32;
+      ob.pack.width = 2;
+    }
+  }
+
+  // WGRAD for the layer whose forward descriptor is `f` (same A runs + a ones run) against upstream gradient `dy`.
+  void wgrad(std::vector<Op>& ops, const RunGemm& f, Ptr dy, const Coef& coef, int tag,
+             const std::function<void(int n, int32_t out[2])>* bias) {
+    RunGemm g = f;
+    g.xdt = DT_F32;   // TODO(bf16): transposing bf16 WGRAD variant; planner keeps WGRAD operands fp32 for now
+    if (bias && g.nseg < kMaxSeg) {
+      Seg& o = g.seg[g.nseg++];
+      o.src = -1; o.dt = 0; o.off = 0; o.len = 1; o.koff = 0;
+    }
+    layout_segs(g);
+    g.y = dy;
+    g.bias = none();
+    g.stats = none();
+    const int tiles = (int)(rup(g.Npad, kWgTN) / kWgTN * rup(g.ldw, kWgTK) / kWgTK);
+    const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
+    int ns = (768 + tiles - 1) / tiles;
+    ns = std::max(1, std::min(ns, std::max(1, steps / 4)));
+    g.nsplit = ns;
+    const int64_t sz = (int64_t)g.Npad * g.ldw;
+    const int64_t rel = gp_off;
+    gp_off += sz * ns;
+    Op& op = push(ops, OP_WGRAD, tag);
+    op.g = g;
+    fixes.push_back(Fix{(int)ops.size() - 1, rel, 0});
+    if (ns > 1) {
+      Op& os = push(ops, OP_SPLITSUM, tag);
+      os.unpack.n = sz;
+      os.unpack.sstride = sz;
+      os.unpack.nsplit = ns;
+      os.unpack.start = os.unpack.ent = os.unpack.dst = none();
+      fixes.push_back(Fix{(int)ops.size() - 1, rel, 1});
+    }
+    // inverse table
+    for (int n = 0; n < g.N; ++n) {
+      for (int s = 0; s < g.nseg; ++s) {
+        if (g.seg[s].src >= 0) {
+          for (int j = 0; j < g.seg[s].len; ++j) {
+            const int32_t t = coef(n, s, j);
+            if (t == 0) continue;
+            const int64_t pos = rel + (int64_t)n * g.ldw + g.seg[s].koff + j + 1;
+            assert(pos < (1LL << 31));
+            inv[std::abs(t) - 1].push_back((int32_t)(t > 0 ? pos : -pos));
+          }
+        } else if (bias) {
+          int32_t bt[2] = {0, 0};
+          (*bias)(n, bt);
+          const int64_t pos = rel + (int64_t)n * g.ldw + g.seg[s].koff + 1;
+          for (int e = 0; e < 2; ++e)
+            if (bt[e] != 0) inv[std::abs(bt[e]) - 1].push_back((int32_t)(bt[e] > 0 ? pos : -pos));
+        }
+      }
+    }
+  }
+
+  void finish_unpack(std::vector<Op>& ops) {
+    Ptr base = ws("gradpart", std::max<int64_t>(gp_off, 1), DT_F32);
+    for (auto& f : fixes) {
+      Ptr p = mk(A_WS, base.off + f.rel * 4);
+      if (f.which == 0) ops[f.op].g.w = p; else ops[f.op].unpack.part = p;
+    }
+    const int64_t n = (int64_t)inv.size();
+    std::vector<int32_t> start(n + 1, 0), ent;
+    for (int64_t j = 0; j < n; ++j) {
+      start[j] = (int32_t)ent.size();
+      for (auto e : inv[j]) ent.push_back(e);
+    }
+    start[n] = (int32_t)ent.size();
+    if (ent.empty()) ent.push_back(0);
+    Op& op = push(ops, OP_UNPACK, 999);
+    op.unpack.start = cst(start.data(), (int64_t)start.size() * 4);
+    op.unpack.ent = cst(ent.data(), (int64_t)ent.size() * 4);
+    op.unpack.part = base;
+    op.unpack.dst = mk(A_GRAD, 0);
+    op.unpack.n = n;
+    op.unpack.sstride = 0;
+    op.unpack.nsplit = 1;
+  }
+};
+
+int32_t pe(const ParamInfo& p, int64_t idx, int sign = 1) { return (int32_t)(sign * (p.off + idx + 1)); }
+
+}  // namespace
+
+// =================================================================================================================
+Plan* build_dccrn_plan(const ModelConfig& cfg) {
+  Plan* P = new Plan();
+  P->cfg = cfg;
+  Builder b;
+  b.P = P;
+  b.c = cfg;
+  const int n = cfg.n_layers;
+  const int B = cfg.B, L = cfg.L, W = cfg.win_len, hop = cfg.hop, NFFT = cfg.fft_len;
+  const int trim = W - hop;
+  const int T = (L + 2 * trim - W) / hop + 1;
+  const int NF = NFFT / 2 + 1, NS = NF + 1, SW = NS * 2;
+  const int Lp = (T - 1) * hop + W;
+  const int adt = cfg.act_dtype;
+  const int KS = cfg.kernel_size;
+  P->T = T;
+  P->NF = NF;
+  if (cfg.model != 0 || !cfg.lstm_complex || KS != 5 || n < 1 || n > 7) { P->error = "unsupported configuration"; return P; }
+  std::vector<int> ch(n + 1), Fe(n + 1);
+  ch[0] = 2;
+  for (int i = 0; i < n; ++i) ch[i + 1] = cfg.kernel_num[i];
+  Fe[0] = NF - 1;
+  for (int i = 0; i < n; ++i) Fe[i + 1] = Fe[i] / 2;
+  const int D = Fe[n];                       // hidden_dim (models.py:81)
+  const int H = cfg.rnn_units / 2;           // per-part hidden size of the complex LSTM
+  const int NL = cfg.rnn_layers;
+  const int Cl = ch[n];                      // channels entering the LSTM
+  for (int i = 1; i <= n; ++i)
+    if (ch[i] % 8 != 0 && !(i == 0)) { P->error = "channel counts must be multiples of 8"; return P; }
+  if (H % 16 != 0 || H > 128) { P->error = "rnn_units/2 must be a multiple of 16 and <= 128"; return P; }
+  if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
+
+  // ------------------------------------------------------------------ parameters (reference registration order)
+  for (int i = 0; i < n; ++i) {
+    const std::string p = "encoder." + std::to_string(i);
+    for (const char* part : {"real_conv", "imag_conv"}) {
+      b.add_param(p + ".0." + part + ".weight", {ch[i + 1] / 2, ch[i] / 2, KS, 2}, true);
+      b.add_param(p + ".0." + part + ".bias", {ch[i + 1] / 2}, true);
+    }
+    b.add_param(p + ".1.weight", {ch[i + 1]}, true);
+    b.add_param(p + ".1.bias", {ch[i + 1]}, true);
+    b.add_param(p + ".1.running_mean", {ch[i + 1]}, false);
+    b.add_param(p + ".1.running_var", {ch[i + 1]}, false);
+    b.add_param(p + ".2.weight", {1}, true);
+  }
+  for (int d = 0; d < n; ++d) {
+    const int idx = n - d;
+    const int cin = ch[idx] * (cfg.skip ? 2 : 1), cout = ch[idx - 1];
+    const std::string p = "decoder." + std::to_string(d);
+    for (const char* part : {"real_conv", "imag_conv"}) {
+      b.add_param(p + ".0." + part + ".weight", {cin / 2, cout / 2, KS, 2}, true);
+      b.add_param(p + ".0." + part + ".bias", {cout / 2}, true);
+    }
+    if (idx != 1) {
+      b.add_param(p + ".1.weight", {cout}, true);
+      b.add_param(p + ".1.bias", {cout}, true);
+      b.add_param(p + ".1.running_mean", {cout}, false);
+      b.add_param(p + ".1.running_var", {cout}, false);
+      b.add_param(p + ".2.weight", {1}, true);
+    }
+  }
+  const int hid = D * Cl;                    // LSTM feature size real+imag
+  for (int l = 0; l < NL; ++l) {
+    const int I = (l == 0 ? hid : cfg.rnn_units) / 2;
+    const std::string p = "enhance." + std::to_string(l);
+    for (const char* part : {"real_lstm", "imag_lstm"}) {
+      b.add_param(p + "." + part + ".weight_ih_l0", {4 * H, I}, true);
+      b.add_param(p + "." + part + ".weight_hh_l0", {4 * H, H}, true);
+      b.add_param(p + "." + part + ".bias_ih_l0", {4 * H}, true);
+      b.add_param(p + "." + part + ".bias_hh_l0", {4 * H}, true);
+    }
+    if (l == NL - 1)
+      for (const char* part : {"r_trans", "i_trans"}) {
+        b.add_param(p + "." + part + ".weight", {hid / 2, H}, true);
+        b.add_param(p + "." + part + ".bias", {hid / 2}, true);
+      }
+  }
+  const int64_t nparam = P->params.back().off + P->params.back().numel;
+  const int64_t nstate = P->state.empty() ? 0 : P->state.back().off + P->state.back().numel;
+  b.inv.resize(nparam);
+
+  // ------------------------------------------------------------------ I/O block
+  Ptr io_wav = b.io("wav", (int64_t)B * L);
+  Ptr io_out = b.io("out_wav", (int64_t)B * L);
+  Ptr io_or = b.io("out_real", (int64_t)B * NF * T);
+  Ptr io_oi = b.io("out_imag", (int64_t)B * NF * T);
+  Ptr io_gw = b.io("grad_wav", (int64_t)B * L);
+  Ptr io_gr = b.io("grad_real", (int64_t)B * NF * T);
+  Ptr io_gi = b.io("grad_imag", (int64_t)B * NF * T);
+
+  // ------------------------------------------------------------------ constants: STFT bases, OLA normaliser
+  // analysis basis (tools_for_model.py:16-33): K[part*NF+k][j] = w[j]*{cos,-sin}(2 pi k j / NFFT); periodic Hann
+  std::vector<double> win(W);
+  for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  auto Kun = [&](int part, int k, int j) {
+    const double ang = 2.0 * kPi * (double)(((int64_t)k * j) % NFFT) / NFFT;
+    return part == 0 ? std::cos(ang) : -std::sin(ang);
+  };
+  // synthesis basis = pinv(K_unwindowed)^T * w, closed form: K^T K = (NFFT/2) I + E, E[n][m] = [n-m even]
+  //   pinv(K)[j][r] = (K[r][j] - sum_{m == j mod 2} K[r][m] / (NFFT/2 + |{m == j mod 2}|)) / (NFFT/2)
+  std::vector<double> Kinv((size_t)2 * NF * W);
+  {
+    const double ne = (W + 1) / 2, no = W / 2;
+    for (int part = 0; part < 2; ++part)
+      for (int k = 0; k < NF; ++k) {
+        double se = 0, so = 0;
+        for (int m = 0; m < W; ++m) (m % 2 == 0 ? se : so) += Kun(part, k, m);
+        for (int j = 0; j < W; ++j) {
+          const double corr = (j % 2 == 0) ? se / (NFFT / 2.0 + ne) : so / (NFFT / 2.0 + no);
+          Kinv[((size_t)part * NF + k) * W + j] = (Kun(part, k, j) - corr) / (NFFT / 2.0) * win[j];
+        }
+      }
+  }
+  std::vector<float> coff(Lp, 0.f);
+  {
+    std::vector<float> w2(W);
+    for (int j = 0; j < W; ++j) { const float wf = (float)win[j]; w2[j] = wf * wf; }
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < W; ++j) coff[t * hop + j] += w2[j];
+  }
+  Ptr c_coff = b.cst(coff.data(), (int64_t)coff.size() * 4);
+
+  auto const_weights = [&](RunGemm& g, const std::function<double(int n, int j)>& val) {
+    std::vector<float> wt((size_t)g.Npad * g.ldw, 0.f);
+    for (int nn = 0; nn < g.N; ++nn)
+      for (int j = 0; j < g.seg[0].len; ++j) wt[(size_t)nn * g.ldw + j] = (float)val(nn, j);
+    g.w = b.cst(wt.data(), (int64_t)wt.size() * 4);
+  };
+
+  std::vector<Op>& F = P->fwd;
+  std::vector<Op>& R = P->bwd;
+
+  // ------------------------------------------------------------------ STFT (ConvSTFT.forward, tools_for_model.py:54-61)
+  Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
+  {
+    RunGemm g = Builder::gemm0();
+    g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
+    g.bstride[0] = L; g.tstride[0] = 0; g.base[0] = 0; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
+    g.M = B * T; g.Tout = 1; g.Fo = T;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, -trim, W, 0};
+    g.N = SW;
+    Builder::layout_segs(g);
+    const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kun(nn & 1, nn / 2 - 1, j) * win[j]; });
+    g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_tstride = 0; g.y_fstride = SW; g.y_off = 0;
+    b.push(F, OP_RUNGEMM, 1).g = g;
+  }
+
+  // ------------------------------------------------------------------ encoder
+  struct Layer { RunGemm f[2]; Builder::Coef coef[2]; std::function<void(int, int32_t*)> bias; bool has_bias_fn; Ptr y, z, mi; int C, Fq; int64_t R; };
+  std::vector<Layer> enc(n), dec(n);
+  std::vector<Ptr> encz(n), ency(n), enc_mi(n);
+  Ptr prev = spec;
+  for (int i = 0; i < n; ++i) {
+    const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
+    const std::string nm = "enc" + std::to_string(i);
+    const std::string pp = "encoder." + std::to_string(i);
+    const ParamInfo &Wr = b.par(pp + ".0.real_conv.weight"), &Wi = b.par(pp + ".0.imag_conv.weight");
+    const ParamInfo &br = b.par(pp + ".0.real_conv.bias"), &bi = b.par(pp + ".0.imag_conv.bias");
+    RunGemm g = Builder::gemm0();
+    g.x[0] = prev;
+    g.xdt = (i == 0) ? DT_F32 : adt;
+    g.ydt = adt;
+    if (i == 0) { g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.base[0] = 4; }
+    else { g.bstride[0] = (int64_t)T * Fi * Ci; g.tstride[0] = Fi * Ci; g.base[0] = 0; }
+    g.rowlen[0] = Fi * Ci; g.fstride[0] = 2 * Ci; g.Tin[0] = T;
+    g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;
+    g.nseg = 2;
+    g.seg[0] = Seg{0, -1, -2 * Ci, KS * Ci, 0};   // kw = 0 : frame t-1
+    g.seg[1] = Seg{0, 0, -2 * Ci, KS * Ci, 0};    // kw = 1 : frame t
+    g.N = Co;
+    Builder::layout_segs(g);
+    const int Ci2 = Ci / 2, Co2 = Co / 2;
+    Builder::Coef coef = [=](int nn, int s, int j) -> int32_t {
+      const int kw = s, kh = j / Ci, ci = j % Ci;
+      const bool oi = nn >= Co2, ii = ci >= Ci2;
+      const int co2 = oi ? nn - Co2 : nn, ci2 = ii ? ci - Ci2 : ci;
+      const int64_t idx = (((int64_t)co2 * Ci2 + ci2) * KS + kh) * 2 + kw;
+      if (!oi) return ii ? pe(Wi, idx, -1) : pe(Wr, idx, 1);
+      return ii ? pe(Wr, idx, 1) : pe(Wi, idx, 1);
+    };
+    std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) {
+      if (nn < Co2) { o[0] = pe(br, nn, 1); o[1] = pe(bi, nn, -1); }
+      else { o[0] = pe(br, nn - Co2, 1); o[1] = pe(bi, nn - Co2, 1); }
+    };
+    b.pack_weights(F, g, coef, nm, 100 + i, &bias);
+    const int64_t Rr = (int64_t)B * T * Fo;
+    ency[i] = b.ws(nm + ".y", Rr * Co, adt);
+    encz[i] = b.ws(nm + ".z", Rr * Co, adt);
+    enc_mi[i] = b.ws(nm + ".mi", 2 * Co, DT_F32);
+    const int nblk = (int)((g.M + kBM - 1) / kBM);
+    Ptr part = b.ws(nm + ".stat", (int64_t)nblk * 2 * g.Npad, DT_F32);
+    g.y = ency[i]; g.y_bstride = (int64_t)T * Fo * Co; g.y_tstride = Fo * Co; g.y_fstride = Co; g.y_off = 0;
+    g.stats = cfg.training ? part : b.none();
+    b.push(F, OP_RUNGEMM, 100 + i).g = g;
+    {
+      Op& op = b.push(F, OP_BN_FINALIZE, 100 + i);
+      op.bnf.part = part; op.bnf.mean_invstd = enc_mi[i];
+      op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
+      op.bnf.nblk = cfg.training ? nblk : -1; op.bnf.C = Co; op.bnf.Cpad = g.Npad; op.bnf.count = (double)Rr;
+      op.bnf.eps = 1e-5f; op.bnf.momentum = 0.1f;
+    }
+    {
+      Op& op = b.push(F, OP_BN_APPLY, 100 + i);
+      op.bna.y = ency[i]; op.bna.z = encz[i]; op.bna.mean_invstd = enc_mi[i];
+      op.bna.gamma = b.pptr(pp + ".1.weight"); op.bna.beta = b.pptr(pp + ".1.bias"); op.bna.slope = b.pptr(pp + ".2.weight");
+      op.bna.R = Rr; op.bna.C = Co; op.bna.dt = adt;
+    }
+    enc[i].f[0] = g; enc[i].coef[0] = coef; enc[i].bias = bias; enc[i].C = Co; enc[i].Fq = Fo; enc[i].R = Rr;
+    prev = encz[i];
+  }
+
+  // ------------------------------------------------------------------ complex LSTM stack (tools_for_model.py:141-181)
+  const int64_t BT = (int64_t)B * T;
+  struct Lstm { RunGemm gx[2]; Builder::Coef cgx[2]; std::function<void(int, int32_t*)> bgx; Ptr gxb, h, gates, cst, hc; RunGemm hh[4]; Builder::Coef chh[4]; };
+  std::vector<Lstm> ls(NL);
+  Ptr lin = encz[n - 1];
+  for (int l = 0; l < NL; ++l) {
+    const std::string nm = "lstm" + std::to_string(l);
+    const std::string pp = "enhance." + std::to_string(l);
+    const ParamInfo* Wih[2] = {&b.par(pp + ".real_lstm.weight_ih_l0"), &b.par(pp + ".imag_lstm.weight_ih_l0")};
+    const ParamInfo* bih[2] = {&b.par(pp + ".real_lstm.bias_ih_l0"), &b.par(pp + ".imag_lstm.bias_ih_l0")};
+    const ParamInfo* bhh[2] = {&b.par(pp + ".real_lstm.bias_hh_l0"), &b.par(pp + ".imag_lstm.bias_hh_l0")};
+    const int I = (l == 0 ? hid : 2 * H) / 2;      // features per part
+    const int rowlen = l == 0 ? D * Cl : 2 * H;
+    ls[l].gxb = b.ws(nm + ".gx", 2 * BT * 8 * H, DT_F32);
+    ls[l].h = b.ws(nm + ".h", 4 * BT * H, adt);
+    ls[l].gates = b.ws(nm + ".gates", 4 * BT * 4 * H, DT_F32);
+    ls[l].cst = b.ws(nm + ".c", 4 * BT * H, DT_F32);
+    ls[l].hc = b.ws(nm + ".hc", BT * 2 * H, adt);
+    std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) {
+      const int set = nn / (4 * H), gq = nn % (4 * H);
+      o[0] = pe(*bih[set], gq, 1); o[1] = pe(*bhh[set], gq, 1);
+    };
+    ls[l].bgx = bias;
+    for (int p = 0; p < 2; ++p) {
+      RunGemm g = Builder::gemm0();
+      g.x[0] = lin; g.xdt = adt; g.ydt = DT_F32;
+      g.bstride[0] = (int64_t)T * rowlen; g.tstride[0] = rowlen; g.base[0] = 0; g.rowlen[0] = rowlen; g.fstride[0] = 0; g.Tin[0] = T;
+      g.M = (int)BT; g.Tout = T; g.Fo = 1;
+      if (l == 0) {
+        g.nseg = D;
+        for (int dd = 0; dd < D; ++dd) g.seg[dd] = Seg{0, 0, dd * Cl + p * (Cl / 2), Cl / 2, 0};
+      } else {
+        g.nseg = 1;
+        g.seg[0] = Seg{0, 0, p * H, H, 0};
+      }
+      g.N = 8 * H;
+      Builder::layout_segs(g);
+      Builder::Coef coef = [=](int nn, int s, int j) -> int32_t {
+        const int set = nn / (4 * H), gq = nn % (4 * H);
+        const int feat = (l == 0) ? j * D + s : j;      // reference feature order c*D + d (models.py:203-206)
+        return pe(*Wih[set], (int64_t)gq * I + feat, 1);
+      };
+      b.pack_weights(F, g, coef, nm + ".ih" + std::to_string(p), 200 + l, p == 0 ? &bias : nullptr);
+      if (p == 1) g.bias = ls[l].gx[0].bias;
+      g.y = b.mk(A_WS, ls[l].gxb.off + (int64_t)p * BT * 8 * H * 4);
+      g.y_bstride = (int64_t)T * 8 * H; g.y_tstride = 8 * H; g.y_fstride = 0; g.y_off = 0;
+      b.push(F, OP_RUNGEMM, 200 + l).g = g;
+      ls[l].gx[p] = g; ls[l].cgx[p] = coef;
+    }
+    {
+      Op& op = b.push(F, OP_LSTM_FWD, 200 + l);
+      LstmRec& r = op.lstm;
+      r.gx = ls[l].gxb;
+      r.whh[0] = b.pptr(pp + ".real_lstm.weight_hh_l0"); r.whh[1] = b.pptr(pp + ".imag_lstm.weight_hh_l0");
+      r.h = ls[l].h; r.gates = ls[l].gates; r.c = ls[l].cst;
+      r.dh = r.dgates = b.none();
+      for (int g4 = 0; g4 < 4; ++g4) r.gx_goff[g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
+      r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = DT_F32;
+    }
+    {
+      Op& op = b.push(F, OP_COMBINE_FWD, 200 + l);
+      op.comb.h = ls[l].h; op.comb.out = ls[l].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt;
+    }
+    lin = ls[l].hc;
+  }
+  // projection r_trans / i_trans (tools_for_model.py:173-175) writing the decoder input [B][T][D][Cl] directly
+  Ptr decin = b.ws("decin", BT * D * Cl, adt);
+  RunGemm proj = Builder::gemm0();
+  Builder::Coef cproj;
+  std::function<void(int, int32_t*)> bproj;
+  {
+    const std::string pp = "enhance." + std::to_string(NL - 1);
+    const ParamInfo* Wt[2] = {&b.par(pp + ".r_trans.weight"), &b.par(pp + ".i_trans.weight")};
+    const ParamInfo* bt[2] = {&b.par(pp + ".r_trans.bias"), &b.par(pp + ".i_trans.bias")};
+    RunGemm& g = proj;
+    g.x[0] = lin; g.xdt = adt; g.ydt = adt;
+    g.bstride[0] = (int64_t)T * 2 * H; g.tstride[0] = 2 * H; g.rowlen[0] = 2 * H; g.Tin[0] = T;
+    g.M = (int)BT; g.Tout = T; g.Fo = 1;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, 0, 2 * H, 0};
+    g.N = D * Cl;
+    Builder::layout_segs(g);
+    const int Ch = Cl / 2;
+    cproj = [=](int nn, int s, int j) -> int32_t {
+      const int dd = nn / Cl, rem = nn % Cl, p = rem / Ch, cc = rem % Ch;
+      if ((j >= H) != (p == 1)) return 0;
+      return pe(*Wt[p], (int64_t)(cc * D + dd) * H + (j - p * H), 1);
+    };
+    bproj = [=](int nn, int32_t* o) {
+      const int dd = nn / Cl, rem = nn % Cl, p = rem / Ch, cc = rem % Ch;
+      o[0] = pe(*bt[p], cc * D + dd, 1); o[1] = 0;
+    };
+    b.pack_weights(F, g, cproj, "proj", 300, &bproj);
+    g.y = decin; g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl; g.y_fstride = 0; g.y_off = 0;
+    b.push(F, OP_RUNGEMM, 300).g = g;
+  }
+
+  // ------------------------------------------------------------------ decoder (models.py:222-226; sub-pixel phases)
+  std::vector<Ptr> decy(n), decz(n), dec_mi(n);
+  struct DecSrc { Ptr p; int64_t bstride; int tstride, base, C; };
+  DecSrc dprev{decin, (int64_t)T * D * Cl, D * Cl, 0, Cl};
+  for (int d = 0; d < n; ++d) {
+    const int idx = n - d;
+    const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
+    const int Fi = Fe[idx], Fo = 2 * Fi;
+    const bool last = (idx == 1);
+    const std::string nm = "dec" + std::to_string(d);
+    const std::string pp = "decoder." + std::to_string(d);
+    const ParamInfo &Wr = b.par(pp + ".0.real_conv.weight"), &Wi = b.par(pp + ".0.imag_conv.weight");
+    const ParamInfo &br = b.par(pp + ".0.real_conv.bias"), &bi = b.par(pp + ".0.imag_conv.bias");
+    const int Co2 = Co / 2, Cin2 = (C0 + C1) / 2;
+    const int64_t Rr = (int64_t)B * (T + 1) * Fo;
+    decy[d] = b.ws(nm + ".y", Rr * Co, adt);
+    if (!last) { decz[d] = b.ws(nm + ".z", Rr * Co, adt); dec_mi[d] = b.ws(nm + ".mi", 2 * Co, DT_F32); }
+    // reference input-channel index (within the real or imag half) of channel c of source s (complex_cat order)
+    auto refc = [=](int s, int cc, bool& imag) {
+      const int Cs = s == 0 ? C0 : C1;
+      imag = cc >= Cs / 2;
+      const int q = imag ? cc - Cs / 2 : cc;
+      return s == 0 ? q : C0 / 2 + q;
+    };
+    std::function<int32_t(int, int, int, int, int)> wcoef = [=](int nn, int s, int cc, int kh, int kw) -> int32_t {
+      bool ii;
+      const int rc = refc(s, cc, ii);
+      const bool oi = nn >= Co2;
+      const int co2 = oi ? nn - Co2 : nn;
+      const int64_t ix = (((int64_t)rc * Co2 + co2) * KS + kh) * 2 + kw;
+      if (!oi) return ii ? pe(Wi, ix, -1) : pe(Wr, ix, 1);
+      return ii ? pe(Wr, ix, 1) : pe(Wi, ix, 1);
+    };
+    std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) {
+      if (nn < Co2) { o[0] = pe(br, nn, 1); o[1] = pe(bi, nn, -1); }
+      else { o[0] = pe(br, nn - Co2, 1); o[1] = pe(bi, nn - Co2, 1); }
+    };
+    (void)Cin2;
+    const int nblk1 = (int)(((int64_t)B * (T + 1) * Fi + kBM - 1) / kBM);
+    Ptr part = b.none();
+    int npad_stat = (int)rup(Co, bn_of(Co));
+    if (!last) part = b.ws(nm + ".stat", (int64_t)2 * nblk1 * 2 * npad_stat, DT_F32);
+    for (int par = 0; par < 2; ++par) {
+      RunGemm g = Builder::gemm0();
+      g.xdt = adt; g.ydt = adt;
+      const int nsrc = cfg.skip ? 2 : 1;
+      DecSrc src[2] = {dprev, DecSrc{encz[idx - 1], (int64_t)T * Fi * C1, Fi * C1, 0, C1}};
+      g.nseg = 0;
+      const int ntap = par == 0 ? 3 : 2;
+      for (int s = 0; s < nsrc; ++s) {
+        g.x[s] = src[s].p; g.bstride[s] = src[s].bstride; g.tstride[s] = src[s].tstride; g.base[s] = src[s].base;
+        g.rowlen[s] = Fi * src[s].C; g.fstride[s] = src[s].C; g.Tin[s] = T;
+        for (int kw = 0; kw < 2; ++kw) g.seg[g.nseg++] = Seg{s, -kw, par == 0 ? -src[s].C : 0, ntap * src[s].C, 0};
+      }
+      g.M = B * (T + 1) * Fi; g.Tout = T + 1; g.Fo = Fi;
+      g.N = Co;
+      Builder::layout_segs(g);
+      const int c0 = C0, c1 = C1;
+      Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+        const int s = sg / 2, kw = sg % 2;
+        const int Cs = s == 0 ? c0 : c1;
+        const int jj = j / Cs, cc = j % Cs;
+        const int kh = par == 0 ? 4 - 2 * jj : 3 - 2 * jj;
+        return wcoef(nn, s, cc, kh, kw);
+      };
+      b.pack_weights(F, g, coef, nm + ".p" + std::to_string(par), 400 + d, par == 0 ? &bias : nullptr);
+      if (par == 1) g.bias = dec[d].f[0].bias;
+      g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Co; g.y_tstride = Fo * Co; g.y_fstride = 2 * Co; g.y_off = par * Co;
+      if (!last && cfg.training) g.stats = b.mk(A_WS, part.off + (int64_t)par * nblk1 * 2 * g.Npad * 4);
+      b.push(F, OP_RUNGEMM, 400 + d).g = g;
+      dec[d].f[par] = g; dec[d].coef[par] = coef;
+    }
+    dec[d].bias = bias; dec[d].C = Co; dec[d].Fq = Fo; dec[d].R = Rr;
+    if (!last) {
+      Op& op = b.push(F, OP_BN_FINALIZE, 400 + d);
+      op.bnf.part = part; op.bnf.mean_invstd = dec_mi[d];
+      op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
+      op.bnf.nblk = cfg.training ? 2 * nblk1 : -1; op.bnf.C = Co; op.bnf.Cpad = npad_stat; op.bnf.count = (double)Rr;
+      op.bnf.eps = 1e-5f; op.bnf.momentum = 0.1f;
+      Op& oa = b.push(F, OP_BN_APPLY, 400 + d);
+      oa.bna.y = decy[d]; oa.bna.z = decz[d]; oa.bna.mean_invstd = dec_mi[d];
+      oa.bna.gamma = b.pptr(pp + ".1.weight"); oa.bna.beta = b.pptr(pp + ".1.bias"); oa.bna.slope = b.pptr(pp + ".2.weight");
+      oa.bna.R = Rr; oa.bna.C = Co; oa.bna.dt = adt;
+      dprev = DecSrc{decz[d], (int64_t)(T + 1) * Fo * Co, Fo * Co, Fo * Co, Co};   // frames 1..T of the T+1 buffer
+    }
+  }
+
+  // ------------------------------------------------------------------ mask, iSTFT, outputs (models.py:253-282)
+  Ptr est = b.ws("est", BT * SW, DT_F32);
+  Ptr frames = b.ws("frames", BT * W, DT_F32);
+  Mask mk;
+  std::memset(&mk, 0, sizeof(mk));
+  {
+    const int Fo = Fe[0], Co = 2;
+    mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.dest = mk.dmask = b.none();
+    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt;
+    mk.mask_fstride = (int64_t)Fo * Co; mk.mask_bstride = (int64_t)(T + 1) * Fo * Co; mk.mask_base = (int64_t)Fo * Co; mk.T = T;
+    b.push(F, OP_MASK_FWD, 500).mask = mk;
+  }
+  RunGemm gi = Builder::gemm0();
+  {
+    RunGemm& g = gi;
+    g.x[0] = est; g.xdt = DT_F32; g.ydt = DT_F32;
+    g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.rowlen[0] = SW; g.Tin[0] = T;
+    g.M = (int)BT; g.Tout = T; g.Fo = 1;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, 0, SW, 0};
+    g.N = W;
+    Builder::layout_segs(g);
+    const_weights(g, [&](int nn, int j) { return j < 2 ? 0.0 : Kinv[((size_t)(j & 1) * NF + (j / 2 - 1)) * W + nn]; });
+    g.y = frames; g.y_bstride = (int64_t)T * W; g.y_tstride = W;
+    b.push(F, OP_RUNGEMM, 501).g = g;
+  }
+  Ola ola;
+  std::memset(&ola, 0, sizeof(ola));
+  ola.frames = frames; ola.wav = io_out; ola.coff = c_coff; ola.dwav = ola.dpad = b.none();
+  ola.B = B; ola.T = T; ola.L = L; ola.win = W; ola.hop = hop; ola.trim = trim;
+  b.push(F, OP_OLA_FWD, 502).ola = ola;
+  SpecOut so;
+  std::memset(&so, 0, sizeof(so));
+  so.est = est; so.out_real = io_or; so.out_imag = io_oi; so.B = B; so.T = T; so.NF = NF; so.accumulate = 0;
+  b.push(F, OP_SPECOUT_FWD, 503).so = so;
+
+  // =================================================================================================== backward
+  if (cfg.training) {
+    Ptr dpad = b.ws("dpad", (int64_t)B * Lp, DT_F32);
+    Ptr dest = b.ws("dest", BT * SW, DT_F32);
+    {
+      Ola o = ola;
+      o.dwav = io_gw; o.dpad = dpad;
+      b.push(R, OP_OLA_BWD, 502).ola = o;
+      RunGemm g = Builder::gemm0();
+      g.x[0] = dpad; g.xdt = DT_F32; g.ydt = DT_F32;
+      g.bstride[0] = Lp; g.tstride[0] = 0; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
+      g.M = (int)BT; g.Tout = 1; g.Fo = T;
+      g.nseg = 1; g.seg[0] = Seg{0, 0, 0, W, 0};
+      g.N = SW;
+      Builder::layout_segs(g);
+      const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kinv[((size_t)(nn & 1) * NF + (nn / 2 - 1)) * W + j]; });
+      g.y = dest; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+      b.push(R, OP_RUNGEMM, 501).g = g;
+      SpecOut s2 = so;
+      s2.est = dest; s2.out_real = io_gr; s2.out_imag = io_gi; s2.accumulate = 1;
+      b.push(R, OP_SPECOUT_BWD, 503).so = s2;
+    }
+    // gradient buffers
+    std::vector<Ptr> d_decy(n), d_decz(n), d_skip(n), d_encz(n), d_ency(n);
+    for (int d = 0; d < n; ++d) {
+      const int idx = n - d;
+      const int Co = ch[idx - 1], Fo = 2 * Fe[idx];
+      d_decy[d] = b.ws("dec" + std::to_string(d) + ".dy", (int64_t)B * (T + 1) * Fo * Co, adt);
+      if (idx != 1) d_decz[d] = b.ws("dec" + std::to_string(d) + ".dz", (int64_t)B * T * Fo * Co, adt);
+    }
+    for (int i = 0; i < n; ++i) {
+      const int64_t e = (int64_t)B * T * Fe[i + 1] * ch[i + 1];
+      d_ency[i] = b.ws("enc" + std::to_string(i) + ".dy", e, adt);
+      d_encz[i] = b.ws("enc" + std::to_string(i) + ".dz", e, adt);
+      if (cfg.skip) d_skip[i] = b.ws("enc" + std::to_string(i) + ".dskip", e, adt);
+    }
+    Ptr d_decin = b.ws("decin.d", BT * D * Cl, adt);
+    {
+      Mask m2 = mk;
+      m2.dest = dest; m2.dmask = d_decy[n - 1];
+      b.push(R, OP_MASK_BWD, 500).mask = m2;
+    }
+    auto bn_bwd = [&](int tag, Ptr y, Ptr dz0, Ptr dz1, Ptr mi, const std::string& pp, int C, int64_t Rr, int64_t rpb, int skip, Ptr dy,
+                      const std::string& nm) {
+      int64_t rpbk = std::max<int64_t>(64, (Rr + 2047) / 2048);
+      const int nblk = (int)((Rr + rpbk - 1) / rpbk);
+      BnBwdReduce r;
+      std::memset(&r, 0, sizeof(r));
+      r.y = y; r.dz0 = dz0; r.dz1 = dz1; r.mean_invstd = mi;
+      r.gamma = b.pptr(pp + ".1.weight"); r.beta = b.pptr(pp + ".1.bias"); r.slope = b.pptr(pp + ".2.weight");
+      r.part = b.ws(nm + ".bnpart", (int64_t)nblk * 3 * C, DT_F32);
+      r.R = Rr; r.C = C; r.dt = adt; r.nblk = nblk; r.rows_per_blk = (int)rpbk; r.rpb = rpb; r.skip = skip;
+      b.push(R, OP_BN_BWD_REDUCE, tag).bnr = r;
+      BnBwdApply a;
+      std::memset(&a, 0, sizeof(a));
+      a.r = r; a.totals = b.ws(nm + ".bntot", 3 * C, DT_F32); a.dy = dy;
+      a.dgamma = b.pptr(pp + ".1.weight", A_GRAD); a.dbeta = b.pptr(pp + ".1.bias", A_GRAD); a.dslope = b.pptr(pp + ".2.weight", A_GRAD);
+      a.count = (double)Rr;
+      b.push(R, OP_BN_BWD_FINALIZE, tag).bnb = a;
+      b.push(R, OP_BN_BWD_APPLY, tag).bnb = a;
+    };
+
+    // ---- decoder backward
+    for (int d = n - 1; d >= 0; --d) {
+      const int idx = n - d;
+      const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
+      const int Fi = Fe[idx], Fo = 2 * Fi;
+      const bool last = (idx == 1);
+      const std::string nm = "dec" + std::to_string(d);
+      const std::string pp = "decoder." + std::to_string(d);
+      if (!last)
+        bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm);
+      // weight gradients of both sub-pixel phases; each phase also contributes its rows to the bias gradient (ones run)
+      for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
+      // input gradients: conv-form over dy [B][T+1][Fo][Co]; dx[ci,f,t] = sum W[ci,co,kh,kw] dy[co, 2f+kh-2, t+kw]
+      const int nsrc = cfg.skip ? 2 : 1;
+      for (int s = 0; s < nsrc; ++s) {
+        const int Cs = s == 0 ? C0 : C1;
+        RunGemm g = Builder::gemm0();
+        g.x[0] = d_decy[d]; g.xdt = adt; g.ydt = adt;
+        g.bstride[0] = (int64_t)(T + 1) * Fo * Co; g.tstride[0] = Fo * Co; g.base[0] = 0; g.rowlen[0] = Fo * Co; g.fstride[0] = 2 * Co; g.Tin[0] = T + 1;
+        g.M = B * T * Fi; g.Tout = T; g.Fo = Fi;
+        g.nseg = 2;
+        g.seg[0] = Seg{0, 0, -2 * Co, KS * Co, 0};    // kw = 0 : buffer frame u = t
+        g.seg[1] = Seg{0, 1, -2 * Co, KS * Co, 0};    // kw = 1 : buffer frame u = t + 1
+        g.N = Cs;
+        Builder::layout_segs(g);
+        // d y[co] / d x[(s,cc)] is the forward coefficient of phase (kh odd) at tap jj: look it up in the forward tables
+        const Builder::Coef f0 = dec[d].coef[0], f1 = dec[d].coef[1];
+        const int Csx = Cs;
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+          const int kw = sg, kh = j / Co, co = j % Co;
+          const int par = kh & 1;
+          const int jj = par == 0 ? (4 - kh) / 2 : (3 - kh) / 2;
+          return (par == 0 ? f0 : f1)(co, s * 2 + kw, jj * Csx + nn);
+        };
+        b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(s), 400 + d);
+        if (s == 0) {
+          if (d > 0) { g.y = d_decz[d - 1]; }
+          else g.y = d_decin;
+        } else {
+          g.y = d_skip[idx - 1];
+        }
+        g.y_bstride = (int64_t)T * Fi * Cs; g.y_tstride = Fi * Cs; g.y_fstride = Cs; g.y_off = 0;
+        b.push(R, OP_RUNGEMM, 400 + d).g = g;
+      }
+    }
+    // ---- projection backward
+    Ptr dhc_next = b.ws("dhc" + std::to_string(NL - 1), BT * 2 * H, DT_F32);
+    {
+      b.wgrad(R, proj, d_decin, cproj, 300, &bproj);
+      RunGemm g = Builder::gemm0();
+      g.x[0] = d_decin; g.xdt = adt; g.ydt = DT_F32;
+      g.bstride[0] = (int64_t)T * D * Cl; g.tstride[0] = D * Cl; g.rowlen[0] = D * Cl; g.Tin[0] = T;
+      g.M = (int)BT; g.Tout = T; g.Fo = 1;
+      g.nseg = 1; g.seg[0] = Seg{0, 0, 0, D * Cl, 0};
+      g.N = 2 * H;
+      Builder::layout_segs(g);
+      Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return cproj(j, 0, nn); };
+      b.pack_weights(R, g, coef, "proj.dg", 300);
+      g.y = dhc_next; g.y_bstride = (int64_t)T * 2 * H; g.y_tstride = 2 * H;
+      b.push(R, OP_RUNGEMM, 300).g = g;
+    }
+    // ---- LSTM backward
+    for (int l = NL - 1; l >= 0; --l) {
+      const std::string nm = "lstm" + std::to_string(l);
+      const std::string pp = "enhance." + std::to_string(l);
+      const ParamInfo* Whh[2] = {&b.par(pp + ".real_lstm.weight_hh_l0"), &b.par(pp + ".imag_lstm.weight_hh_l0")};
+      Ptr dh = b.ws(nm + ".dh", 4 * BT * H, DT_F32);
+      Ptr dgates = b.ws(nm + ".dgates", 2 * BT * 8 * H, DT_F32);
+      {
+        Op& op = b.push(R, OP_COMBINE_BWD, 200 + l);
+        op.comb.h = dh; op.comb.out = dhc_next; op.comb.rows = BT; op.comb.H = H; op.comb.dt = DT_F32;
+      }
+      {
+        Op& op = b.push(R, OP_LSTM_BWD, 200 + l);
+        LstmRec& r = op.lstm;
+        r.gx = ls[l].gxb;
+        r.whh[0] = b.pptr(pp + ".real_lstm.weight_hh_l0"); r.whh[1] = b.pptr(pp + ".imag_lstm.weight_hh_l0");
+        r.h = ls[l].h; r.gates = ls[l].gates; r.c = ls[l].cst; r.dh = dh; r.dgates = dgates;
+        for (int g4 = 0; g4 < 4; ++g4) r.gx_goff[g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
+        r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = DT_F32;
+      }
+      for (int p = 0; p < 2; ++p) {
+        Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * BT * 8 * H * 4);
+        b.wgrad(R, ls[l].gx[p], dyp, ls[l].cgx[p], 200 + l, &ls[l].bgx);
+      }
+      for (int g4 = 0; g4 < 4; ++g4) {       // W_hh: dW[n][k] = sum_t dgates[g][t][n] * h[g][t-1][k]
+        const int p = g4 / 2, set = g4 % 2;
+        RunGemm f = Builder::gemm0();
+        f.x[0] = b.mk(A_WS, ls[l].h.off + (int64_t)g4 * BT * H * esize(adt)); f.xdt = adt; f.ydt = DT_F32;
+        f.bstride[0] = (int64_t)T * H; f.tstride[0] = H; f.rowlen[0] = H; f.Tin[0] = T;
+        f.M = (int)BT; f.Tout = T; f.Fo = 1;
+        f.nseg = 1; f.seg[0] = Seg{0, -1, 0, H, 0};
+        f.N = 4 * H;
+        Builder::layout_segs(f);
+        f.y_bstride = (int64_t)T * 8 * H; f.y_tstride = 8 * H; f.y_off = set * 4 * H;
+        const ParamInfo* Wp = Whh[set];
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)nn * H + j, 1); };
+        Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * BT * 8 * H * 4);
+        b.wgrad(R, f, dyp, coef, 200 + l, nullptr);
+      }
+      // input gradient of the layer
+      Ptr dx_full;
+      if (l > 0) dx_full = b.ws("dhc" + std::to_string(l - 1), BT * 2 * H, DT_F32);
+      for (int p = 0; p < 2; ++p) {
+        const int nout = l == 0 ? D : 1;
+        for (int q = 0; q < nout; ++q) {
+          RunGemm g = Builder::gemm0();
+          g.x[0] = b.mk(A_WS, dgates.off + (int64_t)p * BT * 8 * H * 4); g.xdt = DT_F32;
+          g.bstride[0] = (int64_t)T * 8 * H; g.tstride[0] = 8 * H; g.rowlen[0] = 8 * H; g.Tin[0] = T;
+          g.M = (int)BT; g.Tout = T; g.Fo = 1;
+          g.nseg = 1; g.seg[0] = Seg{0, 0, 0, 8 * H, 0};
+          g.N = l == 0 ? Cl / 2 : H;
+          Builder::layout_segs(g);
+          const Builder::Coef cf = ls[l].cgx[p];
+          Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return l == 0 ? cf(j, q, nn) : cf(j, 0, nn); };
+          b.pack_weights(R, g, coef, nm + ".dx" + std::to_string(p) + "_" + std::to_string(q), 200 + l);
+          if (l == 0) {
+            g.ydt = adt; g.y = d_encz[n - 1];
+            g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl; g.y_off = q * Cl + p * (Cl / 2);
+          } else {
+            g.ydt = DT_F32; g.y = dx_full;
+            g.y_bstride = (int64_t)T * 2 * H; g.y_tstride = 2 * H; g.y_off = p * H;
+          }
+          b.push(R, OP_RUNGEMM, 200 + l).g = g;
+        }
+      }
+      if (l > 0) dhc_next = dx_full;
+    }
+    // ---- encoder backward
+    for (int i = n - 1; i >= 0; --i) {
+      const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
+      const std::string nm = "enc" + std::to_string(i);
+      const std::string pp = "encoder." + std::to_string(i);
+      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, enc[i].R, 0, d_ency[i], nm);
+      b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
+      if (i == 0) continue;
+      // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]
+      for (int par = 0; par < 2; ++par) {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = d_ency[i]; g.xdt = adt; g.ydt = adt;
+        g.bstride[0] = (int64_t)T * Fo * Co; g.tstride[0] = Fo * Co; g.rowlen[0] = Fo * Co; g.fstride[0] = Co; g.Tin[0] = T;
+        g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;           // Fi/2 == Fo output rows per phase
+        const int ntap = par == 0 ? 3 : 2;
+        g.nseg = 2;
+        g.seg[0] = Seg{0, 1, par == 0 ? -Co : 0, ntap * Co, 0};   // kw = 0 : frame t+1
+        g.seg[1] = Seg{0, 0, par == 0 ? -Co : 0, ntap * Co, 0};   // kw = 1 : frame t
+        g.N = Ci;
+        Builder::layout_segs(g);
+        const Builder::Coef cf = enc[i].coef[0];
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+          const int kw = sg, jj = j / Co, co = j % Co;
+          const int kh = par == 0 ? 4 - 2 * jj : 3 - 2 * jj;
+          return cf(co, kw, kh * Ci + nn);
+        };
+        b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(par), 100 + i);
+        g.y = d_encz[i - 1]; g.y_bstride = (int64_t)T * Fi * Ci; g.y_tstride = Fi * Ci; g.y_fstride = 2 * Ci; g.y_off = par * Ci;
+        b.push(R, OP_RUNGEMM, 100 + i).g = g;
+      }
+    }
+    b.finish_unpack(R);
+  }
+
+  P->arena_bytes[A_WS] = b.ws_off;
+  P->arena_bytes[A_PARAM] = nparam * 4;
+  P->arena_bytes[A_GRAD] = nparam * 4;
+  P->arena_bytes[A_STATE] = std::max<int64_t>(nstate, 1) * 4;
+  P->arena_bytes[A_CONST] = (int64_t)P->consts.size();
+  P->arena_bytes[A_IO] = b.io_off;
+  return P;
+}
+
+}  // namespace sefd

@@ -1,0 +1,52 @@
+// Host-side plan: buffers, constants and op lists for one model configuration (pure C++, no HIP).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+#include "sefd_desc.h"
+
+namespace sefd {
+
+struct ModelConfig {
+  int32_t model;            // 0 = DCCRN, 1 = CRN
+  int32_t B, L;
+  int32_t win_len, hop, fft_len;
+  int32_t n_layers;
+  int32_t kernel_num[8];    // output channels per encoder layer (complex: real+imag)
+  int32_t rnn_layers, rnn_units;
+  int32_t mask_mode;        // 0 E, 1 C, 2 R
+  int32_t lstm_complex;     // 1 = NavieComplexLSTM stack, 0 = real nn.LSTM(2 layers)+Linear
+  int32_t skip;             // skip connections (cfg.skip_type)
+  int32_t act_dtype;        // DT_F32 / DT_BF16 storage + MFMA dtype of the conv stack
+  int32_t kernel_size;      // 5
+  int32_t training;         // 1: BatchNorm batch statistics + running update ; 0: eval (running stats)
+};
+
+struct ParamInfo {
+  std::string name;
+  std::vector<int64_t> shape;
+  int64_t numel, off;       // element offset inside A_PARAM (trainable) or A_STATE (buffers)
+  int32_t arena;            // A_PARAM or A_STATE
+};
+
+struct BufInfo {
+  int64_t off, bytes;
+  int32_t dtype;
+};
+
+struct Plan {
+  ModelConfig cfg;
+  int32_t T, NF;
+  std::vector<ParamInfo> params;               // trainable, reference state_dict order
+  std::vector<ParamInfo> state;                // BatchNorm running_mean / running_var
+  std::map<std::string, BufInfo> bufs;         // named workspace buffers (tests / debugging)
+  int64_t arena_bytes[A_COUNT];
+  std::vector<char> consts;                    // host image of A_CONST
+  std::vector<Op> fwd, bwd;
+  std::string error;
+};
+
+Plan* build_dccrn_plan(const ModelConfig& cfg);
+
+}  // namespace sefd

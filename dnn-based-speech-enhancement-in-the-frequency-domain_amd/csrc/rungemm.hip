@@ -1,0 +1,376 @@
+// RUNGEMM / WGRAD: the two MFMA kernels that carry >96 % of the DCCRN train-step FLOPs.
+//
+// gfx950 only.  64-wide wavefronts, 4 waves per workgroup, 32x32 MFMA tiles:
+//   fp32 path  : v_mfma_f32_32x32x2_f32   (exact fp32, used for the parity mode and the fp32-only front end)
+//   bf16 path  : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)
+// Both dtypes use 128-byte K-rows in LDS (32 fp32 / 64 bf16), written as 16-byte chunks with an XOR swizzle on
+// the chunk index so that the ds_read_b128 fragment reads of 16 different rows hit 16 different 16-byte slots.
+// The A operand is never materialised (no im2col): every A row is a handful of contiguous runs of the
+// channels-last activation tensor (see sefd_desc.h), gathered straight from HBM/L2 with 16-byte loads.
+#include <hip/hip_runtime.h>
+#include "sefd_desc.h"
+#include "dev_common.h"
+
+namespace sefd {
+
+template <typename TA>
+struct RowInfo {
+  int64_t base0, base1;   // element offset of (b, u=0-relative) row start in x[0] / x[1] (without time)
+  int32_t u, fo;
+  bool valid;
+};
+
+// One 16-byte chunk (VEC elements) of run `sg` for row `ri`, starting at run position j0.
+template <typename TA>
+__device__ __forceinline__ uint4 load_a_chunk(const RunGemm& d, const TA* x0, const TA* x1, const Seg& sg,
+                                              int64_t base0, int64_t base1, int u, int fo, bool rvalid, int j0) {
+  constexpr int VEC = 16 / sizeof(TA);
+  uint4 z = make_uint4(0, 0, 0, 0);
+  if (!rvalid) return z;
+  if (sg.src < 0) {                       // "ones" run
+    if (j0 == 0) {
+      if (sizeof(TA) == 4) z.x = 0x3f800000u; else z.x = 0x3f80u;
+    }
+    return z;
+  }
+  const int s = sg.src;
+  const int tt = u + sg.dt;
+  if (tt < 0 || tt >= d.Tin[s]) return z;
+  const int r = sg.off + fo * d.fstride[s] + j0;
+  int lo = r < 0 ? -r : 0;
+  int hi = VEC;
+  if (sg.len - j0 < hi) hi = sg.len - j0;
+  if (d.rowlen[s] - r < hi) hi = d.rowlen[s] - r;
+  if (hi <= lo) return z;
+  const TA* src = (s ? x1 : x0) + (s ? base1 : base0) + (int64_t)tt * d.tstride[s] + r;
+  if (lo == 0 && hi == VEC) return *reinterpret_cast<const uint4*>(src);
+  // partially valid chunk: element-wise
+  if (sizeof(TA) == 4) {
+    uint32_t v[4] = {0, 0, 0, 0};
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
+    for (int e = lo; e < hi; ++e) v[e] = p[e];
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(src);
+    for (int e = lo; e < hi; ++e) v[e] = p[e];
+    return make_uint4(v[0] | (uint32_t)v[1] << 16, v[2] | (uint32_t)v[3] << 16, v[4] | (uint32_t)v[5] << 16,
+                      v[6] | (uint32_t)v[7] << 16);
+  }
+}
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {   // byte offset of a 16-byte chunk inside a [rows][128 B] tile
+  return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 16;
+}
+
+template <typename TA>
+__device__ __forceinline__ void mfma_step(f32x16& acc, const uint4& a, const uint4& b) {
+  if constexpr (sizeof(TA) == 4) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+}
+
+// XCD-aware bijective remap of the linear workgroup id (8 XCDs, private L2s): each XCD gets a contiguous
+// range of tiles so that neighbouring M-tiles (which share input rows) and all N-tiles of one M-tile share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + local;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <typename TA, int BN>
+__global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
+  constexpr int VEC = 16 / sizeof(TA);
+  constexpr int BK = 8 * VEC;
+  constexpr int BM = kBM;
+  constexpr int WN_ = BN == 128 ? 2 : 1;      // waves along N
+  constexpr int WM_ = 4 / WN_;                 // waves along M
+  constexpr int MI = BM / (32 * WM_);
+  constexpr int NI = BN / (32 * WN_);
+  constexpr int BPASS = BN / 32;
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int nn = d.Npad / BN;
+  const int nm = (d.M + BM - 1) / BM;
+  const int swz = xcd_remap(blockIdx.x, nm * nn);
+  const int ntile = swz % nn, mtile = swz / nn;
+
+  const TA* x0 = reinterpret_cast<const TA*>(rp(ab, d.x[0]));
+  const TA* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const TA*>(rp(ab, d.x[1])) : x0;
+  const TA* w = reinterpret_cast<const TA*>(rp(ab, d.w));
+
+  // ---- per-thread load assignment: chunk column c, rows r0 + 32p
+  const int c = tid & 7, r0 = tid >> 3;
+  int64_t rb0[4], rb1[4];
+  int ru[4], rfo[4];
+  bool rv[4];
+  const int TF = d.Tout * d.Fo;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int m = mtile * BM + r0 + 32 * p;
+    rv[p] = m < d.M;
+    const int mm = rv[p] ? m : 0;
+    const int b = mm / TF, rem = mm - b * TF;
+    ru[p] = rem / d.Fo;
+    rfo[p] = rem - ru[p] * d.Fo;
+    rb0[p] = (int64_t)b * d.bstride[0] + d.base[0];
+    rb1[p] = (int64_t)b * d.bstride[1] + d.base[1];
+  }
+  const TA* wrow[BPASS];
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) wrow[p] = w + (int64_t)(ntile * BN + r0 + 32 * p) * d.ldw + c * VEC;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm0 = (wid / WN_) * (MI * 32), wn0 = (wid % WN_) * (NI * 32);
+
+  // ---- K-tile iteration state
+  int seg = 0, k0 = 0;
+  int ntiles = 0;
+  for (int s = 0; s < d.nseg; ++s) ntiles += (d.seg[s].len + BK - 1) / BK;
+
+  uint4 aReg[4], bReg[BPASS];
+  auto issue_loads = [&](int sgi, int kk) {
+    const Seg sg = d.seg[sgi];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) aReg[p] = load_a_chunk<TA>(d, x0, x1, sg, rb0[p], rb1[p], ru[p], rfo[p], rv[p], kk + c * VEC);
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) bReg[p] = *reinterpret_cast<const uint4*>(wrow[p] + sg.koff + kk);
+  };
+  issue_loads(0, 0);
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    char* As = smem + (kt & 1) * TILE_BYTES;
+    char* Bs = As + BM * 128;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(As + swz_off(r0 + 32 * p, c)) = aReg[p];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) *reinterpret_cast<uint4*>(Bs + swz_off(r0 + 32 * p, c)) = bReg[p];
+    __syncthreads();
+    // advance (seg, k0) and prefetch the next tile into registers while this one is consumed from LDS
+    k0 += BK;
+    if (k0 >= d.seg[seg].len) { k0 = 0; ++seg; }
+    if (kt + 1 < ntiles) issue_loads(seg, k0);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int ch = 2 * kc + (lane >> 5);
+      uint4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(As + swz_off(wm0 + i * 32 + (lane & 31), ch));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + swz_off(wn0 + j * 32 + (lane & 31), ch));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mfma_step<TA>(acc[i][j], af[i], bf[j]);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: row address table in LDS, bias, store, BatchNorm partial statistics
+  int64_t* rowoff = reinterpret_cast<int64_t*>(smem);              // [BM]
+  float* stat = reinterpret_cast<float*>(smem + BM * 8);           // [WM_][BN][2]
+  if (tid < BM) {
+    const int m = mtile * BM + tid;
+    int64_t o = -1;
+    if (m < d.M) {
+      const int b = m / TF, rem = m - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
+      o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+    }
+    rowoff[tid] = o;
+  }
+  __syncthreads();
+  const float* bias = d.bias.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
+  char* yb = rp(ab, d.y);
+  const bool want_stats = d.stats.arena >= 0;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int nl = wn0 + j * 32 + (lane & 31);
+    const int n = ntile * BN + nl;
+    const float bv = (bias && n < d.N) ? bias[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int64_t o = rowoff[row];
+        const float v = acc[i][j][e] + bv;
+        if (o >= 0 && n < d.N) {
+          if (d.ydt == DT_BF16) reinterpret_cast<uint16_t*>(yb)[o + n] = f2bf(v);
+          else reinterpret_cast<float*>(yb)[o + n] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (want_stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) {
+        stat[((wid / WN_) * BN + nl) * 2 + 0] = s1;
+        stat[((wid / WN_) * BN + nl) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int wmi = 0; wmi < WM_; ++wmi) {
+        s1 += stat[(wmi * BN + tid) * 2 + 0];
+        s2 += stat[(wmi * BN + tid) * 2 + 1];
+      }
+      float* part = reinterpret_cast<float*>(rp(ab, d.stats));
+      part[((int64_t)mtile * 2 + 0) * d.Npad + ntile * BN + tid] = s1;
+      part[((int64_t)mtile * 2 + 1) * d.Npad + ntile * BN + tid] = s2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// WGRAD (fp32 MFMA):  part[split][n][k] = sum_{rows m of the split} dy[m][n] * A[m][k]
+// MFMA view: "A operand" = dy^T (i = n, kk = m), "B operand" = gathered activations (kk = m, j = k).
+// Workgroup tile 64 (n) x 128 (k); 4 waves as 2x2, each 32 x 64; 32 reduction rows per step.
+// LDS tiles are stored in their natural [m][n] / [m][k] layout: the 32x32x2 fp32 MFMA takes ONE scalar per
+// lane per operand, so fragment reads are conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+template <typename TA>
+__global__ __launch_bounds__(256) void wgrad_kernel(const RunGemm d, const ArenaBases ab) {
+  static_assert(sizeof(TA) == 4, "bf16 WGRAD uses the transposing variant");
+  constexpr int TN = kWgTN, TK = kWgTK, RS = kWgRows;
+  __shared__ __attribute__((aligned(16))) float dys[2][RS][TN + 4];
+  __shared__ __attribute__((aligned(16))) float as[2][RS][TK + 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ntile = blockIdx.x, ktile = blockIdx.y, split = blockIdx.z;
+  const float* x0 = reinterpret_cast<const float*>(rp(ab, d.x[0]));
+  const float* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.x[1])) : x0;
+  const float* dy = reinterpret_cast<const float*>(rp(ab, d.y));
+  float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)split * d.Npad * d.ldw;
+
+  // rows of this split, in units of RS
+  const int nsteps_total = (d.M + RS - 1) / RS;
+  const int per = (nsteps_total + d.nsplit - 1) / d.nsplit;
+  const int step0 = split * per;
+  const int step1 = min(nsteps_total, step0 + per);
+  const int TF = d.Tout * d.Fo;
+
+  // A-gather assignment: chunk column ca (32 chunks of 4 floats per row), rows ra + 8p
+  const int ca = tid & 31, ra = tid >> 5;
+  const int kcol = ktile * TK + ca * 4;
+  int sgi = -1, j0 = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const int plen = (d.seg[s].len + 31) / 32 * 32;
+    if (kcol >= d.seg[s].koff && kcol < d.seg[s].koff + plen) { sgi = s; j0 = kcol - d.seg[s].koff; }
+  }
+  Seg sg;
+  if (sgi >= 0) sg = d.seg[sgi]; else { sg.src = 0; sg.dt = 0; sg.off = 0; sg.len = 0; sg.koff = 0; }
+  // dy assignment: chunk column cd (16 chunks of 4 floats), rows rd + 16p
+  const int cd = tid & 15, rd = tid >> 4;
+  const int ncol = ntile * TN + cd * 4;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int wn = (wid >> 1) * 32, wk = (wid & 1) * 64;
+
+  uint4 aReg[4], dReg[2];
+  auto issue = [&](int step) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = step * RS + ra + 8 * p;
+      const bool v = m < d.M;
+      const int mm = v ? m : 0;
+      const int b = mm / TF, rem = mm - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
+      aReg[p] = load_a_chunk<float>(d, x0, x1, sg, (int64_t)b * d.bstride[0] + d.base[0], (int64_t)b * d.bstride[1] + d.base[1],
+                                    u, fo, v && sgi >= 0, j0);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = step * RS + rd + 16 * p;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (m < d.M) {
+        const int b = m / TF, rem = m - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
+        const float* src = dy + (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off + ncol;
+        if (ncol + 4 <= d.N) z = *reinterpret_cast<const uint4*>(src);
+        else {
+          uint32_t v[4] = {0, 0, 0, 0};
+          for (int e = 0; e < 4; ++e) if (ncol + e < d.N) v[e] = reinterpret_cast<const uint32_t*>(src)[e];
+          z = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      dReg[p] = z;
+    }
+  };
+  if (step0 < step1) issue(step0);
+  for (int st = step0; st < step1; ++st) {
+    const int buf = (st - step0) & 1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&as[buf][ra + 8 * p][ca * 4]) = aReg[p];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&dys[buf][rd + 16 * p][cd * 4]) = dReg[p];
+    __syncthreads();
+    if (st + 1 < step1) issue(st + 1);
+#pragma unroll
+    for (int mm = 0; mm < RS; mm += 2) {
+      const int row = mm + (lane >> 5);
+      const float a = dys[buf][row][wn + (lane & 31)];
+      const float b0 = as[buf][row][wk + (lane & 31)];
+      const float b1 = as[buf][row][wk + 32 + (lane & 31)];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+    }
+  }
+  // store: C layout col = lane&31 -> k, row -> n
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = ntile * TN + wn + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      const int k = ktile * TK + wk + j * 32 + (lane & 31);
+      if (n < d.Npad && k < d.ldw) part[(int64_t)n * d.ldw + k] = acc[j][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <typename TA>
+static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  const int bn = bn_of(d.N);
+  const int nm = (d.M + kBM - 1) / kBM;
+  const int grid = nm * (d.Npad / bn);
+  if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128>), dim3(grid), dim3(256), 0, st, d, ab);
+  else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64>), dim3(grid), dim3(256), 0, st, d, ab);
+  else hipLaunchKernelGGL((rungemm_kernel<TA, 32>), dim3(grid), dim3(256), 0, st, d, ab);
+}
+
+void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (d.xdt == DT_BF16) launch_rungemm_t<bf16_t>(d, ab, st);
+  else launch_rungemm_t<float>(d, ab, st);
+}
+
+void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  dim3 grid((d.Npad + kWgTN - 1) / kWgTN, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
+  hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, st, d, ab);
+}
+
+}  // namespace sefd

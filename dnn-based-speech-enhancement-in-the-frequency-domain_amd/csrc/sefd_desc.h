@@ -1,0 +1,203 @@
+// Launch descriptors for the MI355X speech-enhancement hot path.
+//
+// The host-side planner (plan.cpp, pure C++) turns a model configuration into a flat list of
+// `Op`s over five memory arenas.  The HIP executor (exec.hip) launches one hand-written gfx950
+// kernel per Op; the test-only host simulator (tests/hostsim) interprets the same list on the CPU
+// so that the planner's index arithmetic can be checked without a GPU.  All structs are PODs.
+#pragma once
+#include <cstdint>
+
+namespace sefd {
+
+enum Arena : int32_t {
+  A_NONE = -1,
+  A_WS = 0,      // workspace: activations, gradients, packed weights, partial sums (caller allocated)
+  A_PARAM = 1,   // flat fp32 trainable parameters, reference state_dict order
+  A_GRAD = 2,    // flat fp32 gradients, same layout as A_PARAM
+  A_STATE = 3,   // module buffers (BatchNorm running_mean / running_var), fp32
+  A_CONST = 4,   // plan constants: STFT bases, OLA normaliser, pack/unpack index tables
+  A_IO = 5,      // per-call I/O block: [wav | out_wav | out_real | out_imag | grad_wav | grad_real | grad_imag]
+  A_COUNT = 6
+};
+
+enum DType : int32_t { DT_F32 = 0, DT_BF16 = 1 };
+
+struct Ptr {
+  int32_t arena;
+  int32_t pad_;
+  int64_t off;   // byte offset inside the arena
+};
+
+// ----------------------------------------------------------------------------------------------
+// RUNGEMM:  y[row(b,u,fo)][n] = bias[n] + sum_seg sum_j  A_seg(b,u,fo)[j] * W[n][seg.koff + j]
+// where A_seg is a *contiguous run* of `len` elements of source tensor `src`:
+//     tt = u + seg.dt                     (valid iff 0 <= tt < Tin[src])
+//     r  = seg.off + fo*fstride[src] + j  (valid iff 0 <= r < rowlen[src]);  invalid -> 0
+//     elem = x[src][ b*bstride[src] + tt*tstride[src] + base[src] + r ]
+// This single form covers: the strided (5,2) conv, both sub-pixel phases of the transposed conv, their
+// input-gradients, the hoisted LSTM / Linear GEMMs, the conv-STFT framing GEMM and the iSTFT synthesis.
+// seg.src == -1 is the "ones" run (value 1 at j == 0): it turns the weight-gradient GEMM into a bias-gradient too.
+struct Seg {
+  int32_t src, dt, off, len, koff;
+};
+
+constexpr int kMaxSeg = 8;
+
+struct RunGemm {
+  Ptr x[2];
+  int32_t xdt;             // DType of x[*] and of w
+  int32_t ydt;             // DType of y
+  int64_t bstride[2];
+  int32_t tstride[2], base[2], rowlen[2], fstride[2], Tin[2];
+  int32_t M, Tout, Fo;     // M = B*Tout*Fo ; m -> b = m/(Tout*Fo), u = (m/Fo)%Tout, fo = m%Fo
+  int32_t nseg;
+  Seg seg[kMaxSeg];
+  Ptr w;                   // packed weights [Npad][ldw], K-contiguous, zero padded   (WGRAD: fp32 partial output [nsplit][Npad][ldw])
+  int32_t ldw, N, Npad;
+  Ptr bias;                // fp32 [N] or A_NONE
+  Ptr y;                   // output (WGRAD: the upstream gradient dy, read)
+  int64_t y_bstride;
+  int32_t y_tstride, y_fstride, y_off;   // y index = b*y_bstride + u*y_tstride + fo*y_fstride + y_off + n
+  Ptr stats;               // A_NONE or fp32 partial sums [gridM][2][Npad] (sum, sum of squares of the stored value)
+  int32_t nsplit;          // WGRAD only: number of row splits
+  int32_t relu_;           // unused, keeps the struct 8-byte aligned
+};
+
+// PACK: dst[i] = sum_{e < width} sign(tab[i*width+e]) * src[|tab[i*width+e]|-1]   (entry 0 -> nothing).  Table int32 in A_CONST.
+// width 1: packed conv / LSTM weights ; width 2: combined biases (b_r - b_i | b_r + b_i), (b_ih + b_hh).
+struct Pack {
+  Ptr tab, src, dst;
+  int64_t n;
+  int32_t ddt, width;
+};
+
+// SPLITSUM: part[0][i] = sum_s part[s*sstride + i]   (in place, fixed order -> deterministic)
+// UNPACK:   grad[j] = sum_{e in [start[j], start[j+1])} sign(ent[e]) * src[|ent[e]|-1]    (CSR table in A_CONST)
+struct Unpack {
+  Ptr start, ent, part, dst;   // start: int32[n+1]; ent: int32[]; part: fp32 ; dst fp32
+  int64_t n;                   // SPLITSUM: elements per split ; UNPACK: number of gradient elements written
+  int64_t sstride;             // elements between splits
+  int32_t nsplit, pad_;
+};
+
+// BatchNorm2d (training) + PReLU on channels-last rows [R][C].
+struct BnFinalize {            // partial sums -> mean, invstd ; running stats momentum update
+  Ptr part;                    // [nblk][2][Cpad]
+  Ptr mean_invstd;             // fp32 [2][C]  (workspace)
+  Ptr running_mean, running_var;   // A_STATE (or A_NONE in eval)
+  int32_t nblk, C, Cpad, pad_;
+  double count;                // rows contributing
+  float eps, momentum;
+};
+struct BnApply {               // z = prelu(gamma*(y-mean)*invstd + beta)
+  Ptr y, z, mean_invstd, gamma, beta, slope;
+  int64_t R;
+  int32_t C, dt;               // dt: DType of y and z
+};
+struct BnBwdReduce {           // per-channel partial sums of (dbn, dbn*xhat) and the PReLU slope gradient
+  Ptr y, dz0, dz1;             // dz1 optional second upstream gradient (skip connection): dz = dz0 + dz1
+  Ptr mean_invstd, gamma, beta, slope;
+  Ptr part;                    // fp32 [nblk][3][C]  (sum dbn, sum dbn*xhat, [c==0]: sum slope-grad)
+  int64_t R;
+  int32_t C, dt, nblk, rows_per_blk;
+  // y has `rpb` rows per batch element of which the first `skip` (the decoder frame dropped by `[..., 1:]`) receive no
+  // upstream gradient; dz0 holds only the remaining rows:  y row r -> b = r / rpb, q = r % rpb; dz row = b*(rpb-skip) + q-skip.
+  int64_t rpb;
+  int32_t skip, pad_;
+};
+struct BnBwdApply {            // FINALIZE: partials -> totals [3][C] + parameter gradients ; APPLY: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))
+  BnBwdReduce r;
+  Ptr totals;                  // fp32 [3][C] workspace
+  Ptr dy;                      // same shape/dtype as y
+  Ptr dgamma, dbeta, dslope;   // A_GRAD
+  double count;
+};
+
+// LSTM recurrence (input GEMM hoisted).  G independent groups, group g uses weight set g % nset.
+// gx   [G][B][T][4H] fp32 gate pre-activations from the input GEMM (bias included), PyTorch gate order i,f,g,o
+// whh  [nset][4H][H]  (param arena, fp32, reference layout weight_hh_l0)
+// h    [G][B][T][H]   (dtype hdt) ; gates [G][B][T][4H] fp32 post-activation ; c [G][B][T][H] fp32
+// Row (b,t) of group g:  gx  at gx  + gx_goff[g]  + (b*T+t)*gx_ld   (fp32, 4H wide)
+//                        dgates at dgates + gx_goff[g] + (b*T+t)*gx_ld (dtype gdt, 4H wide)
+struct LstmRec {
+  Ptr gx, whh[2], h, gates, c;
+  Ptr dh, dgates;              // backward: dh [G][B][T][H] upstream (fp32) ; dgates out (same addressing as gx)
+  int64_t gx_goff[4];
+  int32_t gx_ld;
+  int32_t G, nset, B, T, H, hdt, gdt;
+};
+
+// Complex combine (tools_for_model.py:171-172): out[b,t, 0:H] = h[g0] - h[g3];  out[b,t,H:2H] = h[g2] + h[g1]
+struct Combine {
+  Ptr h, out;                  // h [4][B*T][H], out [B*T][2H]   (forward)   /  dout -> dh (backward)
+  int64_t rows;
+  int32_t H, dt;
+};
+
+// Mask application (models.py:253-276) on interleaved spectra.
+// spec / est [B][T][NF+1][2] fp32 (r,i) with slot 0 a zero pad and slot k+1 = bin k (keeps bin 1 16-byte aligned);
+// mask [..][NF-1][2] for bins 1..NF-1 (decoder output, dtype mdt).
+struct Mask {
+  Ptr spec, mask, est;         // forward
+  Ptr dest, dmask;             // backward: dest = d(est) (fp32), dmask out (dtype mdt)
+  int64_t frames;              // B*T
+  int32_t NF, mode;            // mode 0=E 1=C 2=R
+  int32_t mdt, pad0_;          // DType of mask / dmask
+  int64_t mask_fstride;        // elements between consecutive frames of `mask` (decoder buffer has T+1 frames / batch)
+  int64_t mask_bstride, mask_base;
+  int32_t T, pad_;
+};
+
+// Overlap-add + 1/(coff+1e-8) + trim + clamp (tools_for_model.py:101-110, models.py:280-282)
+// frames [B][T][win] fp32 ; wav [B][L] fp32 ; coff fp32 [(T-1)*hop+win] in A_CONST
+struct Ola {
+  Ptr frames, wav, coff;
+  Ptr dwav, dpad;              // backward: dpad [B][(T-1)*hop+win] = clampmask*dwav/(coff+1e-8) (0 in the trimmed borders)
+  int32_t B, T, L, win, hop, trim;
+};
+
+// est spec [B][T][NF+1][2] (fp32, slot layout above) <-> reference layout out_real/out_imag [B][NF][T] fp32
+struct SpecOut {
+  Ptr est, out_real, out_imag; // forward: est -> out_*   ; backward: dest += d(out_*)
+  int32_t B, T, NF, accumulate;
+};
+
+struct Memset {
+  Ptr dst;
+  int64_t bytes;
+};
+
+enum OpKind : int32_t {
+  OP_RUNGEMM = 1, OP_WGRAD, OP_PACK, OP_UNPACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY,
+  OP_LSTM_FWD, OP_LSTM_BWD, OP_COMBINE_FWD, OP_COMBINE_BWD, OP_MASK_FWD, OP_MASK_BWD, OP_OLA_FWD, OP_OLA_BWD,
+  OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE
+};
+
+struct Op {
+  int32_t kind;
+  int32_t tag;                 // layer id for profiling / debugging
+  union {
+    RunGemm g;
+    Pack pack;
+    Unpack unpack;
+    BnFinalize bnf;
+    BnApply bna;
+    BnBwdReduce bnr;
+    BnBwdApply bnb;
+    LstmRec lstm;
+    Combine comb;
+    Mask mask;
+    Ola ola;
+    SpecOut so;
+    Memset ms;
+  };
+};
+
+// Tile geometry shared by planner (padding) and kernels.
+constexpr int kBM = 128;                                   // rows per RUNGEMM block == rows per statistics block
+inline int bk_of(int dt) { return dt == DT_BF16 ? 64 : 32; }   // K-tile in elements: 128 bytes of either dtype
+inline int bn_of(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
+constexpr int kWgTN = 64, kWgTK = 128, kWgRows = 32;       // WGRAD block tile (n x k) and reduction rows per step
+inline int esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
+
+}  // namespace sefd

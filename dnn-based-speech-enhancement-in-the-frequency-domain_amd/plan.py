@@ -1,0 +1,118 @@
+"""Python handle on a `sefd_plan` (host-side op list + arena sizes) and its device arenas."""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ARENA_WS, ARENA_PARAM, ARENA_GRAD, ARENA_STATE, ARENA_CONST, ARENA_IO, ARENA_COUNT = 0, 1, 2, 3, 4, 5, 6
+PHASE_FWD, PHASE_BWD = 0, 1
+MASK_MODES = {"E": 0, "C": 1, "R": 2}
+DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+class Plan:
+    def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
+                 win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
+                 kernel_size=5, training=True):
+        self.lib = _lib.lib()
+        if masking_mode not in MASK_MODES:
+            raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
+        cfg = _lib.ModelConfig()
+        cfg.model = 0
+        cfg.B, cfg.L = int(B), int(L)
+        cfg.win_len, cfg.hop, cfg.fft_len = win_len, win_inc, fft_len
+        cfg.n_layers = len(kernel_num)
+        for i, k in enumerate(kernel_num):
+            cfg.kernel_num[i] = int(k)
+        cfg.rnn_layers, cfg.rnn_units = rnn_layers, rnn_units
+        cfg.mask_mode = MASK_MODES[masking_mode]
+        cfg.lstm_complex = 1 if lstm == "complex" else 0
+        cfg.skip = 1 if skip_type else 0
+        cfg.act_dtype = DTYPES[act_dtype]
+        cfg.kernel_size = kernel_size
+        cfg.training = 1 if training else 0
+        self.cfg = cfg
+        self.h = self.lib.sefd_plan_create(C.byref(cfg))
+        err = self.lib.sefd_plan_error(self.h).decode()
+        if err:
+            self.lib.sefd_plan_destroy(self.h)
+            self.h = None
+            raise ValueError("sefd plan: " + err)
+        self.B, self.L = int(B), int(L)
+        self.T = self.lib.sefd_plan_frames(self.h)
+        self.NF = fft_len // 2 + 1
+        self.arena_bytes = [self.lib.sefd_plan_arena_bytes(self.h, a) for a in range(ARENA_COUNT)]
+        self.params = self._param_table(0)
+        self.state = self._param_table(1)
+        self.n_param = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.params.values())
+        self.n_state = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.state.values())
+
+    def _param_table(self, kind):
+        out = OrderedDict()
+        shp = (C.c_int64 * 4)()
+        for i in range(self.lib.sefd_plan_num_params(self.h, kind)):
+            name = self.lib.sefd_plan_param_name(self.h, kind, i).decode()
+            nd = self.lib.sefd_plan_param_shape(self.h, kind, i, shp)
+            out[name] = (self.lib.sefd_plan_param_offset(self.h, kind, i), tuple(int(shp[k]) for k in range(nd)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.sefd_plan_destroy(self.h)
+            self.h = None
+
+    # ---- introspection
+    def num_ops(self, phase):
+        return self.lib.sefd_plan_num_ops(self.h, phase)
+
+    def ops_ptr(self, phase):
+        return self.lib.sefd_plan_ops(self.h, phase)
+
+    def op_kinds(self, phase):
+        n, sz = self.num_ops(phase), self.lib.sefd_op_size()
+        raw = np.ctypeslib.as_array((C.c_int32 * (n * sz // 4)).from_address(self.ops_ptr(phase))).reshape(n, sz // 4)
+        return raw[:, 0].copy(), raw[:, 1].copy()
+
+    def buffer(self, name):
+        a, off, nb, dt = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
+        if self.lib.sefd_plan_buffer(self.h, name.encode(), C.byref(a), C.byref(off), C.byref(nb), C.byref(dt)) != 0:
+            raise KeyError(name)
+        return a.value, off.value, nb.value, dt.value
+
+    def buffer_names(self):
+        return [self.lib.sefd_plan_buffer_name(self.h, i).decode() for i in range(self.lib.sefd_plan_num_buffers(self.h))]
+
+    def const_image(self) -> np.ndarray:
+        n = self.arena_bytes[ARENA_CONST]
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.lib.sefd_plan_const_data(self.h))).copy()
+
+    # ---- arenas
+    def alloc_arenas(self, device):
+        """uint8 tensors for every arena (PARAM/GRAD/STATE as float32). CONST is filled from the host image."""
+        dev = torch.device(device)
+        ar = [None] * ARENA_COUNT
+        ar[ARENA_WS] = torch.zeros(max(self.arena_bytes[ARENA_WS], 256), dtype=torch.uint8, device=dev)
+        ar[ARENA_PARAM] = torch.zeros(self.arena_bytes[ARENA_PARAM] // 4, dtype=torch.float32, device=dev)
+        ar[ARENA_GRAD] = torch.zeros(self.arena_bytes[ARENA_GRAD] // 4, dtype=torch.float32, device=dev)
+        ar[ARENA_STATE] = torch.zeros(self.arena_bytes[ARENA_STATE] // 4, dtype=torch.float32, device=dev)
+        ar[ARENA_CONST] = torch.from_numpy(self.const_image()).to(dev)
+        ar[ARENA_IO] = torch.zeros(self.arena_bytes[ARENA_IO], dtype=torch.uint8, device=dev)
+        return ar
+
+    def view(self, arenas, name):
+        """Typed 1-D view of a named buffer inside its arena."""
+        a, off, nb, dt = self.buffer(name)
+        raw = arenas[a].view(torch.uint8)[off:off + nb]
+        return raw.view(torch.bfloat16 if dt == 1 else torch.float32)
+
+    def io(self, arenas, name, shape):
+        return self.view(arenas, "io." + name).view(*shape)
+
+    def run(self, phase, arenas, stream=0, first=0, last=-1):
+        ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
+        rc = self.lib.sefd_plan_run(self.h, phase, first, last, ptrs, C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"sefd_plan_run failed ({rc})")

@@ -1,0 +1,90 @@
+/* sefd.h - C ABI of the MI355X (gfx950) speech-enhancement training hot path.
+ *
+ * Drop-in boundary: the reference exposes this path only as Python objects -
+ *   models.DCCRN.__init__/forward/loss          /root/reference/models.py:15-323
+ *   ConvSTFT / ConviSTFT                        /root/reference/tools_for_model.py:36-112
+ *   ComplexConv2d / ComplexConvTranspose2d      /root/reference/tools_for_model.py:199-338
+ *   NavieComplexLSTM                            /root/reference/tools_for_model.py:141-181
+ *   sdr / si_snr / si_sdr / F.mse_loss          /root/reference/tools_for_loss.py:17-94, models.py:315-323
+ *   torch.optim.Adam step                       /root/reference/train_interface.py:59, trainer.py:35-37
+ * so this header is what a ctypes binding of those objects calls.
+ * Plain pointers and sizes only; every function enqueues on the given HIP stream and returns 0 or a negative code.
+ * No hidden device allocation: all device memory ("arenas") is owned by the caller.
+ */
+#ifndef SEFD_H_
+#define SEFD_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sefd_plan sefd_plan;
+
+/* Mirror of the config.py knobs that shape DCCRN (config.py:35-68) plus batch geometry. */
+typedef struct sefd_model_config {
+  int32_t model;          /* 0 = DCCRN */
+  int32_t B, L;           /* batch, samples per clip */
+  int32_t win_len, hop, fft_len;
+  int32_t n_layers;
+  int32_t kernel_num[8];  /* cfg.dccrn_kernel_num */
+  int32_t rnn_layers, rnn_units;
+  int32_t mask_mode;      /* 0 'E', 1 'C', 2 'R' (cfg.masking_mode) */
+  int32_t lstm_complex;   /* cfg.lstm == 'complex' */
+  int32_t skip;           /* cfg.skip_type */
+  int32_t act_dtype;      /* 0 fp32, 1 bf16 storage / MFMA dtype */
+  int32_t kernel_size;    /* 5 */
+  int32_t training;       /* 1 train (batch statistics + backward plan), 0 eval */
+} sefd_model_config;
+
+enum { SEFD_ARENA_WS = 0, SEFD_ARENA_PARAM = 1, SEFD_ARENA_GRAD = 2, SEFD_ARENA_STATE = 3, SEFD_ARENA_CONST = 4, SEFD_ARENA_IO = 5,
+       SEFD_ARENA_COUNT = 6 };
+enum { SEFD_PHASE_FWD = 0, SEFD_PHASE_BWD = 1 };
+enum { SEFD_LOSS_MSE = 0, SEFD_LOSS_SDR = 1, SEFD_LOSS_SISNR = 2, SEFD_LOSS_SISDR = 3 };
+
+/* ---- plan life cycle (host only) ---------------------------------------------------------------- */
+sefd_plan* sefd_plan_create(const sefd_model_config* cfg);        /* replaces models.DCCRN.__init__ (models.py:17-172) */
+void sefd_plan_destroy(sefd_plan* p);
+const char* sefd_plan_error(const sefd_plan* p);                  /* "" when the plan is valid */
+int64_t sefd_plan_arena_bytes(const sefd_plan* p, int arena);
+int32_t sefd_plan_frames(const sefd_plan* p);                     /* T */
+/* parameters in reference state_dict order; kind 0 = trainable (A_PARAM / A_GRAD), 1 = buffer (A_STATE) */
+int32_t sefd_plan_num_params(const sefd_plan* p, int kind);
+const char* sefd_plan_param_name(const sefd_plan* p, int kind, int i);
+int64_t sefd_plan_param_offset(const sefd_plan* p, int kind, int i);   /* in elements */
+int64_t sefd_plan_param_numel(const sefd_plan* p, int kind, int i);
+int32_t sefd_plan_param_shape(const sefd_plan* p, int kind, int i, int64_t* shape4);  /* returns ndim */
+/* named workspace / io buffers (tests, debugging). returns 0 if found */
+int32_t sefd_plan_buffer(const sefd_plan* p, const char* name, int32_t* arena, int64_t* off, int64_t* bytes, int32_t* dtype);
+int32_t sefd_plan_num_buffers(const sefd_plan* p);
+const char* sefd_plan_buffer_name(const sefd_plan* p, int i);
+/* host image of the constant arena (STFT bases, OLA normaliser, index tables): copy it to device memory once */
+const void* sefd_plan_const_data(const sefd_plan* p);
+/* op lists (POD array of sefd::Op, see csrc/sefd_desc.h) */
+int32_t sefd_plan_num_ops(const sefd_plan* p, int phase);
+const void* sefd_plan_ops(const sefd_plan* p, int phase);
+int32_t sefd_op_size(void);
+
+/* ---- execution (device) --------------------------------------------------------------------------
+ * arenas: SEFD_ARENA_COUNT device pointers.  Runs ops [first, last) of the phase on `stream`.
+ * Forward  = DCCRN.forward  (models.py:176-284): IO.wav -> IO.out_wav, IO.out_real, IO.out_imag.
+ * Backward = autograd of it: IO.grad_wav / grad_real / grad_imag -> A_GRAD (all parameters). */
+int32_t sefd_plan_run(const sefd_plan* p, int phase, int first, int last, void* const* arenas, void* stream);
+
+/* ---- losses (tools_for_loss.py:17-94, models.py:315-323) ---------------------------------------
+ * est, tgt: fp32 [B][L] device.  ws: fp32 device scratch of sefd_loss_ws_floats(B) floats.
+ * forward writes the scalar loss to loss_out[0]; backward writes grad_est[B][L] = d(loss)/d(est) * grad_scale[0]. */
+int64_t sefd_loss_ws_floats(int32_t B);
+int32_t sefd_loss_forward(int kind, const float* est, const float* tgt, int32_t B, int32_t L, float* ws, float* loss_out, void* stream);
+int32_t sefd_loss_backward(int kind, const float* est, const float* tgt, int32_t B, int32_t L, const float* ws,
+                           const float* grad_scale, float* grad_est, void* stream);
+
+/* ---- Adam (torch.optim.Adam defaults, train_interface.py:59) on flat fp32 buffers ------------------
+ * step is 1-based. */
+int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                       float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

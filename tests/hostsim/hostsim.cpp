@@ -1,0 +1,475 @@
+// TEST INFRASTRUCTURE ONLY - never linked into the product library.
+// CPU interpreter of the launch descriptors (csrc/sefd_desc.h).  It executes the very op list the HIP executor
+// launches, on host copies of the arenas, with straightforward loops and double accumulation.  Two uses:
+//   * CPU tests (-m "not gpu"): planner index arithmetic (descriptors + pack/unpack tables) checked against the oracle
+//     without a GPU;
+//   * GPU tests: per-op expected buffers, so that a wrong kernel is localised to the op that first deviates.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../dnn-based-speech-enhancement-in-the-frequency-domain_amd/csrc/sefd_desc.h"
+
+using namespace sefd;
+
+namespace {
+struct AB { char* p[A_COUNT]; };
+inline char* rp(const AB& ab, const Ptr& q) { return ab.p[q.arena] + q.off; }
+inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+inline uint16_t f2bf(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float ld(const char* b, int dt, int64_t i) { return dt == DT_BF16 ? bf2f(((const uint16_t*)b)[i]) : ((const float*)b)[i]; }
+inline void st(char* b, int dt, int64_t i, float v) { if (dt == DT_BF16) ((uint16_t*)b)[i] = f2bf(v); else ((float*)b)[i] = v; }
+
+// value of run element (seg, j) for row (b,u,fo); `ok` false -> 0
+inline double a_elem(const RunGemm& d, const AB& ab, const Seg& sg, int b, int u, int fo, int j) {
+  if (sg.src < 0) return j == 0 ? 1.0 : 0.0;
+  const int s = sg.src;
+  const int tt = u + sg.dt;
+  if (tt < 0 || tt >= d.Tin[s]) return 0.0;
+  const int r = sg.off + fo * d.fstride[s] + j;
+  if (r < 0 || r >= d.rowlen[s] || j >= sg.len) return 0.0;
+  return ld(rp(ab, d.x[s]), d.xdt, (int64_t)b * d.bstride[s] + (int64_t)tt * d.tstride[s] + d.base[s] + r);
+}
+
+void rungemm(const RunGemm& d, const AB& ab) {
+  const char* w = rp(ab, d.w);
+  const float* bias = d.bias.arena >= 0 ? (const float*)rp(ab, d.bias) : nullptr;
+  char* y = rp(ab, d.y);
+  const int TF = d.Tout * d.Fo;
+  const int nblk = (d.M + kBM - 1) / kBM;
+  std::vector<double> s1, s2;
+  if (d.stats.arena >= 0) { s1.assign((size_t)nblk * d.Npad, 0.0); s2.assign((size_t)nblk * d.Npad, 0.0); }
+  std::vector<double> arow(d.ldw);
+  for (int m = 0; m < d.M; ++m) {
+    const int b = m / TF, rem = m % TF, u = rem / d.Fo, fo = rem % d.Fo;
+    std::fill(arow.begin(), arow.end(), 0.0);
+    for (int s = 0; s < d.nseg; ++s)
+      for (int j = 0; j < d.seg[s].len; ++j) arow[d.seg[s].koff + j] = a_elem(d, ab, d.seg[s], b, u, fo, j);
+    const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+    for (int n = 0; n < d.N; ++n) {
+      double acc = 0.0;
+      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, (int64_t)n * d.ldw + k);
+      const float v = (float)acc + (bias ? bias[n] : 0.f);
+      st(y, d.ydt, o + n, v);
+      if (d.stats.arena >= 0) { s1[(size_t)(m / kBM) * d.Npad + n] += v; s2[(size_t)(m / kBM) * d.Npad + n] += (double)v * v; }
+    }
+  }
+  if (d.stats.arena >= 0) {
+    float* part = (float*)rp(ab, d.stats);
+    for (int blk = 0; blk < nblk; ++blk)
+      for (int n = 0; n < d.Npad; ++n) {
+        part[((int64_t)blk * 2 + 0) * d.Npad + n] = (float)s1[(size_t)blk * d.Npad + n];
+        part[((int64_t)blk * 2 + 1) * d.Npad + n] = (float)s2[(size_t)blk * d.Npad + n];
+      }
+  }
+}
+
+void wgrad(const RunGemm& d, const AB& ab) {
+  const char* dy = rp(ab, d.y);
+  float* part = (float*)rp(ab, d.w);
+  const int TF = d.Tout * d.Fo;
+  const int64_t sz = (int64_t)d.Npad * d.ldw;
+  const int nsteps = (d.M + kWgRows - 1) / kWgRows;
+  const int per = (nsteps + d.nsplit - 1) / d.nsplit;
+  std::vector<double> acc(sz);
+  std::vector<double> arow(d.ldw);
+  for (int sp = 0; sp < d.nsplit; ++sp) {
+    std::fill(acc.begin(), acc.end(), 0.0);
+    const int m0 = sp * per * kWgRows, m1 = std::min<int64_t>(d.M, (int64_t)(sp + 1) * per * kWgRows);
+    for (int m = m0; m < m1; ++m) {
+      const int b = m / TF, rem = m % TF, u = rem / d.Fo, fo = rem % d.Fo;
+      std::fill(arow.begin(), arow.end(), 0.0);
+      for (int s = 0; s < d.nseg; ++s)
+        for (int j = 0; j < d.seg[s].len; ++j) arow[d.seg[s].koff + j] = a_elem(d, ab, d.seg[s], b, u, fo, j);
+      const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+      for (int n = 0; n < d.N; ++n) {
+        const double g = ld(dy, d.ydt, o + n);
+        if (g == 0.0) continue;
+        double* a = &acc[(size_t)n * d.ldw];
+        for (int k = 0; k < d.ldw; ++k) a[k] += g * arow[k];
+      }
+    }
+    for (int64_t i = 0; i < sz; ++i) part[sp * sz + i] = (float)acc[i];
+  }
+}
+
+
+inline void load_dz(const BnBwdReduce& d, const AB& ab, int64_t r, int c, double* g) {
+  const int64_t b = r / d.rpb, q = r - b * d.rpb;
+  *g = 0.0;
+  if (q >= d.skip) *g = ld(rp(ab, d.dz0), d.dt, (b * (d.rpb - d.skip) + q - d.skip) * d.C + c);
+  if (d.dz1.arena >= 0) *g += ld(rp(ab, d.dz1), d.dt, r * d.C + c);
+}
+
+void run_op(const Op& op, const AB& ab) {
+  switch (op.kind) {
+    case OP_RUNGEMM: rungemm(op.g, ab); break;
+    case OP_WGRAD: wgrad(op.g, ab); break;
+    case OP_PACK: {
+      const Pack& d = op.pack;
+      const int32_t* tab = (const int32_t*)rp(ab, d.tab);
+      const float* src = (const float*)rp(ab, d.src);
+      for (int64_t i = 0; i < d.n; ++i) {
+        float v = 0.f;
+        for (int e = 0; e < d.width; ++e) {
+          const int32_t t = tab[i * d.width + e];
+          if (t > 0) v += src[t - 1]; else if (t < 0) v -= src[-t - 1];
+        }
+        st(rp(ab, d.dst), d.ddt, i, v);
+      }
+      break;
+    }
+    case OP_SPLITSUM: {
+      const Unpack& d = op.unpack;
+      float* part = (float*)rp(ab, d.part);
+      for (int64_t i = 0; i < d.n; ++i) {
+        double s = 0;
+        for (int k = 0; k < d.nsplit; ++k) s += part[k * d.sstride + i];
+        part[i] = (float)s;
+      }
+      break;
+    }
+    case OP_UNPACK: {
+      const Unpack& d = op.unpack;
+      const int32_t* start = (const int32_t*)rp(ab, d.start);
+      const int32_t* ent = (const int32_t*)rp(ab, d.ent);
+      const float* part = (const float*)rp(ab, d.part);
+      float* dst = (float*)rp(ab, d.dst);
+      for (int64_t j = 0; j < d.n; ++j) {
+        double v = 0;
+        for (int e = start[j]; e < start[j + 1]; ++e) { const int32_t t = ent[e]; if (t > 0) v += part[t - 1]; else if (t < 0) v -= part[-t - 1]; }
+        if (start[j + 1] > start[j]) dst[j] = (float)v;
+      }
+      break;
+    }
+    case OP_BN_FINALIZE: {
+      const BnFinalize& d = op.bnf;
+      float* mi = (float*)rp(ab, d.mean_invstd);
+      for (int c = 0; c < d.C; ++c) {
+        if (d.nblk < 0) {
+          mi[c] = ((const float*)rp(ab, d.running_mean))[c];
+          mi[d.C + c] = 1.f / std::sqrt(((const float*)rp(ab, d.running_var))[c] + d.eps);
+          continue;
+        }
+        const float* part = (const float*)rp(ab, d.part);
+        double s1 = 0, s2 = 0;
+        for (int b = 0; b < d.nblk; ++b) { s1 += part[((int64_t)b * 2) * d.Cpad + c]; s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c]; }
+        const double mean = s1 / d.count;
+        double var = s2 / d.count - mean * mean;
+        if (var < 0) var = 0;
+        mi[c] = (float)mean;
+        mi[d.C + c] = (float)(1.0 / std::sqrt(var + (double)d.eps));
+        if (d.running_mean.arena >= 0) {
+          float* rm = (float*)rp(ab, d.running_mean);
+          float* rv = (float*)rp(ab, d.running_var);
+          const double unb = var * (d.count / (d.count > 1 ? d.count - 1 : 1));
+          rm[c] = (float)((1.0 - d.momentum) * rm[c] + d.momentum * mean);
+          rv[c] = (float)((1.0 - d.momentum) * rv[c] + d.momentum * unb);
+        }
+      }
+      break;
+    }
+    case OP_BN_APPLY: {
+      const BnApply& d = op.bna;
+      const float* mi = (const float*)rp(ab, d.mean_invstd);
+      const float* gamma = (const float*)rp(ab, d.gamma);
+      const float* beta = (const float*)rp(ab, d.beta);
+      const float a = *(const float*)rp(ab, d.slope);
+      for (int64_t i = 0; i < d.R * d.C; ++i) {
+        const int c = (int)(i % d.C);
+        const float bn = gamma[c] * ((ld(rp(ab, d.y), d.dt, i) - mi[c]) * mi[d.C + c]) + beta[c];
+        st(rp(ab, d.z), d.dt, i, bn > 0.f ? bn : a * bn);
+      }
+      break;
+    }
+    case OP_BN_BWD_REDUCE: {
+      const BnBwdReduce& d = op.bnr;
+      const float* mi = (const float*)rp(ab, d.mean_invstd);
+      const float* gamma = (const float*)rp(ab, d.gamma);
+      const float* beta = (const float*)rp(ab, d.beta);
+      const float a = *(const float*)rp(ab, d.slope);
+      float* part = (float*)rp(ab, d.part);
+      for (int blk = 0; blk < d.nblk; ++blk) {
+        std::vector<double> s0(d.C, 0.0), s1(d.C, 0.0);
+        double sa = 0;
+        const int64_t r0 = (int64_t)blk * d.rows_per_blk, r1 = std::min<int64_t>(d.R, r0 + d.rows_per_blk);
+        for (int64_t r = r0; r < r1; ++r)
+          for (int c = 0; c < d.C; ++c) {
+            double g;
+            load_dz(d, ab, r, c, &g);
+            const float xh = (ld(rp(ab, d.y), d.dt, r * d.C + c) - mi[c]) * mi[d.C + c];
+            const float bn = gamma[c] * xh + beta[c];
+            const double dbn = bn > 0.f ? g : a * g;
+            if (!(bn > 0.f)) sa += bn * g;
+            s0[c] += dbn; s1[c] += dbn * xh;
+          }
+        for (int c = 0; c < d.C; ++c) { part[(int64_t)blk * 3 * d.C + c] = (float)s0[c]; part[(int64_t)blk * 3 * d.C + d.C + c] = (float)s1[c]; }
+        part[(int64_t)blk * 3 * d.C + 2 * d.C] = (float)sa;
+      }
+      break;
+    }
+    case OP_BN_BWD_FINALIZE: {
+      const BnBwdApply& d = op.bnb;
+      const int C = d.r.C;
+      const float* part = (const float*)rp(ab, d.r.part);
+      float* tot = (float*)rp(ab, d.totals);
+      double sa = 0;
+      for (int c = 0; c < C; ++c) {
+        double s0 = 0, s1 = 0;
+        for (int b = 0; b < d.r.nblk; ++b) { s0 += part[(int64_t)b * 3 * C + c]; s1 += part[(int64_t)b * 3 * C + C + c]; }
+        tot[c] = (float)s0; tot[C + c] = (float)s1;
+        ((float*)rp(ab, d.dbeta))[c] = (float)s0;
+        ((float*)rp(ab, d.dgamma))[c] = (float)s1;
+      }
+      for (int b = 0; b < d.r.nblk; ++b) sa += part[(int64_t)b * 3 * C + 2 * C];
+      ((float*)rp(ab, d.dslope))[0] = (float)sa;
+      break;
+    }
+    case OP_BN_BWD_APPLY: {
+      const BnBwdApply& d = op.bnb;
+      const BnBwdReduce& r = d.r;
+      const int C = r.C;
+      const float* mi = (const float*)rp(ab, r.mean_invstd);
+      const float* gamma = (const float*)rp(ab, r.gamma);
+      const float* beta = (const float*)rp(ab, r.beta);
+      const float* tot = (const float*)rp(ab, d.totals);
+      const float a = *(const float*)rp(ab, r.slope);
+      for (int64_t row = 0; row < r.R; ++row)
+        for (int c = 0; c < C; ++c) {
+          double g;
+          load_dz(r, ab, row, c, &g);
+          const float xh = (ld(rp(ab, r.y), r.dt, row * C + c) - mi[c]) * mi[C + c];
+          const float bn = gamma[c] * xh + beta[c];
+          const double dbn = bn > 0.f ? g : a * g;
+          st(rp(ab, d.dy), r.dt, row * C + c, (float)(gamma[c] * mi[C + c] * (dbn - tot[c] / d.count - xh * tot[C + c] / d.count)));
+        }
+      break;
+    }
+    case OP_LSTM_FWD: {
+      const LstmRec& d = op.lstm;
+      const int H = d.H, T = d.T;
+      const float* gxb = (const float*)rp(ab, d.gx);
+      float* gates = (float*)rp(ab, d.gates);
+      float* cs = (float*)rp(ab, d.c);
+      for (int g = 0; g < d.G; ++g) {
+        const float* whh = (const float*)rp(ab, d.whh[g % d.nset]);
+        for (int b = 0; b < d.B; ++b) {
+          std::vector<double> h(H, 0.0), c(H, 0.0), hn(H);
+          for (int t = 0; t < T; ++t) {
+            const float* gx = gxb + d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld;
+            const int64_t row = ((int64_t)g * d.B + b) * T + t;
+            for (int j = 0; j < H; ++j) {
+              double pre[4];
+              for (int q = 0; q < 4; ++q) {
+                double s = gx[q * H + j];
+                const float* wr = whh + (int64_t)(q * H + j) * H;
+                for (int k = 0; k < H; ++k) s += h[k] * wr[k];
+                pre[q] = s;
+              }
+              const double ig = 1 / (1 + std::exp(-pre[0])), fg = 1 / (1 + std::exp(-pre[1])), gg = std::tanh(pre[2]), og = 1 / (1 + std::exp(-pre[3]));
+              c[j] = fg * c[j] + ig * gg;
+              hn[j] = og * std::tanh(c[j]);
+              gates[row * 4 * H + j] = (float)ig; gates[row * 4 * H + H + j] = (float)fg;
+              gates[row * 4 * H + 2 * H + j] = (float)gg; gates[row * 4 * H + 3 * H + j] = (float)og;
+              cs[row * H + j] = (float)c[j];
+            }
+            for (int j = 0; j < H; ++j) {
+              st(rp(ab, d.h), d.hdt, row * H + j, (float)hn[j]);
+              h[j] = d.hdt == DT_BF16 ? bf2f(f2bf((float)hn[j])) : hn[j];
+            }
+          }
+        }
+      }
+      break;
+    }
+    case OP_LSTM_BWD: {
+      const LstmRec& d = op.lstm;
+      const int H = d.H, T = d.T;
+      const float* gates = (const float*)rp(ab, d.gates);
+      const float* cs = (const float*)rp(ab, d.c);
+      const float* dh = (const float*)rp(ab, d.dh);
+      for (int g = 0; g < d.G; ++g) {
+        const float* whh = (const float*)rp(ab, d.whh[g % d.nset]);
+        for (int b = 0; b < d.B; ++b) {
+          std::vector<double> dhrec(H, 0.0), dc(H, 0.0), dg(4 * H);
+          for (int t = T - 1; t >= 0; --t) {
+            const int64_t row = ((int64_t)g * d.B + b) * T + t;
+            for (int j = 0; j < H; ++j) {
+              const double ig = gates[row * 4 * H + j], fg = gates[row * 4 * H + H + j], gg = gates[row * 4 * H + 2 * H + j], og = gates[row * 4 * H + 3 * H + j];
+              const double ct = cs[row * H + j], cp = t > 0 ? cs[(row - 1) * H + j] : 0.0;
+              const double dht = dh[row * H + j] + dhrec[j];
+              const double tc = std::tanh(ct);
+              const double dcv = dht * og * (1 - tc * tc) + dc[j];
+              dg[j] = dcv * gg * ig * (1 - ig);
+              dg[H + j] = dcv * cp * fg * (1 - fg);
+              dg[2 * H + j] = dcv * ig * (1 - gg * gg);
+              dg[3 * H + j] = dht * tc * og * (1 - og);
+              dc[j] = dcv * fg;
+            }
+            const int64_t o = d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld;
+            for (int k = 0; k < 4 * H; ++k) st(rp(ab, d.dgates), d.gdt, o + k, (float)dg[k]);
+            for (int j = 0; j < H; ++j) {
+              double s = 0;
+              if (t > 0) for (int k = 0; k < 4 * H; ++k) s += dg[k] * whh[(int64_t)k * H + j];
+              dhrec[j] = s;
+            }
+          }
+        }
+      }
+      break;
+    }
+    case OP_COMBINE_FWD: {
+      const Combine& d = op.comb;
+      const int64_t gsz = d.rows * d.H;
+      for (int64_t i = 0; i < gsz; ++i) {
+        const int64_t row = i / d.H; const int j = (int)(i % d.H);
+        const char* h = rp(ab, d.h);
+        st(rp(ab, d.out), d.dt, row * 2 * d.H + j, ld(h, d.dt, i) - ld(h, d.dt, 3 * gsz + i));
+        st(rp(ab, d.out), d.dt, row * 2 * d.H + d.H + j, ld(h, d.dt, 2 * gsz + i) + ld(h, d.dt, gsz + i));
+      }
+      break;
+    }
+    case OP_COMBINE_BWD: {
+      const Combine& d = op.comb;
+      const int64_t gsz = d.rows * d.H;
+      float* dh = (float*)rp(ab, d.h);
+      const float* dout = (const float*)rp(ab, d.out);
+      for (int64_t i = 0; i < gsz; ++i) {
+        const int64_t row = i / d.H; const int j = (int)(i % d.H);
+        const float dr = dout[row * 2 * d.H + j], di = dout[row * 2 * d.H + d.H + j];
+        dh[i] = dr; dh[gsz + i] = di; dh[2 * gsz + i] = di; dh[3 * gsz + i] = -dr;
+      }
+      break;
+    }
+    case OP_MASK_FWD: {
+      const Mask& d = op.mask;
+      const float* spec = (const float*)rp(ab, d.spec);
+      float* est = (float*)rp(ab, d.est);
+      const int NS = d.NF + 1;
+      for (int64_t f = 0; f < d.frames; ++f)
+        for (int slot = 0; slot < NS; ++slot) {
+          const int64_t i = f * NS + slot;
+          double er = 0, ei = 0;
+          if (slot >= 2) {
+            const int64_t b = f / d.T, t = f % d.T;
+            const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * 2;
+            const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = ld(rp(ab, d.mask), d.mdt, mo + 1);
+            const double sr = spec[i * 2], si = spec[i * 2 + 1];
+            if (d.mode == 0) {
+              const double mag = std::sqrt(sr * sr + si * si + 1e-8), ph = std::atan2(si, sr), mm = std::sqrt(mr * mr + mi * mi);
+              const double mph = std::atan2(mi / (mm + 1e-8), mr / (mm + 1e-8));
+              const double em = std::tanh(mm) * mag;
+              er = em * std::cos(ph + mph); ei = em * std::sin(ph + mph);
+            } else if (d.mode == 1) { er = sr * mr - si * mi; ei = sr * mi + si * mr; }
+            else { er = sr * mr; ei = si * mi; }
+          }
+          est[i * 2] = (float)er; est[i * 2 + 1] = (float)ei;
+        }
+      break;
+    }
+    case OP_MASK_BWD: {
+      const Mask& d = op.mask;
+      const float* spec = (const float*)rp(ab, d.spec);
+      const float* dest = (const float*)rp(ab, d.dest);
+      const int NB = d.NF - 1, NS = d.NF + 1;
+      const int lead = (int)(d.mask_base / d.mask_fstride), TT = d.T + lead;
+      const int64_t B = d.frames / d.T;
+      for (int64_t b = 0; b < B; ++b)
+        for (int u = 0; u < TT; ++u)
+          for (int k = 0; k < NB; ++k) {
+            const int64_t mo = b * d.mask_bstride + (int64_t)u * d.mask_fstride + k * 2;
+            double gr = 0, gi = 0;
+            if (u >= lead) {
+              const int64_t f = b * d.T + (u - lead);
+              const int64_t s_ = (f * NS + k + 2) * 2;
+              const double sr = spec[s_], si = spec[s_ + 1], der = dest[s_], dei = dest[s_ + 1];
+              const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = ld(rp(ab, d.mask), d.mdt, mo + 1);
+              if (d.mode == 0) {
+                const double mag = std::sqrt(sr * sr + si * si + 1e-8), ph = std::atan2(si, sr), mm = std::sqrt(mr * mr + mi * mi);
+                const double den = mm + 1e-8, rpv = mr / den, ipv = mi / den, mph = std::atan2(ipv, rpv), tm = std::tanh(mm), em = tm * mag;
+                const double sn = std::sin(ph + mph), cs = std::cos(ph + mph);
+                const double d_em = der * cs + dei * sn, d_ph = em * (-der * sn + dei * cs);
+                double d_mm = d_em * mag * (1 - tm * tm);
+                const double q = rpv * rpv + ipv * ipv;
+                double d_rp = 0, d_ip = 0;
+                if (q > 0) { d_ip = d_ph * rpv / q; d_rp = -d_ph * ipv / q; }
+                gr = d_rp / den; gi = d_ip / den;
+                d_mm += -(d_rp * mr + d_ip * mi) / (den * den);
+                if (mm > 0) { gr += d_mm * mr / mm; gi += d_mm * mi / mm; }
+              } else if (d.mode == 1) { gr = der * sr + dei * si; gi = -der * si + dei * sr; }
+              else { gr = der * sr; gi = dei * si; }
+            }
+            st(rp(ab, d.dmask), d.mdt, mo, (float)gr);
+            st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
+          }
+      break;
+    }
+    case OP_OLA_FWD: {
+      const Ola& d = op.ola;
+      const float* fr = (const float*)rp(ab, d.frames);
+      const float* coff = (const float*)rp(ab, d.coff);
+      float* wav = (float*)rp(ab, d.wav);
+      for (int b = 0; b < d.B; ++b)
+        for (int n = 0; n < d.L; ++n) {
+          const int p = n + d.trim;
+          double s = 0;
+          for (int t = 0; t < d.T; ++t) { const int j = p - t * d.hop; if (j >= 0 && j < d.win) s += fr[((int64_t)b * d.T + t) * d.win + j]; }
+          float v = (float)s / (coff[p] + 1e-8f);
+          wav[(int64_t)b * d.L + n] = std::fmin(1.f, std::fmax(-1.f, v));
+        }
+      break;
+    }
+    case OP_OLA_BWD: {
+      const Ola& d = op.ola;
+      const float* coff = (const float*)rp(ab, d.coff);
+      const float* wav = (const float*)rp(ab, d.wav);
+      const float* dwav = (const float*)rp(ab, d.dwav);
+      float* dpad = (float*)rp(ab, d.dpad);
+      const int Lp = (d.T - 1) * d.hop + d.win;
+      for (int b = 0; b < d.B; ++b)
+        for (int p = 0; p < Lp; ++p) {
+          float v = 0.f;
+          const int s = p - d.trim;
+          if (s >= 0 && s < d.L) { const float w = wav[(int64_t)b * d.L + s]; if (w > -1.f && w < 1.f) v = dwav[(int64_t)b * d.L + s] / (coff[p] + 1e-8f); }
+          dpad[(int64_t)b * Lp + p] = v;
+        }
+      break;
+    }
+    case OP_SPECOUT_FWD:
+    case OP_SPECOUT_BWD: {
+      const SpecOut& d = op.so;
+      float* est = (float*)rp(ab, d.est);
+      float* orr = (float*)rp(ab, d.out_real);
+      float* oi = (float*)rp(ab, d.out_imag);
+      const int NS = d.NF + 1;
+      for (int b = 0; b < d.B; ++b)
+        for (int t = 0; t < d.T; ++t)
+          for (int k = 0; k < d.NF; ++k) {
+            const int64_t e = (((int64_t)b * d.T + t) * NS + k + 1) * 2, o = ((int64_t)b * d.NF + k) * d.T + t;
+            if (op.kind == OP_SPECOUT_FWD) { orr[o] = est[e]; oi[o] = est[e + 1]; }
+            else if (d.accumulate) { est[e] += orr[o]; est[e + 1] += oi[o]; }
+            else { est[e] = orr[o]; est[e + 1] = oi[o]; }
+          }
+      break;
+    }
+    case OP_MEMSET: std::memset(rp(ab, op.ms.dst), 0, op.ms.bytes); break;
+    default: std::fprintf(stderr, "hostsim: unknown op %d\n", op.kind);
+  }
+}
+}  // namespace
+
+extern "C" int hostsim_run(const void* ops_, int first, int last, void* const* arenas) {
+  const Op* ops = (const Op*)ops_;
+  AB ab;
+  for (int a = 0; a < A_COUNT; ++a) ab.p[a] = (char*)arenas[a];
+  for (int i = first; i < last; ++i) run_op(ops[i], ab);
+  return 0;
+}
+extern "C" int hostsim_op_size() { return (int)sizeof(Op); }

@@ -1,0 +1,128 @@
+"""GPU tier: every HIP kernel launch of the DCCRN forward+backward op list is compared, op by op, with the
+test-only host simulator started from the *same* pre-op state (so an error is localised to one kernel), and stray
+writes outside the op's output region are detected.  Then the losses and Adam against the oracle formulas."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as ol
+from oracle.dccrn import DCCRNConfig, dccrn_state_shapes
+from oracle.step import adam_update
+from oracle.weights import formula_state_dict, test_signals as make_signals
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+KIND = {1: "RUNGEMM", 2: "WGRAD", 3: "PACK", 4: "UNPACK", 5: "BN_FINALIZE", 6: "BN_APPLY", 7: "BN_BWD_REDUCE", 8: "BN_BWD_APPLY",
+        9: "LSTM_FWD", 10: "LSTM_BWD", 11: "COMBINE_FWD", 12: "COMBINE_BWD", 13: "MASK_FWD", 14: "MASK_BWD", 15: "OLA_FWD",
+        16: "OLA_BWD", 17: "SPECOUT_FWD", 18: "SPECOUT_BWD", 19: "MEMSET", 20: "SPLITSUM", 21: "BN_BWD_FINALIZE"}
+
+
+def _report_path(name):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, name)
+
+
+@pytest.mark.parametrize("B,mode,kn,ru", [(3, "E", (16, 32, 32, 64, 64, 64), 128), (2, "C", (32, 64, 128, 256, 256, 256), 256)])
+def test_every_op_against_host_simulator(B, mode, kn, ru):
+    from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, sim_run
+    L = 4000
+    cfg = DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)
+    P = formula_state_dict(dccrn_state_shapes(cfg))
+    plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru)
+    dev = plan.alloc_arenas("cuda")
+    host = plan.alloc_arenas("cpu")
+    fill_params(plan, dev, P)
+    x, y = make_signals(B, L)
+    plan.io(dev, "wav", (B, L)).copy_(x)
+    torch.manual_seed(1)
+    plan.io(dev, "grad_wav", (B, L)).copy_(torch.randn(B, L) * 1e-3)
+    plan.io(dev, "grad_real", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
+    plan.io(dev, "grad_imag", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
+    lines, bad = [], []
+    check = [0, 2, 3, 5]      # WS, GRAD, STATE, IO
+    for phase in (PHASE_FWD, PHASE_BWD):
+        kinds, tags = plan.op_kinds(phase)
+        for i in range(plan.num_ops(phase)):
+            torch.cuda.synchronize()
+            for a in range(6):
+                host[a].copy_(dev[a])
+            before = [host[a].clone() for a in check]
+            sim_run(plan, phase, host, i, i + 1)
+            plan.run(phase, dev, 0, i, i + 1)
+            torch.cuda.synchronize()
+            worst, nchg, stray = 0.0, 0, 0
+            for a, bef in zip(check, before):
+                h = host[a].view(torch.uint8).view(torch.float32) if host[a].dtype == torch.uint8 else host[a]
+                bf = bef.view(torch.uint8).view(torch.float32) if bef.dtype == torch.uint8 else bef
+                g = dev[a].cpu()
+                g = g.view(torch.uint8).view(torch.float32) if g.dtype == torch.uint8 else g
+                chg = (h != bf) & ~(torch.isnan(h) & torch.isnan(bf))
+                n = int(chg.sum())
+                if n:
+                    hv, gv = h[chg].double(), g[chg].double()
+                    den = float(hv.abs().max())
+                    err = float((hv - gv).abs().max()) / (den if den > 0 else 1.0)
+                    if not np.isfinite(err):
+                        err = float("inf")
+                    worst = max(worst, err)
+                    nchg += n
+                same = ~chg
+                stray += int(((g != bf) & same & ~(torch.isnan(g) & torch.isnan(bf))).sum())
+            lines.append(f"phase {phase} op {i:3d} {KIND.get(int(kinds[i]), kinds[i]):16s} tag {int(tags[i]):4d} changed {nchg:9d} rel_err {worst:.3e} stray {stray}")
+            if not (worst < 1e-3) or stray:
+                bad.append(lines[-1])
+    with open(_report_path(f"ops_report_B{B}_{mode}.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    assert not bad, "\n".join(bad[:20])
+
+
+@pytest.mark.parametrize("kind,name", [(0, "MSE"), (1, "SDR"), (2, "SI-SNR"), (3, "SI-SDR")])
+def test_fused_losses_forward_backward(kind, name):
+    import ctypes as C
+    from sefd_amd import _lib
+    L_ = _lib.lib()
+    B, L = 5, 4802
+    x, y = make_signals(B, L)
+    est = (x * 0.9).clone().requires_grad_(True)
+    ref = ol.main_loss(name, est, y)
+    ref.backward()
+    e_d, y_d = est.detach().cuda(), y.cuda()
+    ws = torch.zeros(L_.sefd_loss_ws_floats(B), device="cuda")
+    out = torch.zeros(1, device="cuda")
+    g = torch.zeros(B, L, device="cuda")
+    gs = torch.full((1,), 0.5, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    assert L_.sefd_loss_forward(kind, vp(e_d), vp(y_d), B, L, vp(ws), vp(out), None) == 0
+    assert L_.sefd_loss_backward(kind, vp(e_d), vp(y_d), B, L, vp(ws), vp(gs), vp(g), None) == 0
+    torch.cuda.synchronize()
+    assert abs(float(out) - float(ref)) < 1e-4 * max(1.0, abs(float(ref))), (float(out), float(ref))
+    assert rel_err(g.cpu(), 0.5 * est.grad) < 1e-3          # tolerance: 1e-3 relative fp32 (north_star)
+
+
+def test_adam_step_matches_torch_formula():
+    import ctypes as C
+    from sefd_amd import _lib
+    L_ = _lib.lib()
+    n = 100003
+    torch.manual_seed(0)
+    p, g = torch.randn(n), torch.randn(n) * 1e-2
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = p.cuda(), g.cuda(), m.cuda(), v.cuda()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    for step in (1, 2, 3):
+        p, m, v = adam_update(p, g, m, v, step)
+        assert L_.sefd_adam_step(vp(pd), vp(gd), vp(md), vp(vd), n, step, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(pd.cpu(), p) < 1e-6
+    # and against torch.optim.Adam itself
+    q = torch.nn.Parameter(torch.ones(8))
+    opt = torch.optim.Adam([q], lr=1e-3)
+    q.grad = torch.arange(8.0) * 0.1 - 0.3
+    opt.step()
+    qd, gq, mq, vq = torch.ones(8).cuda(), q.grad.cuda(), torch.zeros(8).cuda(), torch.zeros(8).cuda()
+    L_.sefd_adam_step(vp(qd), vp(gq), vp(mq), vp(vq), 8, 1, 1e-3, 0.9, 0.999, 1e-8, 1.0, None)
+    assert rel_err(qd.cpu(), q.detach()) < 1e-6

@@ -1,0 +1,120 @@
+"""CPU tier 2: the planner (descriptors, pack/unpack tables, buffer layout) interpreted by the test-only host
+simulator must reproduce the oracle's DCCRN forward AND backward.  No GPU, no HIP kernel runs here; what is
+pinned is all the host logic the HIP executor consumes verbatim."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.dccrn import DCCRNConfig, dccrn_forward, dccrn_state_shapes, is_trainable
+from oracle.frontend import analysis_kernel, synthesis_kernel, ola_normaliser
+from oracle.losses import main_loss
+from oracle.weights import formula_state_dict, test_signals as make_signals
+from simutil import (ARENA_PARAM, PHASE_BWD, PHASE_FWD, Plan, act_to_nchw, fill_params, read_params, sim_run, spec_to_ref)
+from sefd_amd.plan import ARENA_GRAD, ARENA_STATE
+from util import rel_err
+
+SMALL = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128)
+
+
+def oracle_params(cfg):
+    return formula_state_dict(dccrn_state_shapes(cfg))
+
+
+def test_exports_and_param_table():
+    from sefd_amd import _lib
+    L = _lib.lib()
+    for sym in _lib.EXPORTED:
+        assert hasattr(L, sym), sym
+    plan = Plan(2, 4000, **SMALL)
+    cfg = DCCRNConfig(**SMALL)
+    shapes = dccrn_state_shapes(cfg)
+    want = [(k, tuple(v)) for k, v in shapes.items() if is_trainable(k)]
+    got = [(k, shp) for k, (off, shp) in plan.params.items()]
+    assert got == want                       # reference state_dict order, names and shapes
+    want_state = [(k, tuple(v)) for k, v in shapes.items() if "running_" in k]
+    assert [(k, shp) for k, (off, shp) in plan.state.items()] == want_state
+    with pytest.raises(ValueError):
+        Plan(2, 4000, kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=2048)
+
+
+def test_default_plan_matches_reference_param_count():
+    plan = Plan(1, 4000)
+    assert plan.n_param == 3671053 - 0      # DCCRN default; buffers are not counted there
+
+
+@pytest.mark.parametrize("mode,loss", [("E", "SI-SNR"), ("C", "SDR"), ("R", "MSE")])
+def test_hostsim_forward_backward_vs_oracle(mode, loss):
+    B, L = 2, 4000
+    cfg = DCCRNConfig(masking_mode=mode, **SMALL)
+    P = oracle_params(cfg)
+    plan = Plan(B, L, masking_mode=mode, **SMALL)
+    T, NF = plan.T, plan.NF
+    ar = plan.alloc_arenas("cpu")
+    fill_params(plan, ar, P)
+    x, y = make_signals(B, L)
+    plan.io(ar, "wav", (B, L)).copy_(x)
+    sim_run(plan, PHASE_FWD, ar)
+
+    # ---- oracle forward with taps
+    Pg = {k: (v.clone().requires_grad_(True) if is_trainable(k) else v.clone()) for k, v in P.items()}
+    taps = {}
+    (o_r, o_i, wav), new_stats = dccrn_forward(Pg, x, cfg, targets=y, train=True, taps=taps)
+    assert rel_err(spec_to_ref(plan.view(ar, "spec"), B, T, NF), taps["spec"]) < 1e-5
+    ch = (2,) + SMALL["kernel_num"]
+    F = [256 >> i for i in range(7)]
+    for i in range(6):
+        got = act_to_nchw(plan.view(ar, f"enc{i}.y"), B, T, F[i + 1], ch[i + 1])
+        assert rel_err(got, taps[f"enc{i}.conv"]) < 2e-5, f"enc{i}.conv"
+        got = act_to_nchw(plan.view(ar, f"enc{i}.z"), B, T, F[i + 1], ch[i + 1])
+        assert rel_err(got, taps[f"enc{i}.out"]) < 2e-5, f"enc{i}.out"
+    for d in range(6):
+        idx = 6 - d
+        got = act_to_nchw(plan.view(ar, f"dec{d}.y"), B, T + 1, 2 * F[idx], ch[idx - 1])
+        assert rel_err(got, taps[f"dec{d}.conv"]) < 5e-5, f"dec{d}.conv"
+    assert rel_err(plan.io(ar, "out_wav", (B, L)), wav) < 5e-5
+    assert rel_err(plan.io(ar, "out_real", (B, NF, T)), o_r) < 5e-5
+    assert rel_err(plan.io(ar, "out_imag", (B, NF, T)), o_i) < 5e-5
+    got_state = read_params(plan, ar, ARENA_STATE, plan.state)
+    for k, v in new_stats.items():
+        assert rel_err(got_state[k], v) < 1e-5, k
+
+    # ---- backward: loss on the waveform plus a linear functional of the spectra (exercises all three output gradients)
+    torch.manual_seed(3)
+    cr, ci = torch.randn(B, NF, T) * 1e-3, torch.randn(B, NF, T) * 1e-3
+    lossv = main_loss(loss, wav, y) + (o_r * cr).sum() + (o_i * ci).sum()
+    names = [k for k in Pg if is_trainable(k)]
+    grads = dict(zip(names, torch.autograd.grad(lossv, [Pg[k] for k in names] + [wav], allow_unused=True, retain_graph=True)[:len(names)]))
+    gw = torch.autograd.grad(main_loss(loss, wav, y), wav, retain_graph=True)[0]
+    plan.io(ar, "grad_wav", (B, L)).copy_(gw)
+    plan.io(ar, "grad_real", (B, NF, T)).copy_(cr)
+    plan.io(ar, "grad_imag", (B, NF, T)).copy_(ci)
+    sim_run(plan, PHASE_BWD, ar)
+    got = read_params(plan, ar, ARENA_GRAD)
+    worst = 0.0
+    for k in names:
+        ref = grads[k]
+        if k.endswith("conv.bias") and not k.startswith("decoder.5."):
+            # analytically zero (bias in front of BatchNorm): both sides are rounding noise
+            wk = k.replace(".bias", ".weight")
+            assert got[k].abs().max() < 1e-4 * grads[wk].abs().max() + 1e-7, k
+            continue
+        e = rel_err(got[k], ref)
+        worst = max(worst, e)
+        # PReLU slope gradients are one scalar summed over a whole layer with heavy cancellation
+        assert e < (2e-3 if k.endswith(".2.weight") else 2e-4), (k, e)
+    print("worst relative gradient error", worst)
+
+
+def test_plan_constants_match_reference_kernels():
+    """STFT / iSTFT bases and the OLA normaliser the planner bakes into the constant arena (closed form)."""
+    B, L = 1, 4000
+    plan = Plan(B, L, **SMALL)
+    ar = plan.alloc_arenas("cpu")
+    # drive the STFT op alone with unit impulses is overkill: compare through a forward of random spectra instead
+    x = torch.randn(B, L) * 0.1
+    plan.io(ar, "wav", (B, L)).copy_(x)
+    sim_run(plan, PHASE_FWD, ar, 0, 1)
+    from oracle.frontend import conv_stft, conv_istft
+    assert rel_err(spec_to_ref(plan.view(ar, "spec"), B, plan.T, plan.NF), conv_stft(x)) < 1e-5
+    K = synthesis_kernel()
+    assert np.abs(K).max() > 0 and ola_normaliser(plan.T)[300:-300].min() > 1.49

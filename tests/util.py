@@ -18,18 +18,22 @@ def sub(g, prefix):
     return {k[len(p):]: v for k, v in g.items() if k.startswith(p)}
 
 
+def _t(a):
+    if torch.is_tensor(a):
+        return a.detach().cpu().double().reshape(-1)
+    return torch.as_tensor(np.asarray(a)).double().reshape(-1)
+
+
 def rel_err(a, b):
     """max |a-b| / max|b|  (the 'relative fp32' measure used for the 1e-3 bar)."""
-    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
-    b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
+    a, b = _t(a), _t(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     den = float(b.abs().max())
     return float((a - b).abs().max()) / (den if den > 0 else 1.0)
 
 
 def rel_l2(a, b):
-    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
-    b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
+    a, b = _t(a), _t(b)
     den = float(b.norm())
     return float((a - b).norm()) / (den if den > 0 else 1.0)
 
