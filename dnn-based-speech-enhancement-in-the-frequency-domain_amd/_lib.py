@@ -47,6 +47,7 @@ def lib():
         "sefd_plan_num_ops": (i32, [vp, i32]),
         "sefd_plan_ops": (vp, [vp, i32]),
         "sefd_op_size": (i32, []),
+        "sefd_plan_op_info": (i32, [vp, i32, i32, C.POINTER(i64)]),
         "sefd_plan_run": (i32, [vp, i32, i32, i32, C.POINTER(vp), vp]),
         "sefd_loss_ws_floats": (i64, [i32]),
         "sefd_loss_forward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp]),
@@ -64,5 +65,5 @@ def lib():
 EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_plan_arena_bytes", "sefd_plan_frames",
             "sefd_plan_num_params", "sefd_plan_param_name", "sefd_plan_param_offset", "sefd_plan_param_numel",
             "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
-            "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_run",
+            "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
             "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_adam_step"]

@@ -1,0 +1,67 @@
+"""Configuration surface - same names, defaults and asserts as the reference's config.py (config.py:1-107).
+
+Like the reference, it is a module of constants imported as `cfg`; constructor defaults of the models are bound at
+import time and `cfg.loss` / `cfg.perceptual` / `cfg.lstm` / `cfg.skip_type` / `cfg.dccrn_kernel_num` are read at
+construction / call time.  Differences: no banner print, DEVICE defaults to 'cuda' (the MI355X), and two build-side
+knobs (`act_dtype`, `ddp_sync_bn`) that the reference does not have.
+"""
+job_dir = './models/'
+logs_dir = './logs/'
+chkpt_model = None
+chkpt = str("EPOCH")
+
+model_list = ['DCCRN', 'CRN', 'FullSubNet']
+loss_list = ['MSE', 'SDR', 'SI-SNR', 'SI-SDR']
+perceptual_list = [False, 'LMS', 'PMSQE']
+lstm_type = ['real', 'complex']
+main_net = ['LSTM', 'GRU']
+mask_type = ['Direct(None make)', 'E', 'C', 'R']
+
+expr_num = 'EXPERIMENT_NUMBER'
+DEVICE = 'cuda'
+
+model = model_list[0]
+loss = loss_list[1]
+perceptual = perceptual_list[0]
+lstm = lstm_type[1]
+sequence_model = main_net[0]
+
+masking_mode = mask_type[1]
+skip_type = True
+
+max_epochs = 100
+learning_rate = 0.001
+batch = 10
+
+dccrn_kernel_num = [32, 64, 128, 256, 256, 256]
+
+fs = 16000
+win_len = 400
+win_inc = 100
+ola_ratio = 0.75
+fft_len = 512
+sam_sec = fft_len / fs
+frm_samp = fs * (fft_len / fs)
+window = 'hanning'
+
+rnn_layers = 2
+rnn_units = 256
+rnn_input_size = 512
+
+sb_num_neighbors = 15
+fb_num_neighbors = 0
+num_freqs = fft_len // 2 + 1
+look_ahead = 2
+fb_output_activate_function = "ReLU"
+sb_output_activate_function = None
+fb_model_hidden_size = 512
+sb_model_hidden_size = 384
+weight_init = False
+norm_type = "offline_laplace_norm"
+num_groups_in_drop_band = 2
+
+# ---- build-side knobs (not in the reference)
+act_dtype = 'fp32'        # 'fp32' (parity mode) or 'bf16' (storage + MFMA dtype of the conv stack)
+
+assert not (masking_mode == 'Direct(None make)' and perceptual is not False), "This setting is not created "
+assert not (model == 'FullSubNet' and perceptual is not False), "This setting is not created "

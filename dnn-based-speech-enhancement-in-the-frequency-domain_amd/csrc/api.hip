@@ -49,6 +49,23 @@ const void* sefd_plan_const_data(const sefd_plan* h) { return h->p->consts.data(
 int32_t sefd_plan_num_ops(const sefd_plan* h, int phase) { return (int32_t)(phase == 0 ? h->p->fwd.size() : h->p->bwd.size()); }
 const void* sefd_plan_ops(const sefd_plan* h, int phase) { return phase == 0 ? h->p->fwd.data() : h->p->bwd.data(); }
 int32_t sefd_op_size(void) { return (int32_t)sizeof(Op); }
+int32_t sefd_plan_op_info(const sefd_plan* h, int phase, int i, int64_t* o) {
+  const std::vector<Op>& ops = phase == 0 ? h->p->fwd : h->p->bwd;
+  if (i < 0 || i >= (int)ops.size()) return -1;
+  const Op& op = ops[i];
+  for (int k = 0; k < 8; ++k) o[k] = 0;
+  o[0] = op.kind; o[1] = op.tag;
+  if (op.kind == OP_RUNGEMM || op.kind == OP_WGRAD) {
+    const RunGemm& g = op.g;
+    int64_t K = 0;
+    for (int s = 0; s < g.nseg; ++s) K += g.seg[s].len;
+    o[2] = g.M; o[3] = g.N; o[4] = K; o[5] = g.xdt;
+    o[6] = 2 * (int64_t)g.M * g.N * K;                                     // algorithmic flops (true K, true N)
+    // algorithmic bytes: every source element once is not well defined for overlapping runs; report A-row + y + w traffic
+    o[7] = (int64_t)g.M * g.N * esize(g.ydt) + (int64_t)g.N * K * esize(g.xdt);
+  }
+  return 0;
+}
 
 int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream) {
   if (!h || !h->p->error.empty()) return -1;

@@ -1,0 +1,323 @@
+"""Drop-in `models` surface: `DCCRN` with the reference's constructor, forward/loss signatures and state_dict keys
+(reference models.py:15-323), computed by the gfx950 HIP library through its C ABI.
+
+The nn.Module tree only *holds* parameters (same names, shapes, init and registration order as the reference, so
+checkpoints interchange - SURVEY.md Appendix B).  All arithmetic - STFT, complex convs, BatchNorm+PReLU, complex
+LSTM, mask, iSTFT, losses, backward, Adam - runs in `libsefd_hip.so`; there is no PyTorch/CPU fallback.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import config as cfg
+from . import _lib
+from .frontend_consts import stft_kernels
+from .plan import (ARENA_COUNT, ARENA_CONST, ARENA_GRAD, ARENA_IO, ARENA_PARAM, ARENA_STATE, ARENA_WS, PHASE_BWD,
+                   PHASE_FWD, Plan)
+from . import tools_for_loss as tfl
+
+
+# ------------------------------------------------------------------------------------------ parameter holders
+class ConvSTFT(nn.Module):
+    """Buffer holder for `stft.weight` (tools_for_model.py:36-52)."""
+
+    def __init__(self, win_len, win_inc, fft_len, win_type, feature_type='complex', fix=True):
+        super().__init__()
+        K, _, _ = stft_kernels(win_len, fft_len, win_type)
+        self.register_buffer('weight', K)
+        self.feature_type, self.stride, self.win_len, self.dim = feature_type, win_inc, win_len, fft_len
+
+
+class ConviSTFT(nn.Module):
+    """Buffer holder for `istft.weight/window/enframe` (tools_for_model.py:71-88)."""
+
+    def __init__(self, win_len, win_inc, fft_len, win_type, feature_type='complex', fix=True):
+        super().__init__()
+        _, Kinv, w = stft_kernels(win_len, fft_len, win_type)
+        self.register_buffer('weight', Kinv)
+        self.register_buffer('window', w)
+        self.register_buffer('enframe', torch.eye(win_len)[:, None, :])
+        self.feature_type, self.stride, self.win_len, self.dim = feature_type, win_inc, win_len, fft_len
+
+
+class ComplexConv2d(nn.Module):
+    """Parameter holder with the reference's layout and init (tools_for_model.py:199-241)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.real_conv = nn.Conv2d(in_channels // 2, out_channels // 2, kernel_size, stride, padding=[padding[0], 0])
+        self.imag_conv = nn.Conv2d(in_channels // 2, out_channels // 2, kernel_size, stride, padding=[padding[0], 0])
+        for c in (self.real_conv, self.imag_conv):
+            nn.init.normal_(c.weight.data, std=0.05)
+            nn.init.constant_(c.bias, 0.)
+
+
+class ComplexConvTranspose2d(nn.Module):
+    """Parameter holder (tools_for_model.py:272-309)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, output_padding):
+        super().__init__()
+        self.real_conv = nn.ConvTranspose2d(in_channels // 2, out_channels // 2, kernel_size, stride, padding=padding,
+                                            output_padding=output_padding)
+        self.imag_conv = nn.ConvTranspose2d(in_channels // 2, out_channels // 2, kernel_size, stride, padding=padding,
+                                            output_padding=output_padding)
+        for c in (self.real_conv, self.imag_conv):
+            nn.init.normal_(c.weight.data, std=0.05)
+            nn.init.constant_(c.bias, 0.)
+
+
+class NavieComplexLSTM(nn.Module):
+    """Parameter holder (tools_for_model.py:141-160)."""
+
+    def __init__(self, input_size, hidden_size, projection_dim=None, bidirectional=False, batch_first=False):
+        super().__init__()
+        self.input_dim, self.rnn_units = input_size // 2, hidden_size // 2
+        self.real_lstm = nn.LSTM(self.input_dim, self.rnn_units, num_layers=1, bidirectional=False, batch_first=False)
+        self.imag_lstm = nn.LSTM(self.input_dim, self.rnn_units, num_layers=1, bidirectional=False, batch_first=False)
+        if projection_dim is not None:
+            self.projection_dim = projection_dim // 2
+            self.r_trans = nn.Linear(self.rnn_units, self.projection_dim)
+            self.i_trans = nn.Linear(self.rnn_units, self.projection_dim)
+        else:
+            self.projection_dim = None
+
+
+# ------------------------------------------------------------------------------------------ device runtime
+class _Runtime:
+    """Plan + device arenas for one (B, L, training, device) combination."""
+
+    def __init__(self, owner, B, L, training, device):
+        self.plan = Plan(B, L, kernel_num=tuple(owner.kernel_num[1:]), rnn_layers=owner.hidden_layers,
+                         rnn_units=owner.rnn_units, win_len=owner.win_len, win_inc=owner.win_inc, fft_len=owner.fft_len,
+                         masking_mode=owner.masking_mode, lstm=owner._lstm_kind, skip_type=owner._skip,
+                         act_dtype=owner.act_dtype, training=training)
+        p = self.plan
+        self.arenas = [None] * ARENA_COUNT
+        self.arenas[ARENA_WS] = torch.zeros(max(p.arena_bytes[ARENA_WS], 256), dtype=torch.uint8, device=device)
+        self.arenas[ARENA_CONST] = torch.from_numpy(p.const_image()).to(device)
+        self.arenas[ARENA_IO] = torch.zeros(p.arena_bytes[ARENA_IO], dtype=torch.uint8, device=device)
+        self.arenas[ARENA_PARAM] = owner._flat_param
+        self.arenas[ARENA_GRAD] = owner._flat_grad
+        self.arenas[ARENA_STATE] = owner._flat_state
+        T, NF = p.T, p.NF
+        self.wav = p.io(self.arenas, "wav", (B, L))
+        self.out_wav = p.io(self.arenas, "out_wav", (B, L))
+        self.out_real = p.io(self.arenas, "out_real", (B, NF, T))
+        self.out_imag = p.io(self.arenas, "out_imag", (B, NF, T))
+        self.g_wav = p.io(self.arenas, "grad_wav", (B, L))
+        self.g_real = p.io(self.arenas, "grad_real", (B, NF, T))
+        self.g_imag = p.io(self.arenas, "grad_imag", (B, NF, T))
+
+    def run(self, phase):
+        self.plan.run(phase, self.arenas, torch.cuda.current_stream().cuda_stream)
+
+
+class _DCCRNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, rt, inputs, *params):
+        rt.wav.copy_(inputs)
+        rt.run(PHASE_FWD)
+        ctx.owner, ctx.rt = owner, rt
+        ctx.n = len(params)
+        return rt.out_real.clone(), rt.out_imag.clone(), rt.out_wav.clone()
+
+    @staticmethod
+    def backward(ctx, g_real, g_imag, g_wav):
+        rt, owner = ctx.rt, ctx.owner
+        for dst, g in ((rt.g_real, g_real), (rt.g_imag, g_imag), (rt.g_wav, g_wav)):
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+        rt.run(PHASE_BWD)
+        flat = owner._flat_grad.clone()
+        grads = [flat[off:off + n].view(shape) for (off, n, shape) in owner._param_slices]
+        return (None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------ the model
+class DCCRN(nn.Module):
+    """Same constructor as the reference (models.py:17-28)."""
+
+    def __init__(self, rnn_layers=cfg.rnn_layers, rnn_units=cfg.rnn_units, win_len=cfg.win_len, win_inc=cfg.win_inc,
+                 fft_len=cfg.fft_len, win_type=cfg.window, masking_mode=cfg.masking_mode, use_cbn=False, kernel_size=5):
+        super().__init__()
+        if use_cbn:
+            raise NotImplementedError("ComplexBatchNorm (use_cbn=True) is not on the HIP path")
+        self.win_len, self.win_inc, self.fft_len, self.win_type = win_len, win_inc, fft_len, win_type
+        self.rnn_units = rnn_units
+        self.input_dim = self.output_dim = win_len
+        self.hidden_layers = rnn_layers
+        self.kernel_size = kernel_size
+        self.kernel_num = [2] + list(cfg.dccrn_kernel_num)
+        self.masking_mode = masking_mode
+        self.fix = True
+        self.act_dtype = cfg.act_dtype
+        self._lstm_kind = cfg.lstm
+        self._skip = bool(cfg.skip_type)
+        if cfg.lstm != 'complex':
+            raise NotImplementedError("cfg.lstm == 'real' is not on the HIP path yet")
+        self.stft = ConvSTFT(win_len, win_inc, fft_len, win_type, 'complex')
+        self.istft = ConviSTFT(win_len, win_inc, fft_len, win_type, 'complex')
+        self.encoder = nn.ModuleList()
+        self.decoder = nn.ModuleList()
+        kn = self.kernel_num
+        for idx in range(len(kn) - 1):
+            self.encoder.append(nn.Sequential(
+                ComplexConv2d(kn[idx], kn[idx + 1], kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 1)),
+                nn.BatchNorm2d(kn[idx + 1]), nn.PReLU()))
+        hidden_dim = fft_len // (2 ** len(kn))
+        rnns = []
+        for idx in range(rnn_layers):
+            rnns.append(NavieComplexLSTM(
+                input_size=hidden_dim * kn[-1] if idx == 0 else rnn_units, hidden_size=rnn_units,
+                projection_dim=hidden_dim * kn[-1] if idx == rnn_layers - 1 else None))
+        self.enhance = nn.Sequential(*rnns)      # registered here: the reference assigns it before the decoder is filled
+        mult = 2 if cfg.skip_type else 1
+        for idx in range(len(kn) - 1, 0, -1):
+            mods = [ComplexConvTranspose2d(kn[idx] * mult, kn[idx - 1], kernel_size=(kernel_size, 2), stride=(2, 1),
+                                           padding=(2, 0), output_padding=(1, 0))]
+            if idx != 1:
+                mods += [nn.BatchNorm2d(kn[idx - 1]), nn.PReLU()]
+            self.decoder.append(nn.Sequential(*mods))
+        # state_dict order of the reference: stft, istft, encoder, decoder, enhance
+        enh = self._modules.pop('enhance')
+        self._modules['enhance'] = enh
+        self._flat_param = self._flat_grad = self._flat_state = self._flat_nbt = None
+        self._param_slices = None
+        self._runtimes = {}
+
+    def flatten_parameters(self):
+        pass
+
+    # ---- flat storage ---------------------------------------------------------------------------------------
+    def _trainable(self):
+        return [(n, p) for n, p in self.named_parameters()]
+
+    def _bn_buffers(self):
+        out = []
+        for n, b in self.named_buffers():
+            if n.endswith(("running_mean", "running_var")):
+                out.append((n, b))
+        return out
+
+    def _flat_ok(self, device):
+        fp = self._flat_param
+        if fp is None or fp.device != device:
+            return False
+        ps = self._trainable()
+        first, last = ps[0][1], ps[-1][1]
+        off_last, n_last, _ = self._param_slices[-1]
+        return (first.data_ptr() == fp.data_ptr() and last.data_ptr() == fp.data_ptr() + 4 * off_last
+                and self._bn_buffers()[0][1].data_ptr() == self._flat_state.data_ptr())
+
+    def _flatten(self, device):
+        """Re-home every parameter / BatchNorm buffer as a view of one flat fp32 tensor (the C ABI's arenas)."""
+        ps = self._trainable()
+        total = sum(p.numel() for _, p in ps)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        slices, off = [], 0
+        for _, p in ps:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[off:off + n].view(p.shape)
+            slices.append((off, n, tuple(p.shape)))
+            off += n
+        bs = self._bn_buffers()
+        st = torch.empty(max(sum(b.numel() for _, b in bs), 1), dtype=torch.float32, device=device)
+        off = 0
+        mods = dict(self.named_modules())
+        for name, b in bs:
+            n = b.numel()
+            st[off:off + n].copy_(b.reshape(-1).to(device=device, dtype=torch.float32))
+            mname, leaf = name.rsplit(".", 1)
+            mods[mname]._buffers[leaf] = st[off:off + n].view(b.shape)
+            off += n
+        nbts = [(n, b) for n, b in self.named_buffers() if n.endswith("num_batches_tracked")]
+        nbt = torch.zeros(len(nbts), dtype=torch.long, device=device)
+        for i, (name, b) in enumerate(nbts):
+            nbt[i] = b.to(device)
+            mname, leaf = name.rsplit(".", 1)
+            mods[mname]._buffers[leaf] = nbt[i]
+        self._flat_param, self._flat_state, self._flat_nbt = flat, st, nbt
+        self._flat_grad = torch.zeros_like(flat)
+        self._param_slices = slices
+        self._runtimes = {}
+
+    def _runtime(self, B, L, device):
+        if not self._flat_ok(device):
+            self._flatten(device)
+        key = (B, L, bool(self.training), self.masking_mode, self.act_dtype)
+        rt = self._runtimes.get(key)
+        if rt is None:
+            rt = _Runtime(self, B, L, bool(self.training), device)
+            # the plan's parameter table must agree with the module tree (names, order, sizes)
+            names = [n for n, _ in self._trainable()]
+            assert names == list(rt.plan.params.keys()), "parameter order differs from the plan"
+            assert [s[0] for s in self._param_slices] == [v[0] for v in rt.plan.params.values()]
+            self._runtimes[key] = rt
+        return rt
+
+    # ---- reference surface ----------------------------------------------------------------------------------
+    def forward(self, inputs, targets=0):
+        if self.masking_mode == 'Direct(None make)':
+            raise NotImplementedError("Direct (spectral mapping) mode is not on the HIP path yet")
+        if not inputs.is_cuda:
+            raise RuntimeError("sefd DCCRN runs on the MI355X only (inputs must be a cuda tensor); there is no CPU fallback")
+        inputs = inputs.float().contiguous()
+        B, L = inputs.shape
+        rt = self._runtime(B, L, inputs.device)
+        if self.training:
+            self._flat_nbt += 1
+        params = [p for _, p in self._trainable()]
+        out_real, out_imag, out_wav = _DCCRNFunction.apply(self, rt, inputs, *params)
+        return out_real, out_imag, out_wav
+
+    def get_params(self, weight_decay=0.0):
+        weights, biases = [], []
+        for name, param in self.named_parameters():
+            (biases if 'bias' in name else weights).append(param)
+        return [{'params': weights, 'weight_decay': weight_decay}, {'params': biases, 'weight_decay': 0.0}]
+
+    def loss(self, estimated, target, real_spec=0, img_spec=0, perceptual=False):
+        """models.py:303-323."""
+        if perceptual:
+            if cfg.perceptual == 'LMS':
+                raise NotImplementedError("LMS perceptual loss: not on the HIP path yet")
+            raise NotImplementedError("PMSQE is third-party (asteroid) arithmetic: parity unpinned, not built")
+        if cfg.loss == 'MSE':
+            return tfl.mse(estimated, target)
+        elif cfg.loss == 'SDR':
+            return -tfl.sdr(target, estimated)
+        elif cfg.loss == 'SI-SNR':
+            return -(tfl.si_snr(estimated, target))
+        elif cfg.loss == 'SI-SDR':
+            return -(tfl.si_sdr(target, estimated))
+        raise ValueError(cfg.loss)
+
+    # ---- fused training step (what trainer.model_train does per batch, trainer.py:27-39) ---------------------
+    def train_step(self, inputs, targets, optimizer, loss_kind=None, exchange=None):
+        """forward -> loss -> backward -> Adam with no autograd bookkeeping; returns the loss as a 0-d device tensor."""
+        from .optim import Adam
+        if not isinstance(optimizer, Adam):
+            raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
+        kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
+        inputs = inputs.float()
+        B, L = inputs.shape
+        rt = self._runtime(B, L, inputs.device)
+        optimizer.bind(self)
+        self._flat_nbt += 1
+        stream = torch.cuda.current_stream().cuda_stream
+        rt.wav.copy_(inputs)
+        rt.run(PHASE_FWD)
+        ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets.float().contiguous(), stream)
+        rt.g_real.zero_()
+        rt.g_imag.zero_()
+        tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)
+        rt.run(PHASE_BWD)
+        if exchange is not None and exchange.world > 1:      # DDP: sum gradients over ranks (RCCL), average inside Adam
+            exchange.all_reduce(self._flat_grad)
+            optimizer.grad_scale = exchange.grad_scale
+        optimizer.step_flat()
+        return loss

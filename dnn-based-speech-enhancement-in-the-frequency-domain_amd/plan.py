@@ -76,6 +76,13 @@ class Plan:
         raw = np.ctypeslib.as_array((C.c_int32 * (n * sz // 4)).from_address(self.ops_ptr(phase))).reshape(n, sz // 4)
         return raw[:, 0].copy(), raw[:, 1].copy()
 
+    def op_info(self, phase, i):
+        """dict(kind, tag, M, N, K, dtype, flops, bytes) of op i (RUNGEMM / WGRAD carry the GEMM geometry)."""
+        o = (C.c_int64 * 8)()
+        if self.lib.sefd_plan_op_info(self.h, phase, i, o) != 0:
+            raise IndexError(i)
+        return dict(kind=int(o[0]), tag=int(o[1]), M=int(o[2]), N=int(o[3]), K=int(o[4]), dtype=int(o[5]), flops=int(o[6]), bytes=int(o[7]))
+
     def buffer(self, name):
         a, off, nb, dt = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
         if self.lib.sefd_plan_buffer(self.h, name.encode(), C.byref(a), C.byref(off), C.byref(nb), C.byref(dt)) != 0:

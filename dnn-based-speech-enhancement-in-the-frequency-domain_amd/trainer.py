@@ -1,0 +1,53 @@
+"""Step driver mirroring the reference's trainer.py train functions (trainer.py:15-82).
+
+`model_train(model, optimizer, train_loader, DEVICE)` has the reference's signature and epoch semantics (mean of the
+per-batch losses).  With `sefd_amd.optim.Adam` the whole batch step is the fused HIP path (`model.train_step`);
+with any other optimizer it is the literal reference loop (autograd Functions over the same HIP kernels)."""
+import torch
+
+from . import config as cfg
+from .optim import Adam
+
+
+def model_train(model, optimizer, train_loader, DEVICE):
+    train_loss = torch.zeros((), device=DEVICE)
+    batch_num = 0
+    model.train()
+    fused = isinstance(optimizer, Adam)
+    for inputs, targets in train_loader:
+        batch_num += 1
+        inputs = inputs.float().to(DEVICE, non_blocking=True)
+        targets = targets.float().to(DEVICE, non_blocking=True)
+        if fused:
+            loss = model.train_step(inputs, targets, optimizer)
+        else:
+            _, _, outputs = model(inputs, targets)
+            loss = model.loss(outputs, targets)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        train_loss += loss.detach()          # the reference accumulates the graph-attached tensor (trainer.py:39)
+    return train_loss / max(batch_num, 1)
+
+
+def model_perceptual_train(model, optimizer, train_loader, DEVICE):
+    """trainer.py:45-82: loss = (main + perceptual) / 2, forward called without targets."""
+    train_loss = train_main = train_perc = 0
+    batch_num = 0
+    model.train()
+    for inputs, targets in train_loader:
+        batch_num += 1
+        inputs = inputs.float().to(DEVICE)
+        targets = targets.float().to(DEVICE)
+        real_spec, img_spec, outputs = model(inputs)
+        main_loss = model.loss(outputs, targets)
+        perceptual_loss = model.loss(outputs, targets, real_spec, img_spec, perceptual=True)
+        loss = (main_loss + perceptual_loss) / 2
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        train_loss += loss.detach()
+        train_main += main_loss.detach()
+        train_perc += perceptual_loss.detach()
+    n = max(batch_num, 1)
+    return train_loss / n, train_main / n, train_perc / n

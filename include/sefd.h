@@ -64,6 +64,8 @@ const void* sefd_plan_const_data(const sefd_plan* p);
 int32_t sefd_plan_num_ops(const sefd_plan* p, int phase);
 const void* sefd_plan_ops(const sefd_plan* p, int phase);
 int32_t sefd_op_size(void);
+/* per-op summary for measurement: out = {kind, tag, M, N, K (true run length), operand dtype, algorithmic flops, algorithmic bytes} */
+int32_t sefd_plan_op_info(const sefd_plan* p, int phase, int i, int64_t* out8);
 
 /* ---- execution (device) --------------------------------------------------------------------------
  * arenas: SEFD_ARENA_COUNT device pointers.  Runs ops [first, last) of the phase on `stream`.

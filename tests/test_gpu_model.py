@@ -1,0 +1,143 @@
+"""GPU tier: the drop-in `models.DCCRN` (HIP library through the C ABI) against the golden vectors captured from the
+real reference and against the oracle on fresh seeded inputs: outputs, loss, every parameter gradient, BatchNorm
+running statistics and the parameters after one Adam step.  Tolerance: 1e-3 relative fp32 (BASELINE north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.dccrn import DCCRNConfig, dccrn_state_shapes, is_trainable
+from oracle.step import dccrn_train_step
+from oracle.weights import fill_state_dict_, formula_state_dict, test_signals as make_signals
+from util import load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+CASES = [
+    ("small_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR"),
+    ("small_C_sdr", (16, 32, 32, 64, 64, 64), 128, "C", "SDR"),
+    ("small_R_mse", (16, 32, 32, 64, 64, 64), 128, "R", "MSE"),
+    ("small_E_sisdr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SDR"),
+    ("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR"),
+]
+
+
+def make_model(kn, ru, mask, loss):
+    import sefd_amd
+    from sefd_amd import config as cfg, models
+    cfg.dccrn_kernel_num = list(kn)
+    cfg.masking_mode = mask
+    cfg.loss = loss
+    cfg.perceptual = False
+    cfg.lstm = "complex"
+    cfg.skip_type = True
+    cfg.act_dtype = "fp32"
+    m = models.DCCRN(rnn_units=ru, masking_mode=mask)
+    fill_state_dict_(m)
+    return m.to("cuda")
+
+
+def noise_bias(k):
+    return k.endswith("conv.bias") and not k.startswith("decoder.5.")
+
+
+@pytest.mark.parametrize("name,kn,ru,mask,loss", CASES)
+def test_module_step_against_reference_golden(name, kn, ru, mask, loss):
+    g = load_golden("dccrn_" + name)
+    B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
+    m = make_model(kn, ru, mask, loss)
+    m.train()
+    x, y = make_signals(B, L)
+    x, y = x.cuda(), y.cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    P0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    o_r, o_i, wav = m(x, y)
+    lossv = m.loss(wav, y)
+    opt.zero_grad()
+    lossv.backward()
+    assert rel_err(o_r, g["g/out_real"]) < TOL
+    assert rel_err(o_i, g["g/out_imag"]) < TOL
+    assert rel_err(wav, g["g/out_wav"]) < TOL
+    assert abs(float(lossv) - float(g["g/loss"])) < TOL * max(1.0, abs(float(g["g/loss"])))
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    gn = sub(g, "g/grad_norm")
+    for k, v in gn.items():
+        if noise_bias(k):
+            continue
+        assert abs(float(grads[k].double().norm()) - float(v)) <= TOL * float(v) + 1e-7, k
+    for k, v in sub(g, "g/grad").items():
+        if noise_bias(k):
+            assert float(grads[k].abs().max()) < 1e-4 * float(gn[k.replace(".bias", ".weight")]) + 1e-7, k
+            continue
+        tol = 5e-3 if k.endswith(".2.weight") else TOL      # PReLU slope: a single heavily-cancelling sum
+        assert rel_err(grads[k], v) < tol, k
+    for k, v in sub(g, "g/grad_samp").items():
+        if not noise_bias(k):
+            assert rel_err(grads[k].reshape(-1)[::53], v) < TOL, k
+    opt.step()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for k, v in sub(g, "g/running").items():
+        assert rel_err(sd[k], v) < TOL, k
+    for k, v in sub(g, "g/after_adam").items():
+        if noise_bias(k):
+            continue
+        assert np.abs((sd[k].numpy() - P0[k].numpy()) - (v - P0[k].numpy())).max() < 5e-5, k   # updates are ~lr = 1e-3
+    assert int(sd["encoder.0.1.num_batches_tracked"]) == 1
+
+
+def test_fused_train_step_matches_oracle_two_steps():
+    """model.train_step (no autograd, flat fused Adam) == oracle forward/backward/Adam, two consecutive steps."""
+    from sefd_amd.optim import Adam
+    kn, ru = (16, 32, 32, 64, 64, 64), 128
+    m = make_model(kn, ru, "C", "SI-SNR")
+    m.train()
+    B, L = 3, 4000
+    torch.manual_seed(11)
+    y = torch.randn(B, L) * 0.1
+    x = y + 0.05 * torch.randn(B, L)
+    cfg = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode="C")
+    P = formula_state_dict(dccrn_state_shapes(cfg))
+    opt = Adam(m.parameters(), lr=1e-3)
+    state = None
+    for step in (1, 2):
+        r = dccrn_train_step(P, cfg, x, y, loss_kind="SI-SNR", adam_state=state, step=step)
+        loss = m.train_step(x.cuda(), y.cuda(), opt)
+        assert abs(float(loss) - float(r["loss"])) < TOL * max(1.0, abs(float(r["loss"]))), step
+        P = {**P, **r["new_params"], **r["new_stats"]}
+        state = r["adam_state"]
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        for k in r["new_stats"]:
+            assert rel_err(sd[k], P[k]) < TOL, (step, k)
+        worst = 0.0
+        for k in r["new_params"]:
+            if noise_bias(k):
+                continue
+            worst = max(worst, float((sd[k] - P[k]).abs().max()))
+        assert worst < 1e-4 * step, (step, worst)          # parameter updates are O(lr) = 1e-3 per step
+
+
+def test_full_length_clip_and_properties():
+    """BASELINE-size clip (3 s @ 16 kHz, T = 483): golden outputs, plus size-independent properties."""
+    g = load_golden("dccrn_default_C_sisnr_full")
+    m = make_model((32, 64, 128, 256, 256, 256), 256, "C", "SI-SNR")
+    m.train()
+    x, y = make_signals(1, 48000)
+    o_r, o_i, wav = m(x.cuda(), y.cuda())
+    assert rel_err(o_r, g["g/out_real"]) < TOL
+    assert rel_err(wav, g["g/out_wav"]) < TOL
+    assert abs(float(m.loss(wav, y.cuda())) - float(g["g/loss"])) < TOL * abs(float(g["g/loss"]))
+    assert float(wav.abs().max()) <= 1.0                        # clamp (models.py:282)
+    assert float(o_r[:, 0].abs().max()) == 0.0                  # zero DC row
+    # batch independence in eval mode: utterance b of a batch == the same utterance alone
+    m.eval()
+    xs, _ = make_signals(3, 8000)
+    with torch.no_grad():
+        full = m(xs.cuda())[2]
+        one = m(xs[1:2].cuda())[2]
+    assert rel_err(full[1:2], one) < 1e-5
+
+
+def test_cpu_tensor_is_rejected_not_silently_computed():
+    m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4000))
