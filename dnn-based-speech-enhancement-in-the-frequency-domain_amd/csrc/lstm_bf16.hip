@@ -1,0 +1,201 @@
+// bf16 variant of the persistent LSTM recurrence (see kernels.hip for the fp32 parity version and the design notes).
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15], D[row=4*(l>>4)+r][col=l&15], fp32 accumulate.
+// Arithmetic contract of bf16 mode: the recurrent operands (h_{t-1}, W_hh, and dgates_t in the backward) are rounded to
+// bf16; gate pre-activations from the input GEMM, the cell state and all gate math stay fp32.
+#include <hip/hip_runtime.h>
+#include "sefd_desc.h"
+#include "dev_common.h"
+
+namespace sefd {
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+template <int HMAX>
+__global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d, const ArenaBases ab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];
+  const int H = d.H, T = d.T;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = blockIdx.y, b0 = blockIdx.x * 16;
+  const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
+  const float* gx = reinterpret_cast<const float*>(rp(ab, d.gx)) + d.gx_goff[g];
+  uint16_t* hout = reinterpret_cast<uint16_t*>(rp(ab, d.h));
+  float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
+  float* cs = reinterpret_cast<float*>(rp(ab, d.c));
+  const int hs = H + 8;                       // LDS row stride in bf16 elements (16-byte aligned rows, rotating 16-B slots)
+  uint16_t* hbuf[2] = {ldsh, ldsh + 16 * hs};
+  const int KS = H / 32;
+  const int unit = 16 * w + (lane & 15);
+  const int kq = lane >> 4;
+
+  uint4 wreg[4][HMAX / 32];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int ks = 0; ks < HMAX / 32; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ks < KS) {
+        const float* p = whh + (int64_t)(q * H + unit) * H + 32 * ks + 8 * kq;
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v = make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+      }
+      wreg[q][ks] = v;
+    }
+  for (int i = threadIdx.x; i < 2 * 16 * hs; i += blockDim.x) ldsh[i] = 0;
+  __syncthreads();
+
+  bool rvalid[4];
+  int64_t rowbt[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * kq + r;
+    rvalid[r] = b < d.B;
+    rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
+  }
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  float gxv[4][4];
+  auto load_gx = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gxv[q][r] = rvalid[r] ? gx[(rowbt[r] + t) * d.gx_ld + q * H + unit] : 0.f;
+  };
+  load_gx(0);
+  const int64_t GBT = (int64_t)d.B * T;
+  for (int t = 0; t < T; ++t) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = gxv[q][r];
+    if (t + 1 < T) load_gx(t + 1);
+    const uint16_t* hp = hbuf[t & 1];
+    if (t > 0) {
+#pragma unroll
+      for (int ks = 0; ks < HMAX / 32; ++ks) {
+        if (ks < KS) {
+          const uint4 a = *reinterpret_cast<const uint4*>(hp + (lane & 15) * hs + 32 * ks + 8 * kq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wreg[q][ks]), acc[q], 0, 0, 0);
+        }
+      }
+    }
+    uint16_t* hn = hbuf[(t + 1) & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+      c[r] = fg * c[r] + ig * gg;
+      const uint16_t hb = f2bf(og * tanhf(c[r]));
+      hn[(4 * kq + r) * hs + unit] = hb;
+      if (rvalid[r]) {
+        const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
+        hout[row * H + unit] = hb;
+        gates[row * 4 * H + unit] = ig;
+        gates[row * 4 * H + H + unit] = fg;
+        gates[row * 4 * H + 2 * H + unit] = gg;
+        gates[row * 4 * H + 3 * H + unit] = og;
+        cs[row * H + unit] = c[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int HMAX>
+__global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d, const ArenaBases ab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];
+  const int H = d.H, T = d.T;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = blockIdx.y, b0 = blockIdx.x * 16;
+  const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
+  const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates));
+  const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
+  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
+  char* dgo = rp(ab, d.dgates);
+  const int gs = 4 * H + 8;
+  const int unit = 16 * w + (lane & 15);
+  const int kq = lane >> 4;
+  const int KS = 4 * H / 32;
+
+  uint4 wreg[HMAX / 8];                       // B[k = n][j = unit] = W_hh[n][unit], n = 32*ks + 8*kq + e
+#pragma unroll
+  for (int ks = 0; ks < HMAX / 8; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ks < KS) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = whh[(int64_t)(32 * ks + 8 * kq + e) * H + unit];
+      v = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+    }
+    wreg[ks] = v;
+  }
+  bool rvalid[4];
+  int64_t rowbt[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * kq + r;
+    rvalid[r] = b < d.B;
+    rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
+  }
+  const int64_t GBT = (int64_t)d.B * T;
+  float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float di = 0.f, df = 0.f, dg = 0.f, dog = 0.f;
+      if (rvalid[r]) {
+        const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
+        const float ig = gates[row * 4 * H + unit], fg = gates[row * 4 * H + H + unit];
+        const float gg = gates[row * 4 * H + 2 * H + unit], og = gates[row * 4 * H + 3 * H + unit];
+        const float ct = cs[row * H + unit];
+        const float cp = t > 0 ? cs[(row - 1) * H + unit] : 0.f;
+        const float dht = dh[row * H + unit] + dhrec[r];
+        const float tc = tanhf(ct);
+        dog = dht * tc * og * (1.f - og);
+        const float dc = dht * og * (1.f - tc * tc) + dcarry[r];
+        di = dc * gg * ig * (1.f - ig);
+        df = dc * cp * fg * (1.f - fg);
+        dg = dc * ig * (1.f - gg * gg);
+        dcarry[r] = dc * fg;
+        const int64_t o = d.gx_goff[g] + (rowbt[r] + t) * d.gx_ld;
+        st_elem(dgo, d.gdt, o + unit, di);
+        st_elem(dgo, d.gdt, o + H + unit, df);
+        st_elem(dgo, d.gdt, o + 2 * H + unit, dg);
+        st_elem(dgo, d.gdt, o + 3 * H + unit, dog);
+      }
+      uint16_t* lrow = ldsh + (4 * kq + r) * gs;
+      lrow[unit] = f2bf(di); lrow[H + unit] = f2bf(df); lrow[2 * H + unit] = f2bf(dg); lrow[3 * H + unit] = f2bf(dog);
+    }
+    __syncthreads();
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {
+#pragma unroll
+      for (int ks = 0; ks < HMAX / 8; ks += 2) {
+        if (ks < KS) {
+          const uint4 x0 = *reinterpret_cast<const uint4*>(ldsh + (lane & 15) * gs + 32 * ks + 8 * kq);
+          const uint4 x1 = *reinterpret_cast<const uint4*>(ldsh + (lane & 15) * gs + 32 * (ks + 1) + 8 * kq);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x0), __builtin_bit_cast(bf16x8, wreg[ks]), a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x1), __builtin_bit_cast(bf16x8, wreg[ks + 1]), a1, 0, 0, 0);
+        }
+      }
+    }
+    dhrec = a0 + a1;
+    __syncthreads();
+  }
+}
+
+template <int HMAX>
+static void launch_t(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  dim3 grid((d.B + 15) / 16, d.G);
+  dim3 block(64 * (d.H / 16));
+  if (fwd) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX>), grid, block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);
+  else hipLaunchKernelGGL((lstm_bwd_bf16_kernel<HMAX>), grid, block, 16 * (4 * d.H + 8) * sizeof(uint16_t), st, d, ab);
+}
+
+void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  if (d.H <= 64) launch_t<64>(d, ab, st, fwd);
+  else launch_t<128>(d, ab, st, fwd);
+}
+
+}  // namespace sefd

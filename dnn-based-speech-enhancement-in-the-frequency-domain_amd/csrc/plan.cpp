@@ -137,8 +137,7 @@ struct Builder {
   // WGRAD for the layer whose forward descriptor is `f` (same A runs + a ones run) against upstream gradient `dy`.
   void wgrad(std::vector<Op>& ops, const RunGemm& f, Ptr dy, const Coef& coef, int tag,
              const std::function<void(int n, int32_t out[2])>* bias) {
-    RunGemm g = f;
-    g.xdt = DT_F32;   // TODO(bf16): transposing bf16 WGRAD variant; planner keeps WGRAD operands fp32 for now
+    RunGemm g = f;            // operands keep the forward dtype: fp32 -> 32x32x2 fp32 MFMA, bf16 -> transposing 16x16x32 bf16 MFMA
     if (bias && g.nseg < kMaxSeg) {
       Seg& o = g.seg[g.nseg++];
       o.src = -1; o.dt = 0; o.off = 0; o.len = 1; o.koff = 0;
@@ -247,6 +246,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   for (int i = 1; i <= n; ++i)
     if (ch[i] % 8 != 0 && !(i == 0)) { P->error = "channel counts must be multiples of 8"; return P; }
   if (H % 16 != 0 || H > 128) { P->error = "rnn_units/2 must be a multiple of 16 and <= 128"; return P; }
+  if (adt == DT_BF16 && H % 32 != 0) { P->error = "bf16: rnn_units/2 must be a multiple of 32"; return P; }
   if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
 
   // ------------------------------------------------------------------ parameters (reference registration order)
@@ -351,6 +351,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
 
   // ------------------------------------------------------------------ STFT (ConvSTFT.forward, tools_for_model.py:54-61)
   Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
+  Ptr spec_lp = spec;
   {
     RunGemm g = Builder::gemm0();
     g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
@@ -362,13 +363,18 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kun(nn & 1, nn / 2 - 1, j) * win[j]; });
     g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_tstride = 0; g.y_fstride = SW; g.y_off = 0;
     b.push(F, OP_RUNGEMM, 1).g = g;
+    if (adt == DT_BF16) {      // bf16 mode: the encoder reads a bf16 copy of the spectrogram (second epilogue of the same GEMM)
+      spec_lp = b.ws("spec.bf16", (int64_t)B * T * SW, DT_BF16);
+      g.y = spec_lp; g.ydt = DT_BF16;
+      b.push(F, OP_RUNGEMM, 1).g = g;
+    }
   }
 
   // ------------------------------------------------------------------ encoder
   struct Layer { RunGemm f[2]; Builder::Coef coef[2]; std::function<void(int, int32_t*)> bias; bool has_bias_fn; Ptr y, z, mi; int C, Fq; int64_t R; };
   std::vector<Layer> enc(n), dec(n);
   std::vector<Ptr> encz(n), ency(n), enc_mi(n);
-  Ptr prev = spec;
+  Ptr prev = spec_lp;
   for (int i = 0; i < n; ++i) {
     const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
     const std::string nm = "enc" + std::to_string(i);
@@ -377,7 +383,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     const ParamInfo &br = b.par(pp + ".0.real_conv.bias"), &bi = b.par(pp + ".0.imag_conv.bias");
     RunGemm g = Builder::gemm0();
     g.x[0] = prev;
-    g.xdt = (i == 0) ? DT_F32 : adt;
+    g.xdt = adt;
     g.ydt = adt;
     if (i == 0) { g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.base[0] = 4; }
     else { g.bstride[0] = (int64_t)T * Fi * Ci; g.tstride[0] = Fi * Ci; g.base[0] = 0; }
@@ -775,7 +781,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const std::string pp = "enhance." + std::to_string(l);
       const ParamInfo* Whh[2] = {&b.par(pp + ".real_lstm.weight_hh_l0"), &b.par(pp + ".imag_lstm.weight_hh_l0")};
       Ptr dh = b.ws(nm + ".dh", 4 * BT * H, DT_F32);
-      Ptr dgates = b.ws(nm + ".dgates", 2 * BT * 8 * H, DT_F32);
+      Ptr dgates = b.ws(nm + ".dgates", 2 * BT * 8 * H, adt);
+      const int64_t dg_half = BT * 8 * H * esize(adt);
       {
         Op& op = b.push(R, OP_COMBINE_BWD, 200 + l);
         op.comb.h = dh; op.comb.out = dhc_next; op.comb.rows = BT; op.comb.H = H; op.comb.dt = DT_F32;
@@ -787,16 +794,18 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         r.whh[0] = b.pptr(pp + ".real_lstm.weight_hh_l0"); r.whh[1] = b.pptr(pp + ".imag_lstm.weight_hh_l0");
         r.h = ls[l].h; r.gates = ls[l].gates; r.c = ls[l].cst; r.dh = dh; r.dgates = dgates;
         for (int g4 = 0; g4 < 4; ++g4) r.gx_goff[g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
-        r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = DT_F32;
+        r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = adt;
       }
       for (int p = 0; p < 2; ++p) {
-        Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * BT * 8 * H * 4);
-        b.wgrad(R, ls[l].gx[p], dyp, ls[l].cgx[p], 200 + l, &ls[l].bgx);
+        Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);
+        RunGemm fw = ls[l].gx[p];
+        fw.ydt = adt;                       // WGRAD reads dy = dgates (act dtype), not the fp32 gx the forward wrote
+        b.wgrad(R, fw, dyp, ls[l].cgx[p], 200 + l, &ls[l].bgx);
       }
       for (int g4 = 0; g4 < 4; ++g4) {       // W_hh: dW[n][k] = sum_t dgates[g][t][n] * h[g][t-1][k]
         const int p = g4 / 2, set = g4 % 2;
         RunGemm f = Builder::gemm0();
-        f.x[0] = b.mk(A_WS, ls[l].h.off + (int64_t)g4 * BT * H * esize(adt)); f.xdt = adt; f.ydt = DT_F32;
+        f.x[0] = b.mk(A_WS, ls[l].h.off + (int64_t)g4 * BT * H * esize(adt)); f.xdt = adt; f.ydt = adt;
         f.bstride[0] = (int64_t)T * H; f.tstride[0] = H; f.rowlen[0] = H; f.Tin[0] = T;
         f.M = (int)BT; f.Tout = T; f.Fo = 1;
         f.nseg = 1; f.seg[0] = Seg{0, -1, 0, H, 0};
@@ -805,7 +814,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         f.y_bstride = (int64_t)T * 8 * H; f.y_tstride = 8 * H; f.y_off = set * 4 * H;
         const ParamInfo* Wp = Whh[set];
         Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)nn * H + j, 1); };
-        Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * BT * 8 * H * 4);
+        Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);
         b.wgrad(R, f, dyp, coef, 200 + l, nullptr);
       }
       // input gradient of the layer
@@ -815,7 +824,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         const int nout = l == 0 ? D : 1;
         for (int q = 0; q < nout; ++q) {
           RunGemm g = Builder::gemm0();
-          g.x[0] = b.mk(A_WS, dgates.off + (int64_t)p * BT * 8 * H * 4); g.xdt = DT_F32;
+          g.x[0] = b.mk(A_WS, dgates.off + (int64_t)p * dg_half); g.xdt = adt;
           g.bstride[0] = (int64_t)T * 8 * H; g.tstride[0] = 8 * H; g.rowlen[0] = 8 * H; g.Tin[0] = T;
           g.M = (int)BT; g.Tout = T; g.Fo = 1;
           g.nseg = 1; g.seg[0] = Seg{0, 0, 0, 8 * H, 0};

@@ -259,7 +259,9 @@ void run_op(const Op& op, const AB& ab) {
       float* gates = (float*)rp(ab, d.gates);
       float* cs = (float*)rp(ab, d.c);
       for (int g = 0; g < d.G; ++g) {
-        const float* whh = (const float*)rp(ab, d.whh[g % d.nset]);
+        const float* whh_ = (const float*)rp(ab, d.whh[g % d.nset]);
+        std::vector<float> whh(whh_, whh_ + (size_t)4 * H * H);
+        if (d.hdt == DT_BF16) for (auto& x : whh) x = bf2f(f2bf(x));     // bf16 mode: recurrent operands are bf16
         for (int b = 0; b < d.B; ++b) {
           std::vector<double> h(H, 0.0), c(H, 0.0), hn(H);
           for (int t = 0; t < T; ++t) {
@@ -269,7 +271,7 @@ void run_op(const Op& op, const AB& ab) {
               double pre[4];
               for (int q = 0; q < 4; ++q) {
                 double s = gx[q * H + j];
-                const float* wr = whh + (int64_t)(q * H + j) * H;
+                const float* wr = whh.data() + (int64_t)(q * H + j) * H;
                 for (int k = 0; k < H; ++k) s += h[k] * wr[k];
                 pre[q] = s;
               }
@@ -296,7 +298,9 @@ void run_op(const Op& op, const AB& ab) {
       const float* cs = (const float*)rp(ab, d.c);
       const float* dh = (const float*)rp(ab, d.dh);
       for (int g = 0; g < d.G; ++g) {
-        const float* whh = (const float*)rp(ab, d.whh[g % d.nset]);
+        const float* whh_ = (const float*)rp(ab, d.whh[g % d.nset]);
+        std::vector<float> whh(whh_, whh_ + (size_t)4 * H * H);
+        if (d.hdt == DT_BF16) for (auto& x : whh) x = bf2f(f2bf(x));
         for (int b = 0; b < d.B; ++b) {
           std::vector<double> dhrec(H, 0.0), dc(H, 0.0), dg(4 * H);
           for (int t = T - 1; t >= 0; --t) {
@@ -317,7 +321,7 @@ void run_op(const Op& op, const AB& ab) {
             for (int k = 0; k < 4 * H; ++k) st(rp(ab, d.dgates), d.gdt, o + k, (float)dg[k]);
             for (int j = 0; j < H; ++j) {
               double s = 0;
-              if (t > 0) for (int k = 0; k < 4 * H; ++k) s += dg[k] * whh[(int64_t)k * H + j];
+              if (t > 0) for (int k = 0; k < 4 * H; ++k) s += (d.hdt == DT_BF16 ? (double)bf2f(f2bf((float)dg[k])) : dg[k]) * whh[(int64_t)k * H + j];
               dhrec[j] = s;
             }
           }
