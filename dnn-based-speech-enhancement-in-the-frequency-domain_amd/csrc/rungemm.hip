@@ -353,6 +353,127 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const RunGemm d, const Arena
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// WGRAD (bf16 MFMA).  The contraction index of a weight gradient is the pixel row m, which is the *strided* index of
+// both channels-last operands, while v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane.  gfx950's LDS transpose
+// read does the turn for free: ds_read_b64_tr_b16 with lane i of a 16-lane group pointing at (row 4g + i/4, col 4(i%4))
+// of a row-major [m][c] tile returns (rows 4g..4g+3, col i) - four consecutive m for one channel (probed on MI355X,
+// tools/probe_tr16.hip).  Two such reads (rows +0 and +16) fill one 8-wide k fragment; A and B use the same m order.
+// Workgroup tile TN (n) x 128 (k), 4 waves as 2x2, 32 reduction rows per step, fp32 partial sums per row split.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+struct Frag8 { s16x4 lo, hi; };
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int pitch, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const uint16_t* p = tile + (4 * g + (i >> 2)) * pitch + col0 + 4 * (i & 3);
+  Frag8 f;
+  f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 16 * pitch));
+  return __builtin_bit_cast(bf16x8, f);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const RunGemm d, const ArenaBases ab) {
+  constexpr int TK = kWgTK, RS = kWgRows, PN = TN + 8, PK = TK + 8;
+  constexpr int NT = TN / 32;                  // 16-wide n tiles per wave
+  constexpr int DPASS = TN / 64;               // dy chunk passes per thread
+  __shared__ __attribute__((aligned(16))) uint16_t dys[2][RS][PN];
+  __shared__ __attribute__((aligned(16))) uint16_t as[2][RS][PK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ntile = blockIdx.x, ktile = blockIdx.y, split = blockIdx.z;
+  const bf16_t* x0 = reinterpret_cast<const bf16_t*>(rp(ab, d.x[0]));
+  const bf16_t* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const bf16_t*>(rp(ab, d.x[1])) : x0;
+  const uint16_t* dy = reinterpret_cast<const uint16_t*>(rp(ab, d.y));
+  float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)split * d.Npad * d.ldw;
+
+  const int nsteps_total = (d.M + RS - 1) / RS;
+  const int per = (nsteps_total + d.nsplit - 1) / d.nsplit;
+  const int step0 = split * per;
+  const int step1 = min(nsteps_total, step0 + per);
+  const int TF = d.Tout * d.Fo;
+
+  // A gather: 16 chunks (8 bf16) per row; rows ra + 16p
+  const int ca = tid & 15, ra = tid >> 4;
+  const int kcol = ktile * TK + ca * 8;
+  int sgi = -1, j0 = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const int plen = (d.seg[s].len + 63) / 64 * 64;
+    if (kcol >= d.seg[s].koff && kcol < d.seg[s].koff + plen) { sgi = s; j0 = kcol - d.seg[s].koff; }
+  }
+  Seg sg;
+  if (sgi >= 0) sg = d.seg[sgi]; else { sg.src = 0; sg.dt = 0; sg.off = 0; sg.len = 0; sg.koff = 0; }
+  // dy: TN/8 chunks per row
+  constexpr int DCH = TN / 8;
+  const int cd = tid % DCH, rd = tid / DCH;     // rows rd + (256/DCH) p
+  const int ncol = ntile * TN + cd * 8;
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wn = (wid >> 1) * (TN / 2), wk = (wid & 1) * 64;
+
+  uint4 aReg[2], dReg[DPASS];
+  auto issue = [&](int step) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = step * RS + ra + 16 * p;
+      const bool v = m < d.M;
+      const int mm = v ? m : 0;
+      const int b = mm / TF, rem = mm - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
+      aReg[p] = load_a_chunk<bf16_t>(d, x0, x1, sg, (int64_t)b * d.bstride[0] + d.base[0], (int64_t)b * d.bstride[1] + d.base[1],
+                                     u, fo, v && sgi >= 0, j0);
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) {
+      const int m = step * RS + rd + (256 / DCH) * p;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (m < d.M) {
+        const int b = m / TF, rem = m - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
+        const uint16_t* src = dy + (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off + ncol;
+        if (ncol + 8 <= d.N) z = *reinterpret_cast<const uint4*>(src);
+        else {
+          uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int e = 0; e < 8; ++e) if (ncol + e < d.N) v[e] = src[e];
+          z = make_uint4(v[0] | (uint32_t)v[1] << 16, v[2] | (uint32_t)v[3] << 16, v[4] | (uint32_t)v[5] << 16, v[6] | (uint32_t)v[7] << 16);
+        }
+      }
+      dReg[p] = z;
+    }
+  };
+  if (step0 < step1) issue(step0);
+  for (int st = step0; st < step1; ++st) {
+    const int buf = (st - step0) & 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&as[buf][ra + 16 * p][ca * 8]) = aReg[p];
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) *reinterpret_cast<uint4*>(&dys[buf][rd + (256 / DCH) * p][cd * 8]) = dReg[p];
+    __syncthreads();
+    if (st + 1 < step1) issue(st + 1);
+    bf16x8 af[NT], bfr[4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) af[a] = tr_frag(&dys[buf][0][0], PN, wn + a * 16, lane);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bfr[b] = tr_frag(&as[buf][0][0], PK, wk + b * 16, lane);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = ntile * TN + wn + a * 16 + 4 * (lane >> 4) + r;
+        const int k = ktile * TK + wk + b * 16 + (lane & 15);
+        if (n < d.Npad && k < d.ldw) part[(int64_t)n * d.ldw + k] = acc[a][b][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 template <typename TA>
 static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   const int bn = bn_of(d.N);
@@ -369,6 +490,16 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 }
 
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (d.xdt == DT_BF16) {
+    if (d.Npad >= 128) {
+      dim3 grid((d.Npad + 127) / 128, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
+      hipLaunchKernelGGL((wgrad_bf16_kernel<128>), grid, dim3(256), 0, st, d, ab);
+    } else {
+      dim3 grid((d.Npad + 63) / 64, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
+      hipLaunchKernelGGL((wgrad_bf16_kernel<64>), grid, dim3(256), 0, st, d, ab);
+    }
+    return;
+  }
   dim3 grid((d.Npad + kWgTN - 1) / kWgTN, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
   hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, st, d, ab);
 }
