@@ -132,6 +132,45 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
     print(f"dccrn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
 
 
+def crn_case(cfg, models, name, kernel_num, rnn_units, rnn_input, mask, loss, B, L):
+    cfg.dccrn_kernel_num = list(kernel_num)
+    cfg.masking_mode = mask
+    cfg.loss = loss
+    cfg.perceptual = False
+    cfg.skip_type = True
+    torch.manual_seed(0)
+    m = models.CRN(rnn_units=rnn_units, rnn_input_size=rnn_input, masking_mode=mask)
+    fill_state_dict_(m)
+    m.train()
+    x, y = test_signals(B, L)
+    taps = {}
+    hooks = [layer[0].register_forward_hook(lambda mod, i, o, k=f"enc{j}.conv": taps.__setitem__(k, sample(o))) for j, layer in enumerate(m.encoder)]
+    hooks += [layer[0].register_forward_hook(lambda mod, i, o, k=f"dec{j}.conv": taps.__setitem__(k, sample(o))) for j, layer in enumerate(m.decoder)]
+    hooks.append(m.tranform.register_forward_hook(lambda mod, i, o: taps.__setitem__("lstm", sample(o))))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    est_mags, target_mags, wav = m(x, y)
+    for h in hooks:
+        h.remove()
+    lossv = m.loss(wav, y)
+    opt.zero_grad()
+    lossv.backward()
+    g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    opt.step()
+    sd = m.state_dict()
+    small = lambda k: (k.startswith("encoder.0.0.") or k.endswith(".2.weight") or ".1.weight" in k or ".1.bias" in k
+                       or k.startswith("decoder.5.0.") or k.startswith("tranform.bias") or k.endswith("bias_hh_l0"))
+    rec = dict(
+        meta=dict(B=B, L=L, kernel_num=np.array(kernel_num), rnn_units=rnn_units, rnn_input=rnn_input, mask=np.array(mask), loss=np.array(loss)),
+        est_mags=est_mags.detach().numpy(), target_mags=target_mags.detach().numpy(), out_wav=wav.detach().numpy(), loss=float(lossv),
+        taps=taps, grad_norm={k: float(v.double().norm()) for k, v in g.items()},
+        grad={k: v.numpy() for k, v in g.items() if small(k)},
+        grad_samp={k: sample(v, 53)["samp"] for k, v in g.items() if not small(k)},
+        after_adam={k: sd[k].numpy().copy() for k in g if small(k)},
+        running={k: v.numpy().copy() for k, v in sd.items() if "running_" in k})
+    np.savez_compressed(os.path.join(HERE, f"crn_{name}.npz"), **flat(rec, "g"))
+    print(f"crn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
+
+
 def frontend_and_losses(cfg, models, tfm, tfl):
     out = {}
     K, _ = tfm.init_kernels(400, 100, 512, "hann")
@@ -202,6 +241,8 @@ def main():
     dccrn_case(cfg, models, "small_E_sisnr_lms", small, 128, "E", "SI-SNR", "LMS", 2, 4000, store_taps=False)
     dccrn_case(cfg, models, "default_E_sisnr", dflt, 256, "E", "SI-SNR", False, 2, 4000)
     dccrn_case(cfg, models, "default_C_sisnr_full", dflt, 256, "C", "SI-SNR", False, 1, 48000, store_taps=False)
+    crn_case(cfg, models, "default_E_mse", dflt, 256, 512, "E", "MSE", 2, 4000)
+    crn_case(cfg, models, "small_E_sisnr", small, 128, 128, "E", "SI-SNR", 2, 4000)
 
 
 if __name__ == "__main__":
