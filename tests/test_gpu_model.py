@@ -111,7 +111,12 @@ def test_fused_train_step_matches_oracle_two_steps():
         state = r["adam_state"]
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         for k in r["new_stats"]:
-            assert rel_err(sd[k], P[k]) < TOL, (step, k)
+            if step > 1 and k.endswith("running_mean"):
+                # the conv bias in front of a BatchNorm random-walks by +-lr per step on the sign of a rounding-noise
+                # gradient (same in the reference); it shifts the batch mean by up to 2*lr, the running mean by 0.1 of that
+                assert float((sd[k] - P[k]).abs().max()) < 3e-4, (step, k)
+            else:
+                assert rel_err(sd[k], P[k]) < TOL, (step, k)
         # Adam's step is lr * m/(sqrt(v)+eps) ~ lr * sign(g) on the first steps: compare the parameters where the oracle
         # gradient is well above rounding noise (elsewhere the *sign* of a noise-level gradient decides a +-lr move)
         worst, covered, total = 0.0, 0, 0
