@@ -1,0 +1,215 @@
+// BatchNorm2d(train) + PReLU on channels-last rows [R][C] - the HBM-bound passes of the conv stack.
+// 16-byte accesses for both storage dtypes (4 fp32 / 8 bf16 per lane), per-channel parameters staged once per
+// workgroup in LDS, row -> (batch item, frame) decode kept incremental (no 64-bit divisions in the loops).
+// Statistics themselves come for free from the producing GEMM's epilogue (rungemm.hip) -> bn_finalize (kernels.hip).
+#include <hip/hip_runtime.h>
+#include "sefd_desc.h"
+#include "dev_common.h"
+
+namespace sefd {
+
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void load(const char* base, int64_t i, float* o) {
+    const float4 v = *reinterpret_cast<const float4*>(base + i * 4);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  static __device__ __forceinline__ void store(char* base, int64_t i, const float* o) {
+    *reinterpret_cast<float4*>(base + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct VecIO<bf16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void load(const char* base, int64_t i, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + i * 2);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[2 * k] = bf2f(w[k] & 0xffff); o[2 * k + 1] = bf2f(w[k] >> 16); }
+  }
+  static __device__ __forceinline__ void store(char* base, int64_t i, const float* o) {
+    uint4 v;
+    v.x = f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16); v.y = f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    v.z = f2bf(o[4]) | ((uint32_t)f2bf(o[5]) << 16); v.w = f2bf(o[6]) | ((uint32_t)f2bf(o[7]) << 16);
+    *reinterpret_cast<uint4*>(base + i * 2) = v;
+  }
+};
+
+constexpr int kMaxC = 1024;
+
+// LDS parameter block: mean | invstd | gamma | beta  (each C floats)
+__device__ __forceinline__ void stage_params(float* sp, int C, const float* mi, const float* gamma, const float* beta) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { sp[c] = mi[c]; sp[C + c] = mi[C + c]; sp[2 * C + c] = gamma[c]; sp[3 * C + c] = beta[c]; }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel_v(const BnApply d, const ArenaBases ab) {
+  constexpr int V = VecIO<T>::V;
+  __shared__ float sp[4 * kMaxC];
+  const int C = d.C;
+  stage_params(sp, C, reinterpret_cast<const float*>(rp(ab, d.mean_invstd)), reinterpret_cast<const float*>(rp(ab, d.gamma)),
+               reinterpret_cast<const float*>(rp(ab, d.beta)));
+  const char* y = rp(ab, d.y);
+  char* z = rp(ab, d.z);
+  const float a = *reinterpret_cast<const float*>(rp(ab, d.slope));
+  const int cmask = (C & (C - 1)) == 0 ? C - 1 : -1;
+  const int64_t nq = d.R * C / V;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = q * V;
+    const int c = cmask >= 0 ? (int)(i & cmask) : (int)(i % C);
+    float v[V];
+    VecIO<T>::load(y, i, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float bn = sp[2 * C + c + e] * ((v[e] - sp[c + e]) * sp[C + c + e]) + sp[3 * C + c + e];
+      v[e] = bn > 0.f ? bn : a * bn;
+    }
+    VecIO<T>::store(z, i, v);
+  }
+}
+
+// dz for y-row (b, ql) where ql = row inside the batch item; chunk of V channels at c
+template <typename T>
+__device__ __forceinline__ void load_dz_v(const BnBwdReduce& d, const char* dz0, const char* dz1, int64_t b, int ql, int c, float* g) {
+  constexpr int V = VecIO<T>::V;
+#pragma unroll
+  for (int e = 0; e < V; ++e) g[e] = 0.f;
+  if (ql >= d.skip) VecIO<T>::load(dz0, (b * (d.rpb - d.skip) + ql - d.skip) * d.C + c, g);
+  if (dz1) {
+    float h[V];
+    VecIO<T>::load(dz1, (b * d.rpb + ql) * d.C + c, h);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] += h[e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce d, const ArenaBases ab) {
+  constexpr int V = VecIO<T>::V;
+  __shared__ float sp[4 * kMaxC];
+  __shared__ float red[512 * V + 8];
+  const int C = d.C;
+  stage_params(sp, C, reinterpret_cast<const float*>(rp(ab, d.mean_invstd)), reinterpret_cast<const float*>(rp(ab, d.gamma)),
+               reinterpret_cast<const float*>(rp(ab, d.beta)));
+  const char* y = rp(ab, d.y);
+  const char* dz0 = rp(ab, d.dz0);
+  const char* dz1 = d.dz1.arena >= 0 ? rp(ab, d.dz1) : nullptr;
+  const float a = *reinterpret_cast<const float*>(rp(ab, d.slope));
+  const int CV = C / V;                         // chunk columns (<= 256 for C <= 1024 fp32 / 2048 bf16)
+  const int nrl = 256 / CV > 0 ? 256 / CV : 1;  // row lanes
+  const int rl = threadIdx.x / CV, cc = threadIdx.x - rl * CV;
+  float s0[V], s1[V], sa = 0.f;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  const int64_t row0 = (int64_t)blockIdx.x * d.rows_per_blk;
+  const int64_t row1 = min(d.R, row0 + d.rows_per_blk);
+  if (rl < nrl && cc < CV) {
+    const int c = cc * V;
+    int64_t r = row0 + rl;
+    int64_t b = r / d.rpb;
+    int ql = (int)(r - b * d.rpb);
+    for (; r < row1; r += nrl) {
+      float yv[V], gz[V];
+      VecIO<T>::load(y, r * C + c, yv);
+      load_dz_v<T>(d, dz0, dz1, b, ql, c, gz);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (yv[e] - sp[c + e]) * sp[C + c + e];
+        const float bn = sp[2 * C + c + e] * xh + sp[3 * C + c + e];
+        const float dbn = bn > 0.f ? gz[e] : a * gz[e];
+        sa += bn > 0.f ? 0.f : bn * gz[e];
+        s0[e] += dbn;
+        s1[e] += dbn * xh;
+      }
+      ql += nrl;
+      while (ql >= d.rpb) { ql -= (int)d.rpb; ++b; }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      red[(rl * C + c + e) * 2 + 0] = s0[e];
+      red[(rl * C + c + e) * 2 + 1] = s1[e];
+    }
+  }
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(rp(ab, d.part)) + (int64_t)blockIdx.x * 3 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < nrl; ++k) { t0 += red[(k * C + c) * 2 + 0]; t1 += red[(k * C + c) * 2 + 1]; }
+    part[c] = t0;
+    part[C + c] = t1;
+  }
+  __syncthreads();
+  sa = wave_sum(sa);
+  if ((threadIdx.x & 63) == 0) red[512 * V + (threadIdx.x >> 6)] = sa;
+  __syncthreads();
+  if (threadIdx.x == 0) part[2 * C] = red[512 * V] + red[512 * V + 1] + red[512 * V + 2] + red[512 * V + 3];
+}
+
+// grid: x over the chunks of one batch item, y = batch item
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel_v(const BnBwdApply d, const ArenaBases ab) {
+  constexpr int V = VecIO<T>::V;
+  __shared__ float sp[4 * kMaxC];
+  __shared__ float st[2 * kMaxC];
+  const BnBwdReduce& r = d.r;
+  const int C = r.C;
+  stage_params(sp, C, reinterpret_cast<const float*>(rp(ab, r.mean_invstd)), reinterpret_cast<const float*>(rp(ab, r.gamma)),
+               reinterpret_cast<const float*>(rp(ab, r.beta)));
+  const float* tot = reinterpret_cast<const float*>(rp(ab, d.totals));
+  const float inv_n = (float)(1.0 / d.count);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { st[c] = tot[c] * inv_n; st[C + c] = tot[C + c] * inv_n; }
+  __syncthreads();
+  const char* y = rp(ab, r.y);
+  const char* dz0 = rp(ab, r.dz0);
+  const char* dz1 = r.dz1.arena >= 0 ? rp(ab, r.dz1) : nullptr;
+  char* dy = rp(ab, d.dy);
+  const float a = *reinterpret_cast<const float*>(rp(ab, r.slope));
+  const int64_t b = blockIdx.y;
+  const int nq = (int)(r.rpb * C / V);
+  const int cmask = (C & (C - 1)) == 0 ? C - 1 : -1;
+  const int csh = cmask >= 0 ? __ffs(C) - 1 : 0;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    const int il = q * V;
+    const int ql = cmask >= 0 ? (il >> csh) : il / C;
+    const int c = il - ql * C;
+    float yv[V], gz[V], o[V];
+    const int64_t gi = b * r.rpb * C + il;
+    VecIO<T>::load(y, gi, yv);
+    load_dz_v<T>(r, dz0, dz1, b, ql, c, gz);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float xh = (yv[e] - sp[c + e]) * sp[C + c + e];
+      const float bn = sp[2 * C + c + e] * xh + sp[3 * C + c + e];
+      const float dbn = bn > 0.f ? gz[e] : a * gz[e];
+      o[e] = sp[2 * C + c + e] * sp[C + c + e] * (dbn - st[c + e] - xh * st[C + c + e]);
+    }
+    VecIO<T>::store(dy, gi, o);
+  }
+}
+
+static inline int gridcap(int64_t n, int cap = 16384) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st) {
+  if (op.kind == OP_BN_APPLY) {
+    const BnApply& d = op.bna;
+    if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_apply_kernel_v<bf16_t>), dim3(gridcap(d.R * d.C / 8)), dim3(256), 0, st, d, ab);
+    else hipLaunchKernelGGL((bn_apply_kernel_v<float>), dim3(gridcap(d.R * d.C / 4)), dim3(256), 0, st, d, ab);
+  } else if (op.kind == OP_BN_BWD_REDUCE) {
+    const BnBwdReduce& d = op.bnr;
+    if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel_v<bf16_t>), dim3(d.nblk), dim3(256), 0, st, d, ab);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel_v<float>), dim3(d.nblk), dim3(256), 0, st, d, ab);
+  } else if (op.kind == OP_BN_BWD_APPLY) {
+    const BnBwdApply& d = op.bnb;
+    const int nb = (int)(d.r.R / d.r.rpb);
+    const int v = d.r.dt == DT_BF16 ? 8 : 4;
+    int gx = gridcap(d.r.rpb * d.r.C / v, 16384 / (nb > 0 ? nb : 1) + 1);
+    if (d.r.dt == DT_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel_v<bf16_t>), dim3(gx, nb), dim3(256), 0, st, d, ab);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel_v<float>), dim3(gx, nb), dim3(256), 0, st, d, ab);
+  }
+}
+
+}  // namespace sefd

@@ -57,11 +57,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the recurrence is
+// latency-bound per time step, libm-accurate expf/tanhf would triple the step time for ~1e-7 of accuracy.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
+void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);
 
 }  // namespace sefd

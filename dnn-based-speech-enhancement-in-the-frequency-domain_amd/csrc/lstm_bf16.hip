@@ -83,9 +83,9 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     uint16_t* hn = hbuf[(t + 1) & 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf_(acc[2][r]), og = sigmoidf_(acc[3][r]);
       c[r] = fg * c[r] + ig * gg;
-      const uint16_t hb = f2bf(og * tanhf(c[r]));
+      const uint16_t hb = f2bf(og * tanhf_(c[r]));
       hn[(4 * kq + r) * hs + unit] = hb;
       if (rvalid[r]) {
         const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
@@ -140,18 +140,33 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
   const int64_t GBT = (int64_t)d.B * T;
   float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
+  // software prefetch: the saved activations of step t-1 are fetched while step t computes (all addresses are known)
+  float pg[4][4], pct[4], pcp[4], pdh[4];       // gates i,f,g,o ; c_t ; c_{t-1} ; upstream dh   for the current step
+  float ng[4][4], ncp[4], ndh[4];               // the same for the next (t-1) step
+  auto fetch = [&](int t, float (&g4)[4][4], float (&cp)[4], float (&dhv)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g4[r][q] = rvalid[r] ? gates[row * 4 * H + q * H + unit] : 0.f;
+      cp[r] = (rvalid[r] && t > 0) ? cs[(row - 1) * H + unit] : 0.f;
+      dhv[r] = rvalid[r] ? dh[row * H + unit] : 0.f;
+    }
+  };
+  fetch(T - 1, pg, pcp, pdh);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pct[r] = rvalid[r] ? cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit] : 0.f;
   for (int t = T - 1; t >= 0; --t) {
+    if (t > 0) fetch(t - 1, ng, ncp, ndh);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float di = 0.f, df = 0.f, dg = 0.f, dog = 0.f;
       if (rvalid[r]) {
-        const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
-        const float ig = gates[row * 4 * H + unit], fg = gates[row * 4 * H + H + unit];
-        const float gg = gates[row * 4 * H + 2 * H + unit], og = gates[row * 4 * H + 3 * H + unit];
-        const float ct = cs[row * H + unit];
-        const float cp = t > 0 ? cs[(row - 1) * H + unit] : 0.f;
-        const float dht = dh[row * H + unit] + dhrec[r];
-        const float tc = tanhf(ct);
+        const float ig = pg[r][0], fg = pg[r][1], gg = pg[r][2], og = pg[r][3];
+        const float ct = pct[r];
+        const float cp = pcp[r];
+        const float dht = pdh[r] + dhrec[r];
+        const float tc = tanhf_(ct);
         dog = dht * tc * og * (1.f - og);
         const float dc = dht * og * (1.f - tc * tc) + dcarry[r];
         di = dc * gg * ig * (1.f - ig);
@@ -181,6 +196,12 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
       }
     }
     dhrec = a0 + a1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pct[r] = pcp[r]; pcp[r] = ncp[r]; pdh[r] = ndh[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pg[r][q] = ng[r][q];
+    }
     __syncthreads();
   }
 }

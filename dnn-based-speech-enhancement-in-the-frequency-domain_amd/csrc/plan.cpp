@@ -850,7 +850,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
       const std::string nm = "enc" + std::to_string(i);
       const std::string pp = "encoder." + std::to_string(i);
-      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, enc[i].R, 0, d_ency[i], nm);
+      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm);
       b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
       if (i == 0) continue;
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]

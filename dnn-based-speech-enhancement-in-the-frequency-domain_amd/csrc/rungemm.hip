@@ -141,41 +141,101 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
 
   const int wm0 = (wid / WN_) * (MI * 32), wn0 = (wid % WN_) * (NI * 32);
 
-  // ---- K-tile iteration state
+  // ---- K-tile iteration state.  Everything that depends only on (row, run) - run start pointer, valid j-range,
+  // alignment - is hoisted to run entry; a K-tile then costs two compares and one 16-byte load per chunk.
   int seg = 0, k0 = 0;
   int ntiles = 0;
   for (int s = 0; s < d.nseg; ++s) ntiles += (d.seg[s].len + BK - 1) / BK;
 
-  uint4 aReg[4], bReg[BPASS];
-  auto issue_loads = [&](int sgi, int kk) {
+  const TA* rptr[4];
+  int jlo[4], jhi[4];
+  int seglen = 0, wseg = 0;
+  auto enter_run = [&](int sgi) {
     const Seg sg = d.seg[sgi];
+    seglen = sg.len;
+    wseg = sg.koff;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) aReg[p] = load_a_chunk<TA>(d, x0, x1, sg, rb0[p], rb1[p], ru[p], rfo[p], rv[p], kk + c * VEC);
-#pragma unroll
-    for (int p = 0; p < BPASS; ++p) bReg[p] = *reinterpret_cast<const uint4*>(wrow[p] + sg.koff + kk);
+    for (int p = 0; p < 4; ++p) {
+      int lo = 0, hi = 0;
+      const TA* ptr = x0;
+      if (sg.src >= 0 && rv[p]) {
+        const int s = sg.src;
+        const int tt = ru[p] + sg.dt;
+        if (tt >= 0 && tt < d.Tin[s]) {
+          const int rr = sg.off + rfo[p] * d.fstride[s];
+          lo = rr < 0 ? -rr : 0;
+          hi = min(sg.len, d.rowlen[s] - rr);
+          ptr = (s ? x1 : x0) + (s ? rb1[p] : rb0[p]) + (int64_t)tt * d.tstride[s] + rr;
+          if ((reinterpret_cast<uintptr_t>(ptr) & 15) != 0) { lo |= 0x40000000; }   // unaligned run: element-wise path
+        }
+      }
+      rptr[p] = ptr; jlo[p] = lo; jhi[p] = hi;
+    }
   };
-  issue_loads(0, 0);
+  uint4 aReg[4], bReg[BPASS];
+  auto issue_loads = [&](int kk) {
+    const int j0 = kk + c * VEC;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (j0 >= jlo[p] && j0 + VEC <= jhi[p]) {
+        v = *reinterpret_cast<const uint4*>(rptr[p] + j0);
+      } else {
+        const int lo = jlo[p] & 0x3fffffff;
+        if (j0 + VEC > lo && j0 < jhi[p]) {              // partially valid or unaligned chunk (never on the DCCRN shapes)
+          const int e0 = lo > j0 ? lo - j0 : 0, e1 = jhi[p] - j0 < VEC ? jhi[p] - j0 : VEC;
+          if constexpr (sizeof(TA) == 4) {
+            uint32_t t[4] = {0, 0, 0, 0};
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(rptr[p] + j0);
+            for (int e = e0; e < e1; ++e) t[e] = q[e];
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+          } else {
+            uint16_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(rptr[p] + j0);
+            for (int e = e0; e < e1; ++e) t[e] = q[e];
+            v = make_uint4(t[0] | (uint32_t)t[1] << 16, t[2] | (uint32_t)t[3] << 16, t[4] | (uint32_t)t[5] << 16, t[6] | (uint32_t)t[7] << 16);
+          }
+        }
+      }
+      aReg[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) bReg[p] = *reinterpret_cast<const uint4*>(wrow[p] + wseg + kk);
+  };
+  enter_run(0);
+  issue_loads(0);
+
+  // LDS offsets: the swizzle term ((row >> 1) & 7) is the same for all of a thread's rows (row strides are multiples of 16)
+  int woff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) woff[p] = swz_off(r0 + 32 * p, c);
+  const int rsw = ((lane & 31) >> 1) & 7;
+  int chs[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) chs[kc] = ((2 * kc + (lane >> 5)) ^ rsw) * 16;
+  const int arow = (wm0 + (lane & 31)) * 128, brow = (wn0 + (lane & 31)) * 128;
 
   for (int kt = 0; kt < ntiles; ++kt) {
     char* As = smem + (kt & 1) * TILE_BYTES;
     char* Bs = As + BM * 128;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(As + swz_off(r0 + 32 * p, c)) = aReg[p];
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(As + woff[p]) = aReg[p];
 #pragma unroll
-    for (int p = 0; p < BPASS; ++p) *reinterpret_cast<uint4*>(Bs + swz_off(r0 + 32 * p, c)) = bReg[p];
+    for (int p = 0; p < BPASS; ++p) *reinterpret_cast<uint4*>(Bs + woff[p]) = bReg[p];
     __syncthreads();
-    // advance (seg, k0) and prefetch the next tile into registers while this one is consumed from LDS
+    // advance (run, k0) and prefetch the next tile into registers while this one is consumed from LDS
     k0 += BK;
-    if (k0 >= d.seg[seg].len) { k0 = 0; ++seg; }
-    if (kt + 1 < ntiles) issue_loads(seg, k0);
+    if (kt + 1 < ntiles) {
+      if (k0 >= seglen) { k0 = 0; ++seg; enter_run(seg); }
+      issue_loads(k0);
+    }
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-      const int ch = 2 * kc + (lane >> 5);
       uint4 af[MI], bf[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(As + swz_off(wm0 + i * 32 + (lane & 31), ch));
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(As + arow + i * 4096 + chs[kc]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + swz_off(wn0 + j * 32 + (lane & 31), ch));
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + brow + j * 4096 + chs[kc]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -414,25 +474,59 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const RunGemm d, const 
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wn = (wid >> 1) * (TN / 2), wk = (wid & 1) * 64;
 
+  // Row decode is incremental: a thread's rows advance by RS per step, so (b, q = position inside the batch item) is
+  // carried along and only the split u = q / Fo remains (a shift when Fo is a power of two, as in every conv layer).
+  const int fsh = (d.Fo & (d.Fo - 1)) == 0 ? __ffs(d.Fo) - 1 : -1;
+  struct RowPos { int b, q; };
+  auto init_pos = [&](int m) { RowPos r; r.b = m / TF; r.q = m - r.b * TF; return r; };
+  auto advance = [&](RowPos& r) { r.q += RS; while (r.q >= TF) { r.q -= TF; ++r.b; } };
+  RowPos apos[2], dpos[DPASS];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) apos[p] = init_pos(step0 * RS + ra + 16 * p);
+#pragma unroll
+  for (int p = 0; p < DPASS; ++p) dpos[p] = init_pos(step0 * RS + rd + (256 / DCH) * p);
+  const bool a_full = sgi >= 0 && sg.src >= 0 && j0 + 8 <= sg.len;          // chunk entirely inside the run
+  const bool a_ones = sgi >= 0 && sg.src < 0 && j0 == 0;
+  const int asrc = sg.src > 0 ? 1 : 0;
+  const bf16_t* xs = asrc ? x1 : x0;
+  const bool d_full = ncol + 8 <= d.N;
+
   uint4 aReg[2], dReg[DPASS];
   auto issue = [&](int step) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int m = step * RS + ra + 16 * p;
-      const bool v = m < d.M;
-      const int mm = v ? m : 0;
-      const int b = mm / TF, rem = mm - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
-      aReg[p] = load_a_chunk<bf16_t>(d, x0, x1, sg, (int64_t)b * d.bstride[0] + d.base[0], (int64_t)b * d.bstride[1] + d.base[1],
-                                     u, fo, v && sgi >= 0, j0);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < d.M) {
+        const int u = fsh >= 0 ? (apos[p].q >> fsh) : (apos[p].q / d.Fo);
+        const int fo = apos[p].q - u * d.Fo;
+        if (a_full) {
+          const int tt = u + sg.dt;
+          const int rr = sg.off + fo * d.fstride[asrc] + j0;
+          if (tt >= 0 && tt < d.Tin[asrc]) {
+            const bf16_t* src = xs + (int64_t)apos[p].b * d.bstride[asrc] + d.base[asrc] + (int64_t)tt * d.tstride[asrc] + rr;
+            if (rr >= 0 && rr + 8 <= d.rowlen[asrc] && (reinterpret_cast<uintptr_t>(src) & 15) == 0) v = *reinterpret_cast<const uint4*>(src);
+            else if (rr + 8 > 0 && rr < d.rowlen[asrc])
+              v = load_a_chunk<bf16_t>(d, x0, x1, sg, (int64_t)apos[p].b * d.bstride[0] + d.base[0], (int64_t)apos[p].b * d.bstride[1] + d.base[1], u, fo, true, j0);
+          }
+        } else if (a_ones) {
+          v.x = 0x3f80u;
+        } else if (sgi >= 0 && sg.src >= 0) {
+          v = load_a_chunk<bf16_t>(d, x0, x1, sg, (int64_t)apos[p].b * d.bstride[0] + d.base[0], (int64_t)apos[p].b * d.bstride[1] + d.base[1], u, fo, true, j0);
+        }
+      }
+      aReg[p] = v;
+      advance(apos[p]);
     }
 #pragma unroll
     for (int p = 0; p < DPASS; ++p) {
       const int m = step * RS + rd + (256 / DCH) * p;
       uint4 z = make_uint4(0, 0, 0, 0);
       if (m < d.M) {
-        const int b = m / TF, rem = m - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
-        const uint16_t* src = dy + (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off + ncol;
-        if (ncol + 8 <= d.N) z = *reinterpret_cast<const uint4*>(src);
+        const int u = fsh >= 0 ? (dpos[p].q >> fsh) : (dpos[p].q / d.Fo);
+        const int fo = dpos[p].q - u * d.Fo;
+        const uint16_t* src = dy + (int64_t)dpos[p].b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off + ncol;
+        if (d_full && (reinterpret_cast<uintptr_t>(src) & 15) == 0) z = *reinterpret_cast<const uint4*>(src);
         else {
           uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           for (int e = 0; e < 8; ++e) if (ncol + e < d.N) v[e] = src[e];
@@ -440,6 +534,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const RunGemm d, const 
         }
       }
       dReg[p] = z;
+      advance(dpos[p]);
     }
   };
   if (step0 < step1) issue(step0);
