@@ -18,7 +18,7 @@ sefd_plan* sefd_plan_create(const sefd_model_config* cfg) {
   ModelConfig mc;
   std::memcpy(&mc, cfg, sizeof(mc));
   sefd_plan* h = new sefd_plan();
-  h->p = build_dccrn_plan(mc);
+  h->p = build_plan(mc);
   for (auto& kv : h->p->bufs) h->names.push_back(kv.first);
   return h;
 }

@@ -491,13 +491,19 @@ __global__ void mask_fwd_kernel(const Mask d, const ArenaBases ab) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f = i / NS;
     const int slot = (int)(i - f * NS);
-    float er = 0.f, ei = 0.f;
+    float er = 0.f, ei = 0.f, emag = 0.f;
     if (slot >= 2) {                           // bins >= 1 ; bin 0 (slot 1) has a zero mask (models.py:255-256) -> est = 0
       const int64_t b = f / d.T, t = f - b * d.T;
-      const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * 2;
-      const float mr = ld_elem(mask, d.mdt, mo), mi = ld_elem(mask, d.mdt, mo + 1);
+      const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * d.mch;
+      const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch == 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
       const float sr = spec[i * 2], si = spec[i * 2 + 1];
-      if (d.mode == 0) {
+      if (d.mode == 3) {                         // CRN (models.py:519-526): est_mags = tanh(out) * mags, noisy phase re-attached
+        const float em = tanhf(mr) * sqrtf(sr * sr + si * si);
+        float sn, cs;
+        sincosf(atan2f(si, sr), &sn, &cs);
+        er = em * cs; ei = em * sn;
+        emag = em;
+      } else if (d.mode == 0) {
         const float mag = sqrtf(sr * sr + si * si + 1e-8f);
         const float ph = atan2f(si, sr);
         const float mm = sqrtf(mr * mr + mi * mi);
@@ -514,6 +520,7 @@ __global__ void mask_fwd_kernel(const Mask d, const ArenaBases ab) {
     }
     est[i * 2] = er;
     est[i * 2 + 1] = ei;
+    if (d.mode == 3 && slot >= 1) reinterpret_cast<float*>(rp(ab, d.estm))[f * d.NF + slot - 1] = emag;
   }
 }
 
@@ -533,15 +540,20 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
     const int64_t bu = i / NB;
     const int64_t b = bu / TT;
     const int u = (int)(bu - b * TT);
-    const int64_t mo = b * d.mask_bstride + (int64_t)u * d.mask_fstride + k * 2;   // includes the leading frame
+    const int64_t mo = b * d.mask_bstride + (int64_t)u * d.mask_fstride + k * d.mch;   // includes the leading frame
     float gr = 0.f, gi = 0.f;
     if (u >= lead) {
       const int64_t f = b * d.T + (u - lead);
       const int64_t si_ = (f * NS + k + 2) * 2;
       const float sr = spec[si_], si = spec[si_ + 1];
       const float der = dest[si_], dei = dest[si_ + 1];
-      const float mr = ld_elem(mask, d.mdt, mo), mi = ld_elem(mask, d.mdt, mo + 1);
-      if (d.mode == 0) {
+      const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch == 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
+      if (d.mode == 3) {
+        const float tm = tanhf(mr);
+        float sn, cs;
+        sincosf(atan2f(si, sr), &sn, &cs);
+        gr = (der * cs + dei * sn) * sqrtf(sr * sr + si * si) * (1.f - tm * tm);
+      } else if (d.mode == 0) {
         const float mag = sqrtf(sr * sr + si * si + 1e-8f);
         const float ph = atan2f(si, sr);
         const float mm = sqrtf(mr * mr + mi * mi);
@@ -568,7 +580,24 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
       }
     }
     st_elem(dmask, d.mdt, mo, gr);
-    st_elem(dmask, d.mdt, mo + 1, gi);
+    if (d.mch == 2) st_elem(dmask, d.mdt, mo + 1, gi);
+  }
+}
+
+__global__ void mags_kernel(const Mags d, const ArenaBases ab) {
+  const float* spec = reinterpret_cast<const float*>(rp(ab, d.spec));
+  char* mags = rp(ab, d.mags);
+  const int NS = d.NF + 1;
+  const int64_t n = d.frames * d.MS;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = i / d.MS;
+    const int k = (int)(i - f * d.MS) - d.MO;
+    float v = 0.f;
+    if (k >= 0 && k < d.NF) {
+      const float sr = spec[(f * NS + k + 1) * 2], si = spec[(f * NS + k + 1) * 2 + 1];
+      v = sqrtf(sr * sr + si * si);
+    }
+    st_elem(mags, d.dt, i, v);
   }
 }
 
@@ -616,7 +645,7 @@ __global__ __launch_bounds__(256) void specout_fwd_kernel(const SpecOut d, const
   __shared__ float tr[32][33], ti[32][33];
   const float* est = reinterpret_cast<const float*>(rp(ab, d.est));
   float* outr = reinterpret_cast<float*>(rp(ab, d.out_real));
-  float* outi = reinterpret_cast<float*>(rp(ab, d.out_imag));
+  float* outi = d.mode == 0 ? reinterpret_cast<float*>(rp(ab, d.out_imag)) : nullptr;
   const int NS = d.NF + 1;
   const int b = blockIdx.z, t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -624,8 +653,13 @@ __global__ __launch_bounds__(256) void specout_fwd_kernel(const SpecOut d, const
     const int t = t0 + r, k = k0 + tx;
     float vr = 0.f, vi = 0.f;
     if (t < d.T && k < d.NF) {
-      const int64_t o = (((int64_t)b * d.T + t) * NS + k + 1) * 2;
-      vr = est[o]; vi = est[o + 1];
+      if (d.mode == 2) {
+        vr = est[((int64_t)b * d.T + t) * d.NF + k];
+      } else {
+        const int64_t o = (((int64_t)b * d.T + t) * NS + k + 1) * 2;
+        vr = est[o]; vi = est[o + 1];
+        if (d.mode == 1) vr = sqrtf(vr * vr + vi * vi);
+      }
     }
     tr[r][tx] = vr; ti[r][tx] = vi;
   }
@@ -634,7 +668,8 @@ __global__ __launch_bounds__(256) void specout_fwd_kernel(const SpecOut d, const
     const int k = k0 + r, t = t0 + tx;
     if (t < d.T && k < d.NF) {
       const int64_t o = ((int64_t)b * d.NF + k) * d.T + t;
-      outr[o] = tr[tx][r]; outi[o] = ti[tx][r];
+      outr[o] = tr[tx][r];
+      if (d.mode == 0) outi[o] = ti[tx][r];
     }
   }
 }
@@ -724,6 +759,8 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
       else hipLaunchKernelGGL(specout_bwd_kernel, grid, dim3(256), 0, st, op.so, ab);
       break;
     }
+    case OP_MAGS:
+      hipLaunchKernelGGL(mags_kernel, dim3(grid_for(op.mags.frames * op.mags.MS)), dim3(256), 0, st, op.mags, ab); break;
     case OP_MEMSET:
       (void)hipMemsetAsync(rp(ab, op.ms.dst), 0, op.ms.bytes, st); break;
     default: break;

@@ -625,7 +625,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   {
     const int Fo = Fe[0], Co = 2;
     mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.dest = mk.dmask = b.none();
-    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt;
+    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt; mk.mch = 2; mk.estm = b.none();
     mk.mask_fstride = (int64_t)Fo * Co; mk.mask_bstride = (int64_t)(T + 1) * Fo * Co; mk.mask_base = (int64_t)Fo * Co; mk.T = T;
     b.push(F, OP_MASK_FWD, 500).mask = mk;
   }
@@ -887,5 +887,538 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   P->arena_bytes[A_IO] = b.io_off;
   return P;
 }
+
+// =================================================================================================================
+// CRN (reference models.py:329-565): the real twin of DCCRN on magnitudes.  Same kernels, different planner:
+// real convs with half the channels (C_in = 1 magnitudes), plain [prev, skip] concat, ONE-layer nn.LSTM + `tranform`
+// Linear, mask = tanh(out) * |spec| re-attached to the noisy phase.  I/O: wav, tgt -> out_wav, out_real (= est_mags),
+// out_imag (= target_mags).  Gradients flow from out_wav only (est_mags / target_mags feed nothing the reference can
+// reach: CRN + perceptual crashes in the reference).
+Plan* build_crn_plan(const ModelConfig& cfg) {
+  Plan* P = new Plan();
+  P->cfg = cfg;
+  Builder b;
+  b.P = P;
+  b.c = cfg;
+  const int n = cfg.n_layers;
+  const int B = cfg.B, L = cfg.L, W = cfg.win_len, hop = cfg.hop, NFFT = cfg.fft_len;
+  const int trim = W - hop;
+  const int T = (L + 2 * trim - W) / hop + 1;
+  const int NF = NFFT / 2 + 1, NS = NF + 1, SW = NS * 2;
+  const int Lp = (T - 1) * hop + W;
+  const int adt = cfg.act_dtype;
+  const int KS = cfg.kernel_size;
+  const int MS = NF + 7, MO = 7;            // magnitude rows: bin k at element k + 7 -> bin 1 is 16-byte aligned in fp32 and bf16
+  P->T = T;
+  P->NF = NF;
+  if (KS != 5 || n < 1 || n > 7 || cfg.mask_mode != 0) { P->error = "CRN: unsupported configuration (only masking mode 'E')"; return P; }
+  std::vector<int> ch(n + 1), Fe(n + 1);
+  ch[0] = 1;
+  for (int i = 0; i < n; ++i) ch[i + 1] = cfg.kernel_num[i] / 2;
+  Fe[0] = NF - 1;
+  for (int i = 0; i < n; ++i) Fe[i + 1] = Fe[i] / 2;
+  const int D = Fe[n], Cl = ch[n];
+  const int H = cfg.rnn_units / 2;
+  const int hid = D * Cl;                    // must equal cfg.rnn_input_size
+  for (int i = 1; i <= n; ++i)
+    if (ch[i] % 8 != 0) { P->error = "channel counts must be multiples of 8"; return P; }
+  if (H % 16 != 0 || H > 128 || (adt == DT_BF16 && H % 32 != 0)) { P->error = "rnn_units/2 must be a multiple of 16 (32 for bf16) and <= 128"; return P; }
+  if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
+
+  for (int i = 0; i < n; ++i) {
+    const std::string p = "encoder." + std::to_string(i);
+    b.add_param(p + ".0.conv.weight", {ch[i + 1], ch[i], KS, 2}, true);
+    b.add_param(p + ".0.conv.bias", {ch[i + 1]}, true);
+    b.add_param(p + ".1.weight", {ch[i + 1]}, true);
+    b.add_param(p + ".1.bias", {ch[i + 1]}, true);
+    b.add_param(p + ".1.running_mean", {ch[i + 1]}, false);
+    b.add_param(p + ".1.running_var", {ch[i + 1]}, false);
+    b.add_param(p + ".2.weight", {1}, true);
+  }
+  for (int d = 0; d < n; ++d) {
+    const int idx = n - d;
+    const int cin = ch[idx] * (cfg.skip ? 2 : 1), cout = ch[idx - 1];
+    const std::string p = "decoder." + std::to_string(d);
+    b.add_param(p + ".0.conv.weight", {cin, cout, KS, 2}, true);
+    b.add_param(p + ".0.conv.bias", {cout}, true);
+    if (idx != 1) {
+      b.add_param(p + ".1.weight", {cout}, true);
+      b.add_param(p + ".1.bias", {cout}, true);
+      b.add_param(p + ".1.running_mean", {cout}, false);
+      b.add_param(p + ".1.running_var", {cout}, false);
+      b.add_param(p + ".2.weight", {1}, true);
+    }
+  }
+  b.add_param("enhance.weight_ih_l0", {4 * H, hid}, true);
+  b.add_param("enhance.weight_hh_l0", {4 * H, H}, true);
+  b.add_param("enhance.bias_ih_l0", {4 * H}, true);
+  b.add_param("enhance.bias_hh_l0", {4 * H}, true);
+  b.add_param("tranform.weight", {hid, H}, true);
+  b.add_param("tranform.bias", {hid}, true);
+  const int64_t nparam = P->params.back().off + P->params.back().numel;
+  const int64_t nstate = P->state.empty() ? 0 : P->state.back().off + P->state.back().numel;
+  b.inv.resize(nparam);
+
+  Ptr io_wav = b.io("wav", (int64_t)B * L);
+  Ptr io_out = b.io("out_wav", (int64_t)B * L);
+  Ptr io_or = b.io("out_real", (int64_t)B * NF * T);      // est_mags
+  Ptr io_oi = b.io("out_imag", (int64_t)B * NF * T);      // target_mags
+  Ptr io_gw = b.io("grad_wav", (int64_t)B * L);
+  b.io("grad_real", (int64_t)B * NF * T);
+  b.io("grad_imag", (int64_t)B * NF * T);
+  Ptr io_tgt = b.io("tgt", (int64_t)B * L);
+
+  std::vector<double> win(W);
+  for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  auto Kun = [&](int part, int k, int j) {
+    const double ang = 2.0 * kPi * (double)(((int64_t)k * j) % NFFT) / NFFT;
+    return part == 0 ? std::cos(ang) : -std::sin(ang);
+  };
+  std::vector<double> Kinv((size_t)2 * NF * W);
+  {
+    const double ne = (W + 1) / 2, no = W / 2;
+    for (int part = 0; part < 2; ++part)
+      for (int k = 0; k < NF; ++k) {
+        double se = 0, so = 0;
+        for (int m = 0; m < W; ++m) (m % 2 == 0 ? se : so) += Kun(part, k, m);
+        for (int j = 0; j < W; ++j) {
+          const double corr = (j % 2 == 0) ? se / (NFFT / 2.0 + ne) : so / (NFFT / 2.0 + no);
+          Kinv[((size_t)part * NF + k) * W + j] = (Kun(part, k, j) - corr) / (NFFT / 2.0) * win[j];
+        }
+      }
+  }
+  std::vector<float> coff(Lp, 0.f);
+  {
+    std::vector<float> w2(W);
+    for (int j = 0; j < W; ++j) { const float wf = (float)win[j]; w2[j] = wf * wf; }
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < W; ++j) coff[t * hop + j] += w2[j];
+  }
+  Ptr c_coff = b.cst(coff.data(), (int64_t)coff.size() * 4);
+  auto const_weights = [&](RunGemm& g, const std::function<double(int n, int j)>& val) {
+    std::vector<float> wt((size_t)g.Npad * g.ldw, 0.f);
+    for (int nn = 0; nn < g.N; ++nn)
+      for (int j = 0; j < g.seg[0].len; ++j) wt[(size_t)nn * g.ldw + j] = (float)val(nn, j);
+    g.w = b.cst(wt.data(), (int64_t)wt.size() * 4);
+  };
+  std::vector<Op>& F = P->fwd;
+  std::vector<Op>& R = P->bwd;
+  const int64_t BT = (int64_t)B * T;
+
+  // ---- STFT of the noisy input and of the target (CRN.forward always does both, models.py:468, 505)
+  Ptr spec = b.ws("spec", BT * SW, DT_F32);
+  Ptr spec_t = b.ws("spec_t", BT * SW, DT_F32);
+  {
+    RunGemm g = Builder::gemm0();
+    g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
+    g.bstride[0] = L; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
+    g.M = (int)BT; g.Tout = 1; g.Fo = T;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, -trim, W, 0};
+    g.N = SW;
+    Builder::layout_segs(g);
+    const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kun(nn & 1, nn / 2 - 1, j) * win[j]; });
+    g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+    b.push(F, OP_RUNGEMM, 1).g = g;
+    g.x[0] = io_tgt; g.y = spec_t;
+    b.push(F, OP_RUNGEMM, 2).g = g;
+  }
+  Ptr mags = b.ws("mags", BT * MS, adt);
+  {
+    Op& op = b.push(F, OP_MAGS, 3);
+    op.mags.spec = spec; op.mags.mags = mags; op.mags.frames = BT; op.mags.NF = NF; op.mags.MS = MS; op.mags.MO = MO; op.mags.dt = adt;
+  }
+
+  // ---- encoder (RealConv2d, tools_for_model.py:341-386)
+  struct Layer { RunGemm f[2]; Builder::Coef coef[2]; std::function<void(int, int32_t*)> bias; int C, Fq; int64_t R; };
+  std::vector<Layer> enc(n), dec(n);
+  std::vector<Ptr> encz(n), ency(n), enc_mi(n);
+  Ptr prev = mags;
+  for (int i = 0; i < n; ++i) {
+    const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
+    const std::string nm = "enc" + std::to_string(i);
+    const std::string pp = "encoder." + std::to_string(i);
+    const ParamInfo &Wc = b.par(pp + ".0.conv.weight"), &bc = b.par(pp + ".0.conv.bias");
+    RunGemm g = Builder::gemm0();
+    g.x[0] = prev; g.xdt = adt; g.ydt = adt;
+    if (i == 0) { g.bstride[0] = (int64_t)T * MS; g.tstride[0] = MS; g.base[0] = MO + 1; }
+    else { g.bstride[0] = (int64_t)T * Fi * Ci; g.tstride[0] = Fi * Ci; g.base[0] = 0; }
+    g.rowlen[0] = Fi * Ci; g.fstride[0] = 2 * Ci; g.Tin[0] = T;
+    g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;
+    g.nseg = 2;
+    g.seg[0] = Seg{0, -1, -2 * Ci, KS * Ci, 0};
+    g.seg[1] = Seg{0, 0, -2 * Ci, KS * Ci, 0};
+    g.N = Co;
+    Builder::layout_segs(g);
+    Builder::Coef coef = [=](int nn, int s, int j) -> int32_t {
+      const int kw = s, kh = j / Ci, ci = j % Ci;
+      return pe(Wc, (((int64_t)nn * Ci + ci) * KS + kh) * 2 + kw, 1);
+    };
+    std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) { o[0] = pe(bc, nn, 1); o[1] = 0; };
+    b.pack_weights(F, g, coef, nm, 100 + i, &bias);
+    const int64_t Rr = (int64_t)B * T * Fo;
+    ency[i] = b.ws(nm + ".y", Rr * Co, adt);
+    encz[i] = b.ws(nm + ".z", Rr * Co, adt);
+    enc_mi[i] = b.ws(nm + ".mi", 2 * Co, DT_F32);
+    const int nblk = (int)((g.M + kBM - 1) / kBM);
+    Ptr part = b.ws(nm + ".stat", (int64_t)nblk * 2 * g.Npad, DT_F32);
+    g.y = ency[i]; g.y_bstride = (int64_t)T * Fo * Co; g.y_tstride = Fo * Co; g.y_fstride = Co; g.y_off = 0;
+    g.stats = cfg.training ? part : b.none();
+    b.push(F, OP_RUNGEMM, 100 + i).g = g;
+    {
+      Op& op = b.push(F, OP_BN_FINALIZE, 100 + i);
+      op.bnf.part = part; op.bnf.mean_invstd = enc_mi[i];
+      op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
+      op.bnf.nblk = cfg.training ? nblk : -1; op.bnf.C = Co; op.bnf.Cpad = g.Npad; op.bnf.count = (double)Rr;
+      op.bnf.eps = 1e-5f; op.bnf.momentum = 0.1f;
+      Op& oa = b.push(F, OP_BN_APPLY, 100 + i);
+      oa.bna.y = ency[i]; oa.bna.z = encz[i]; oa.bna.mean_invstd = enc_mi[i];
+      oa.bna.gamma = b.pptr(pp + ".1.weight"); oa.bna.beta = b.pptr(pp + ".1.bias"); oa.bna.slope = b.pptr(pp + ".2.weight");
+      oa.bna.R = Rr; oa.bna.C = Co; oa.bna.dt = adt;
+    }
+    enc[i].f[0] = g; enc[i].coef[0] = coef; enc[i].bias = bias; enc[i].C = Co; enc[i].Fq = Fo; enc[i].R = Rr;
+    prev = encz[i];
+  }
+
+  // ---- single-layer LSTM + Linear (models.py:391-398, 483-486); feature order c*D + d
+  const ParamInfo &Wih = b.par("enhance.weight_ih_l0"), &Whh = b.par("enhance.weight_hh_l0");
+  const ParamInfo &bih = b.par("enhance.bias_ih_l0"), &bhh = b.par("enhance.bias_hh_l0");
+  Ptr gxb = b.ws("lstm.gx", BT * 4 * H, DT_F32);
+  Ptr hbuf = b.ws("lstm.h", BT * H, adt);
+  Ptr gatesb = b.ws("lstm.gates", BT * 4 * H, DT_F32);
+  Ptr cbuf = b.ws("lstm.c", BT * H, DT_F32);
+  RunGemm ggx = Builder::gemm0();
+  Builder::Coef cgx;
+  std::function<void(int, int32_t*)> bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, nn, 1); o[1] = pe(bhh, nn, 1); };
+  {
+    RunGemm& g = ggx;
+    g.x[0] = encz[n - 1]; g.xdt = adt; g.ydt = DT_F32;
+    g.bstride[0] = (int64_t)T * D * Cl; g.tstride[0] = D * Cl; g.rowlen[0] = D * Cl; g.Tin[0] = T;
+    g.M = (int)BT; g.Tout = T; g.Fo = 1;
+    g.nseg = D;
+    for (int dd = 0; dd < D; ++dd) g.seg[dd] = Seg{0, 0, dd * Cl, Cl, 0};
+    g.N = 4 * H;
+    Builder::layout_segs(g);
+    cgx = [=](int nn, int s, int j) -> int32_t { return pe(Wih, (int64_t)nn * hid + (j * D + s), 1); };
+    b.pack_weights(F, g, cgx, "lstm.ih", 200, &bgx);
+    g.y = gxb; g.y_bstride = (int64_t)T * 4 * H; g.y_tstride = 4 * H;
+    b.push(F, OP_RUNGEMM, 200).g = g;
+  }
+  auto lstm_desc = [&](LstmRec& r) {
+    std::memset(&r, 0, sizeof(r));
+    r.gx = gxb; r.whh[0] = r.whh[1] = b.pptr("enhance.weight_hh_l0");
+    r.h = hbuf; r.gates = gatesb; r.c = cbuf; r.dh = r.dgates = b.none();
+    r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = adt;
+  };
+  lstm_desc(b.push(F, OP_LSTM_FWD, 200).lstm);
+  Ptr decin = b.ws("decin", BT * D * Cl, adt);
+  RunGemm proj = Builder::gemm0();
+  Builder::Coef cproj;
+  std::function<void(int, int32_t*)> bproj;
+  {
+    const ParamInfo &Wt = b.par("tranform.weight"), &bt = b.par("tranform.bias");
+    RunGemm& g = proj;
+    g.x[0] = hbuf; g.xdt = adt; g.ydt = adt;
+    g.bstride[0] = (int64_t)T * H; g.tstride[0] = H; g.rowlen[0] = H; g.Tin[0] = T;
+    g.M = (int)BT; g.Tout = T; g.Fo = 1;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, 0, H, 0};
+    g.N = D * Cl;
+    Builder::layout_segs(g);
+    cproj = [=](int nn, int s, int j) -> int32_t { const int dd = nn / Cl, cc = nn % Cl; return pe(Wt, (int64_t)(cc * D + dd) * H + j, 1); };
+    bproj = [=](int nn, int32_t* o) { const int dd = nn / Cl, cc = nn % Cl; o[0] = pe(bt, cc * D + dd, 1); o[1] = 0; };
+    b.pack_weights(F, g, cproj, "proj", 300, &bproj);
+    g.y = decin; g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl;
+    b.push(F, OP_RUNGEMM, 300).g = g;
+  }
+
+  // ---- decoder (RealConvTranspose2d, tools_for_model.py:389-425; torch.cat([out, enc], 1) skips)
+  std::vector<Ptr> decy(n), decz(n), dec_mi(n);
+  struct DecSrc { Ptr p; int64_t bstride; int tstride, base, C; };
+  DecSrc dprev{decin, (int64_t)T * D * Cl, D * Cl, 0, Cl};
+  for (int d = 0; d < n; ++d) {
+    const int idx = n - d;
+    const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
+    const int Fi = Fe[idx], Fo = 2 * Fi;
+    const bool last = (idx == 1);
+    const std::string nm = "dec" + std::to_string(d);
+    const std::string pp = "decoder." + std::to_string(d);
+    const ParamInfo &Wc = b.par(pp + ".0.conv.weight"), &bc = b.par(pp + ".0.conv.bias");
+    const int64_t Rr = (int64_t)B * (T + 1) * Fo;
+    decy[d] = b.ws(nm + ".y", Rr * Co, adt);
+    if (!last) { decz[d] = b.ws(nm + ".z", Rr * Co, adt); dec_mi[d] = b.ws(nm + ".mi", 2 * Co, DT_F32); }
+    std::function<int32_t(int, int, int, int, int)> wcoef = [=](int nn, int s, int cc, int kh, int kw) -> int32_t {
+      const int rc = s == 0 ? cc : C0 + cc;
+      return pe(Wc, (((int64_t)rc * Co + nn) * KS + kh) * 2 + kw, 1);
+    };
+    std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) { o[0] = pe(bc, nn, 1); o[1] = 0; };
+    const int nblk1 = (int)(((int64_t)B * (T + 1) * Fi + kBM - 1) / kBM);
+    Ptr part = b.none();
+    const int npad_stat = (int)rup(Co, bn_of(Co));
+    if (!last) part = b.ws(nm + ".stat", (int64_t)2 * nblk1 * 2 * npad_stat, DT_F32);
+    for (int par = 0; par < 2; ++par) {
+      RunGemm g = Builder::gemm0();
+      g.xdt = adt; g.ydt = adt;
+      const int nsrc = cfg.skip ? 2 : 1;
+      DecSrc src[2] = {dprev, DecSrc{encz[idx - 1], (int64_t)T * Fi * C1, Fi * C1, 0, C1}};
+      g.nseg = 0;
+      const int ntap = par == 0 ? 3 : 2;
+      for (int s = 0; s < nsrc; ++s) {
+        g.x[s] = src[s].p; g.bstride[s] = src[s].bstride; g.tstride[s] = src[s].tstride; g.base[s] = src[s].base;
+        g.rowlen[s] = Fi * src[s].C; g.fstride[s] = src[s].C; g.Tin[s] = T;
+        for (int kw = 0; kw < 2; ++kw) g.seg[g.nseg++] = Seg{s, -kw, par == 0 ? -src[s].C : 0, ntap * src[s].C, 0};
+      }
+      g.M = B * (T + 1) * Fi; g.Tout = T + 1; g.Fo = Fi;
+      g.N = Co;
+      Builder::layout_segs(g);
+      const int c0 = C0, c1 = C1;
+      Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+        const int s = sg / 2, kw = sg % 2;
+        const int Cs = s == 0 ? c0 : c1;
+        const int jj = j / Cs, cc = j % Cs;
+        return wcoef(nn, s, cc, par == 0 ? 4 - 2 * jj : 3 - 2 * jj, kw);
+      };
+      b.pack_weights(F, g, coef, nm + ".p" + std::to_string(par), 400 + d, par == 0 ? &bias : nullptr);
+      if (par == 1) g.bias = dec[d].f[0].bias;
+      g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Co; g.y_tstride = Fo * Co; g.y_fstride = 2 * Co; g.y_off = par * Co;
+      if (!last && cfg.training) g.stats = b.mk(A_WS, part.off + (int64_t)par * nblk1 * 2 * g.Npad * 4);
+      b.push(F, OP_RUNGEMM, 400 + d).g = g;
+      dec[d].f[par] = g; dec[d].coef[par] = coef;
+    }
+    dec[d].bias = bias; dec[d].C = Co; dec[d].Fq = Fo; dec[d].R = Rr;
+    if (!last) {
+      Op& op = b.push(F, OP_BN_FINALIZE, 400 + d);
+      op.bnf.part = part; op.bnf.mean_invstd = dec_mi[d];
+      op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
+      op.bnf.nblk = cfg.training ? 2 * nblk1 : -1; op.bnf.C = Co; op.bnf.Cpad = npad_stat; op.bnf.count = (double)Rr;
+      op.bnf.eps = 1e-5f; op.bnf.momentum = 0.1f;
+      Op& oa = b.push(F, OP_BN_APPLY, 400 + d);
+      oa.bna.y = decy[d]; oa.bna.z = decz[d]; oa.bna.mean_invstd = dec_mi[d];
+      oa.bna.gamma = b.pptr(pp + ".1.weight"); oa.bna.beta = b.pptr(pp + ".1.bias"); oa.bna.slope = b.pptr(pp + ".2.weight");
+      oa.bna.R = Rr; oa.bna.C = Co; oa.bna.dt = adt;
+      dprev = DecSrc{decz[d], (int64_t)(T + 1) * Fo * Co, Fo * Co, Fo * Co, Co};
+    }
+  }
+
+  // ---- mask, iSTFT, outputs (models.py:519-532)
+  Ptr est = b.ws("est", BT * SW, DT_F32);
+  Ptr estm = b.ws("estm", BT * NF, DT_F32);
+  Ptr frames = b.ws("frames", BT * W, DT_F32);
+  Mask mk;
+  std::memset(&mk, 0, sizeof(mk));
+  {
+    const int Fo = Fe[0];
+    mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.estm = estm; mk.dest = mk.dmask = b.none();
+    mk.frames = BT; mk.NF = NF; mk.mode = 3; mk.mdt = adt; mk.mch = 1;
+    mk.mask_fstride = Fo; mk.mask_bstride = (int64_t)(T + 1) * Fo; mk.mask_base = Fo; mk.T = T;
+    b.push(F, OP_MASK_FWD, 500).mask = mk;
+  }
+  {
+    RunGemm g = Builder::gemm0();
+    g.x[0] = est; g.xdt = DT_F32; g.ydt = DT_F32;
+    g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.rowlen[0] = SW; g.Tin[0] = T;
+    g.M = (int)BT; g.Tout = T; g.Fo = 1;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, 0, SW, 0};
+    g.N = W;
+    Builder::layout_segs(g);
+    const_weights(g, [&](int nn, int j) { return j < 2 ? 0.0 : Kinv[((size_t)(j & 1) * NF + (j / 2 - 1)) * W + nn]; });
+    g.y = frames; g.y_bstride = (int64_t)T * W; g.y_tstride = W;
+    b.push(F, OP_RUNGEMM, 501).g = g;
+  }
+  Ola ola;
+  std::memset(&ola, 0, sizeof(ola));
+  ola.frames = frames; ola.wav = io_out; ola.coff = c_coff; ola.dwav = ola.dpad = b.none();
+  ola.B = B; ola.T = T; ola.L = L; ola.win = W; ola.hop = hop; ola.trim = trim;
+  b.push(F, OP_OLA_FWD, 502).ola = ola;
+  {
+    SpecOut so;
+    std::memset(&so, 0, sizeof(so));
+    so.est = estm; so.out_real = io_or; so.out_imag = b.none(); so.B = B; so.T = T; so.NF = NF; so.mode = 2;
+    b.push(F, OP_SPECOUT_FWD, 503).so = so;
+    so.est = spec_t; so.out_real = io_oi; so.mode = 1;
+    b.push(F, OP_SPECOUT_FWD, 504).so = so;
+  }
+
+  // =================================================================================================== backward
+  if (cfg.training) {
+    Ptr dpad = b.ws("dpad", (int64_t)B * Lp, DT_F32);
+    Ptr dest = b.ws("dest", BT * SW, DT_F32);
+    {
+      Ola o = ola;
+      o.dwav = io_gw; o.dpad = dpad;
+      b.push(R, OP_OLA_BWD, 502).ola = o;
+      RunGemm g = Builder::gemm0();
+      g.x[0] = dpad; g.xdt = DT_F32; g.ydt = DT_F32;
+      g.bstride[0] = Lp; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
+      g.M = (int)BT; g.Tout = 1; g.Fo = T;
+      g.nseg = 1; g.seg[0] = Seg{0, 0, 0, W, 0};
+      g.N = SW;
+      Builder::layout_segs(g);
+      const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kinv[((size_t)(nn & 1) * NF + (nn / 2 - 1)) * W + j]; });
+      g.y = dest; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+      b.push(R, OP_RUNGEMM, 501).g = g;
+    }
+    std::vector<Ptr> d_decy(n), d_decz(n), d_skip(n), d_encz(n), d_ency(n);
+    for (int d = 0; d < n; ++d) {
+      const int idx = n - d;
+      const int Co = ch[idx - 1], Fo = 2 * Fe[idx];
+      d_decy[d] = b.ws("dec" + std::to_string(d) + ".dy", (int64_t)B * (T + 1) * Fo * Co, adt);
+      if (idx != 1) d_decz[d] = b.ws("dec" + std::to_string(d) + ".dz", (int64_t)B * T * Fo * Co, adt);
+    }
+    for (int i = 0; i < n; ++i) {
+      const int64_t e = (int64_t)B * T * Fe[i + 1] * ch[i + 1];
+      d_ency[i] = b.ws("enc" + std::to_string(i) + ".dy", e, adt);
+      d_encz[i] = b.ws("enc" + std::to_string(i) + ".dz", e, adt);
+      if (cfg.skip) d_skip[i] = b.ws("enc" + std::to_string(i) + ".dskip", e, adt);
+    }
+    Ptr d_decin = b.ws("decin.d", BT * D * Cl, adt);
+    {
+      Mask m2 = mk;
+      m2.dest = dest; m2.dmask = d_decy[n - 1];
+      b.push(R, OP_MASK_BWD, 500).mask = m2;
+    }
+    auto bn_bwd = [&](int tag, Ptr y, Ptr dz0, Ptr dz1, Ptr mi, const std::string& pp, int C, int64_t Rr, int64_t rpb, int skip, Ptr dy,
+                      const std::string& nm) {
+      int64_t rpbk = std::max<int64_t>(64, (Rr + 2047) / 2048);
+      const int nblk = (int)((Rr + rpbk - 1) / rpbk);
+      BnBwdReduce r;
+      std::memset(&r, 0, sizeof(r));
+      r.y = y; r.dz0 = dz0; r.dz1 = dz1; r.mean_invstd = mi;
+      r.gamma = b.pptr(pp + ".1.weight"); r.beta = b.pptr(pp + ".1.bias"); r.slope = b.pptr(pp + ".2.weight");
+      r.part = b.ws(nm + ".bnpart", (int64_t)nblk * 3 * C, DT_F32);
+      r.R = Rr; r.C = C; r.dt = adt; r.nblk = nblk; r.rows_per_blk = (int)rpbk; r.rpb = rpb; r.skip = skip;
+      b.push(R, OP_BN_BWD_REDUCE, tag).bnr = r;
+      BnBwdApply a;
+      std::memset(&a, 0, sizeof(a));
+      a.r = r; a.totals = b.ws(nm + ".bntot", 3 * C, DT_F32); a.dy = dy;
+      a.dgamma = b.pptr(pp + ".1.weight", A_GRAD); a.dbeta = b.pptr(pp + ".1.bias", A_GRAD); a.dslope = b.pptr(pp + ".2.weight", A_GRAD);
+      a.count = (double)Rr;
+      b.push(R, OP_BN_BWD_FINALIZE, tag).bnb = a;
+      b.push(R, OP_BN_BWD_APPLY, tag).bnb = a;
+    };
+    for (int d = n - 1; d >= 0; --d) {
+      const int idx = n - d;
+      const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
+      const int Fi = Fe[idx], Fo = 2 * Fi;
+      const bool last = (idx == 1);
+      const std::string nm = "dec" + std::to_string(d);
+      const std::string pp = "decoder." + std::to_string(d);
+      if (!last)
+        bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm);
+      for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
+      const int nsrc = cfg.skip ? 2 : 1;
+      for (int s = 0; s < nsrc; ++s) {
+        const int Cs = s == 0 ? C0 : C1;
+        RunGemm g = Builder::gemm0();
+        g.x[0] = d_decy[d]; g.xdt = adt; g.ydt = adt;
+        g.bstride[0] = (int64_t)(T + 1) * Fo * Co; g.tstride[0] = Fo * Co; g.rowlen[0] = Fo * Co; g.fstride[0] = 2 * Co; g.Tin[0] = T + 1;
+        g.M = B * T * Fi; g.Tout = T; g.Fo = Fi;
+        g.nseg = 2;
+        g.seg[0] = Seg{0, 0, -2 * Co, KS * Co, 0};
+        g.seg[1] = Seg{0, 1, -2 * Co, KS * Co, 0};
+        g.N = Cs;
+        Builder::layout_segs(g);
+        const Builder::Coef f0 = dec[d].coef[0], f1 = dec[d].coef[1];
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+          const int kw = sg, kh = j / Co, co = j % Co;
+          const int par = kh & 1;
+          const int jj = par == 0 ? (4 - kh) / 2 : (3 - kh) / 2;
+          return (par == 0 ? f0 : f1)(co, s * 2 + kw, jj * Cs + nn);
+        };
+        b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(s), 400 + d);
+        g.y = s == 0 ? (d > 0 ? d_decz[d - 1] : d_decin) : d_skip[idx - 1];
+        g.y_bstride = (int64_t)T * Fi * Cs; g.y_tstride = Fi * Cs; g.y_fstride = Cs; g.y_off = 0;
+        b.push(R, OP_RUNGEMM, 400 + d).g = g;
+      }
+    }
+    // projection + LSTM backward
+    Ptr dh = b.ws("lstm.dh", BT * H, DT_F32);
+    {
+      b.wgrad(R, proj, d_decin, cproj, 300, &bproj);
+      RunGemm g = Builder::gemm0();
+      g.x[0] = d_decin; g.xdt = adt; g.ydt = DT_F32;
+      g.bstride[0] = (int64_t)T * D * Cl; g.tstride[0] = D * Cl; g.rowlen[0] = D * Cl; g.Tin[0] = T;
+      g.M = (int)BT; g.Tout = T; g.Fo = 1;
+      g.nseg = 1; g.seg[0] = Seg{0, 0, 0, D * Cl, 0};
+      g.N = H;
+      Builder::layout_segs(g);
+      Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return cproj(j, 0, nn); };
+      b.pack_weights(R, g, coef, "proj.dg", 300);
+      g.y = dh; g.y_bstride = (int64_t)T * H; g.y_tstride = H;
+      b.push(R, OP_RUNGEMM, 300).g = g;
+    }
+    Ptr dgates = b.ws("lstm.dgates", BT * 4 * H, adt);
+    {
+      LstmRec& r = b.push(R, OP_LSTM_BWD, 200).lstm;
+      lstm_desc(r);
+      r.dh = dh; r.dgates = dgates;
+    }
+    {
+      RunGemm fw = ggx;
+      fw.ydt = adt;
+      b.wgrad(R, fw, dgates, cgx, 200, &bgx);
+      RunGemm f = Builder::gemm0();
+      f.x[0] = hbuf; f.xdt = adt; f.ydt = adt;
+      f.bstride[0] = (int64_t)T * H; f.tstride[0] = H; f.rowlen[0] = H; f.Tin[0] = T;
+      f.M = (int)BT; f.Tout = T; f.Fo = 1;
+      f.nseg = 1; f.seg[0] = Seg{0, -1, 0, H, 0};
+      f.N = 4 * H;
+      Builder::layout_segs(f);
+      f.y_bstride = (int64_t)T * 4 * H; f.y_tstride = 4 * H;
+      Builder::Coef chh = [=](int nn, int sg, int j) -> int32_t { return pe(Whh, (int64_t)nn * H + j, 1); };
+      b.wgrad(R, f, dgates, chh, 200, nullptr);
+      for (int q = 0; q < D; ++q) {            // dX into the encoder-output gradient, one slice per frequency row d
+        RunGemm g = Builder::gemm0();
+        g.x[0] = dgates; g.xdt = adt; g.ydt = adt;
+        g.bstride[0] = (int64_t)T * 4 * H; g.tstride[0] = 4 * H; g.rowlen[0] = 4 * H; g.Tin[0] = T;
+        g.M = (int)BT; g.Tout = T; g.Fo = 1;
+        g.nseg = 1; g.seg[0] = Seg{0, 0, 0, 4 * H, 0};
+        g.N = Cl;
+        Builder::layout_segs(g);
+        const Builder::Coef cf = cgx;
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return cf(j, q, nn); };
+        b.pack_weights(R, g, coef, "lstm.dx" + std::to_string(q), 200);
+        g.y = d_encz[n - 1]; g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl; g.y_off = q * Cl;
+        b.push(R, OP_RUNGEMM, 200).g = g;
+      }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
+      const std::string nm = "enc" + std::to_string(i);
+      const std::string pp = "encoder." + std::to_string(i);
+      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm);
+      b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
+      if (i == 0) continue;
+      for (int par = 0; par < 2; ++par) {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = d_ency[i]; g.xdt = adt; g.ydt = adt;
+        g.bstride[0] = (int64_t)T * Fo * Co; g.tstride[0] = Fo * Co; g.rowlen[0] = Fo * Co; g.fstride[0] = Co; g.Tin[0] = T;
+        g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;
+        const int ntap = par == 0 ? 3 : 2;
+        g.nseg = 2;
+        g.seg[0] = Seg{0, 1, par == 0 ? -Co : 0, ntap * Co, 0};
+        g.seg[1] = Seg{0, 0, par == 0 ? -Co : 0, ntap * Co, 0};
+        g.N = Ci;
+        Builder::layout_segs(g);
+        const Builder::Coef cf = enc[i].coef[0];
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+          const int kw = sg, jj = j / Co, co = j % Co;
+          return cf(co, kw, (par == 0 ? 4 - 2 * jj : 3 - 2 * jj) * Ci + nn);
+        };
+        b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(par), 100 + i);
+        g.y = d_encz[i - 1]; g.y_bstride = (int64_t)T * Fi * Ci; g.y_tstride = Fi * Ci; g.y_fstride = 2 * Ci; g.y_off = par * Ci;
+        b.push(R, OP_RUNGEMM, 100 + i).g = g;
+      }
+    }
+    b.finish_unpack(R);
+  }
+  P->arena_bytes[A_WS] = b.ws_off;
+  P->arena_bytes[A_PARAM] = nparam * 4;
+  P->arena_bytes[A_GRAD] = nparam * 4;
+  P->arena_bytes[A_STATE] = std::max<int64_t>(nstate, 1) * 4;
+  P->arena_bytes[A_CONST] = (int64_t)P->consts.size();
+  P->arena_bytes[A_IO] = b.io_off;
+  return P;
+}
+
+Plan* build_plan(const ModelConfig& cfg) { return cfg.model == 1 ? build_crn_plan(cfg) : build_dccrn_plan(cfg); }
 
 }  // namespace sefd

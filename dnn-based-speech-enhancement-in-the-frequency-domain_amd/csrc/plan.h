@@ -48,5 +48,7 @@ struct Plan {
 };
 
 Plan* build_dccrn_plan(const ModelConfig& cfg);
+Plan* build_crn_plan(const ModelConfig& cfg);
+Plan* build_plan(const ModelConfig& cfg);
 
 }  // namespace sefd

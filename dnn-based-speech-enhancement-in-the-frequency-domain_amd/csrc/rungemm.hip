@@ -43,8 +43,8 @@ __device__ __forceinline__ uint4 load_a_chunk(const RunGemm& d, const TA* x0, co
   if (d.rowlen[s] - r < hi) hi = d.rowlen[s] - r;
   if (hi <= lo) return z;
   const TA* src = (s ? x1 : x0) + (s ? base1 : base0) + (int64_t)tt * d.tstride[s] + r;
-  if (lo == 0 && hi == VEC) return *reinterpret_cast<const uint4*>(src);
-  // partially valid chunk: element-wise
+  if (lo == 0 && hi == VEC && (reinterpret_cast<uintptr_t>(src) & 15) == 0) return *reinterpret_cast<const uint4*>(src);
+  // partially valid or unaligned chunk: element-wise
   if (sizeof(TA) == 4) {
     uint32_t v[4] = {0, 0, 0, 0};
     const uint32_t* p = reinterpret_cast<const uint32_t*>(src);

@@ -145,7 +145,17 @@ struct Mask {
   int32_t mdt, pad0_;          // DType of mask / dmask
   int64_t mask_fstride;        // elements between consecutive frames of `mask` (decoder buffer has T+1 frames / batch)
   int64_t mask_bstride, mask_base;
-  int32_t T, pad_;
+  int32_t T;
+  int32_t mch;                 // channels of the mask tensor: 2 (DCCRN complex mask) or 1 (CRN magnitude mask, mode 3)
+  Ptr estm;                    // mode 3 only: est_mags = tanh(mask) * |spec|  as [B*T][NF] fp32 (CRN.forward's first output)
+};
+
+// |spec| for the CRN encoder (ConvSTFT 'real', tools_for_model.py:62-68: no eps): mags[f][MO + k] = sqrt(re^2 + im^2), k < NF;
+// the MS-wide rows are zero padded; MO keeps bin 1 16-byte aligned for both storage dtypes.
+struct Mags {
+  Ptr spec, mags;
+  int64_t frames;
+  int32_t NF, MS, MO, dt;
 };
 
 // Overlap-add + 1/(coff+1e-8) + trim + clamp (tools_for_model.py:101-110, models.py:280-282)
@@ -157,9 +167,11 @@ struct Ola {
 };
 
 // est spec [B][T][NF+1][2] (fp32, slot layout above) <-> reference layout out_real/out_imag [B][NF][T] fp32
+// mode 1: out_real = |est| (magnitude of the pairs, CRN target_mags) ; mode 2: est is a plain [B*T][NF] fp32 array -> out_real
 struct SpecOut {
   Ptr est, out_real, out_imag; // forward: est -> out_*   ; backward: dest += d(out_*)
   int32_t B, T, NF, accumulate;
+  int32_t mode, pad_;
 };
 
 struct Memset {
@@ -170,7 +182,7 @@ struct Memset {
 enum OpKind : int32_t {
   OP_RUNGEMM = 1, OP_WGRAD, OP_PACK, OP_UNPACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY,
   OP_LSTM_FWD, OP_LSTM_BWD, OP_COMBINE_FWD, OP_COMBINE_BWD, OP_MASK_FWD, OP_MASK_BWD, OP_OLA_FWD, OP_OLA_BWD,
-  OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE
+  OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE, OP_MAGS
 };
 
 struct Op {
@@ -190,6 +202,7 @@ struct Op {
     Ola ola;
     SpecOut so;
     Memset ms;
+    Mags mags;
   };
 };
 

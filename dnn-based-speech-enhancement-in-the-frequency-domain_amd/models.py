@@ -88,10 +88,7 @@ class _Runtime:
     """Plan + device arenas for one (B, L, training, device) combination."""
 
     def __init__(self, owner, B, L, training, device):
-        self.plan = Plan(B, L, kernel_num=tuple(owner.kernel_num[1:]), rnn_layers=owner.hidden_layers,
-                         rnn_units=owner.rnn_units, win_len=owner.win_len, win_inc=owner.win_inc, fft_len=owner.fft_len,
-                         masking_mode=owner.masking_mode, lstm=owner._lstm_kind, skip_type=owner._skip,
-                         act_dtype=owner.act_dtype, training=training)
+        self.plan = owner._make_plan(B, L, training)
         p = self.plan
         self.arenas = [None] * ARENA_COUNT
         self.arenas[ARENA_WS] = torch.zeros(max(p.arena_bytes[ARENA_WS], 256), dtype=torch.uint8, device=device)
@@ -108,6 +105,7 @@ class _Runtime:
         self.g_wav = p.io(self.arenas, "grad_wav", (B, L))
         self.g_real = p.io(self.arenas, "grad_real", (B, NF, T))
         self.g_imag = p.io(self.arenas, "grad_imag", (B, NF, T))
+        self.tgt = p.io(self.arenas, "tgt", (B, L)) if "io.tgt" in p.buffer_names() else None
 
     def run(self, phase):
         self.plan.run(phase, self.arenas, torch.cuda.current_stream().cuda_stream)
@@ -115,8 +113,10 @@ class _Runtime:
 
 class _DCCRNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, owner, rt, inputs, *params):
+    def forward(ctx, owner, rt, inputs, targets, *params):
         rt.wav.copy_(inputs)
+        if rt.tgt is not None:
+            rt.tgt.copy_(targets)
         rt.run(PHASE_FWD)
         ctx.owner, ctx.rt = owner, rt
         ctx.n = len(params)
@@ -133,57 +133,14 @@ class _DCCRNFunction(torch.autograd.Function):
         rt.run(PHASE_BWD)
         flat = owner._flat_grad.clone()
         grads = [flat[off:off + n].view(shape) for (off, n, shape) in owner._param_slices]
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
-# ------------------------------------------------------------------------------------------ the model
-class DCCRN(nn.Module):
-    """Same constructor as the reference (models.py:17-28)."""
+# ------------------------------------------------------------------------------------------ shared machinery
+class _SefdModule(nn.Module):
+    """Flat parameter storage + per-(B, L) device runtimes shared by the HIP-backed models."""
 
-    def __init__(self, rnn_layers=cfg.rnn_layers, rnn_units=cfg.rnn_units, win_len=cfg.win_len, win_inc=cfg.win_inc,
-                 fft_len=cfg.fft_len, win_type=cfg.window, masking_mode=cfg.masking_mode, use_cbn=False, kernel_size=5):
-        super().__init__()
-        if use_cbn:
-            raise NotImplementedError("ComplexBatchNorm (use_cbn=True) is not on the HIP path")
-        self.win_len, self.win_inc, self.fft_len, self.win_type = win_len, win_inc, fft_len, win_type
-        self.rnn_units = rnn_units
-        self.input_dim = self.output_dim = win_len
-        self.hidden_layers = rnn_layers
-        self.kernel_size = kernel_size
-        self.kernel_num = [2] + list(cfg.dccrn_kernel_num)
-        self.masking_mode = masking_mode
-        self.fix = True
-        self.act_dtype = cfg.act_dtype
-        self._lstm_kind = cfg.lstm
-        self._skip = bool(cfg.skip_type)
-        if cfg.lstm != 'complex':
-            raise NotImplementedError("cfg.lstm == 'real' is not on the HIP path yet")
-        self.stft = ConvSTFT(win_len, win_inc, fft_len, win_type, 'complex')
-        self.istft = ConviSTFT(win_len, win_inc, fft_len, win_type, 'complex')
-        self.encoder = nn.ModuleList()
-        self.decoder = nn.ModuleList()
-        kn = self.kernel_num
-        for idx in range(len(kn) - 1):
-            self.encoder.append(nn.Sequential(
-                ComplexConv2d(kn[idx], kn[idx + 1], kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 1)),
-                nn.BatchNorm2d(kn[idx + 1]), nn.PReLU()))
-        hidden_dim = fft_len // (2 ** len(kn))
-        rnns = []
-        for idx in range(rnn_layers):
-            rnns.append(NavieComplexLSTM(
-                input_size=hidden_dim * kn[-1] if idx == 0 else rnn_units, hidden_size=rnn_units,
-                projection_dim=hidden_dim * kn[-1] if idx == rnn_layers - 1 else None))
-        self.enhance = nn.Sequential(*rnns)      # registered here: the reference assigns it before the decoder is filled
-        mult = 2 if cfg.skip_type else 1
-        for idx in range(len(kn) - 1, 0, -1):
-            mods = [ComplexConvTranspose2d(kn[idx] * mult, kn[idx - 1], kernel_size=(kernel_size, 2), stride=(2, 1),
-                                           padding=(2, 0), output_padding=(1, 0))]
-            if idx != 1:
-                mods += [nn.BatchNorm2d(kn[idx - 1]), nn.PReLU()]
-            self.decoder.append(nn.Sequential(*mods))
-        # state_dict order of the reference: stft, istft, encoder, decoder, enhance
-        enh = self._modules.pop('enhance')
-        self._modules['enhance'] = enh
+    def _init_runtime_state(self):
         self._flat_param = self._flat_grad = self._flat_state = self._flat_nbt = None
         self._param_slices = None
         self._runtimes = {}
@@ -191,16 +148,11 @@ class DCCRN(nn.Module):
     def flatten_parameters(self):
         pass
 
-    # ---- flat storage ---------------------------------------------------------------------------------------
     def _trainable(self):
         return [(n, p) for n, p in self.named_parameters()]
 
     def _bn_buffers(self):
-        out = []
-        for n, b in self.named_buffers():
-            if n.endswith(("running_mean", "running_var")):
-                out.append((n, b))
-        return out
+        return [(n, b) for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var"))]
 
     def _flat_ok(self, device):
         fp = self._flat_param
@@ -259,33 +211,14 @@ class DCCRN(nn.Module):
             self._runtimes[key] = rt
         return rt
 
-    # ---- reference surface ----------------------------------------------------------------------------------
-    def forward(self, inputs, targets=0):
-        if self.masking_mode == 'Direct(None make)':
-            raise NotImplementedError("Direct (spectral mapping) mode is not on the HIP path yet")
-        if not inputs.is_cuda:
-            raise RuntimeError("sefd DCCRN runs on the MI355X only (inputs must be a cuda tensor); there is no CPU fallback")
-        inputs = inputs.float().contiguous()
-        B, L = inputs.shape
-        rt = self._runtime(B, L, inputs.device)
-        if self.training:
-            self._flat_nbt += 1
-        params = [p for _, p in self._trainable()]
-        out_real, out_imag, out_wav = _DCCRNFunction.apply(self, rt, inputs, *params)
-        return out_real, out_imag, out_wav
-
     def get_params(self, weight_decay=0.0):
         weights, biases = [], []
         for name, param in self.named_parameters():
             (biases if 'bias' in name else weights).append(param)
         return [{'params': weights, 'weight_decay': weight_decay}, {'params': biases, 'weight_decay': 0.0}]
 
-    def loss(self, estimated, target, real_spec=0, img_spec=0, perceptual=False):
-        """models.py:303-323."""
-        if perceptual:
-            if cfg.perceptual == 'LMS':
-                raise NotImplementedError("LMS perceptual loss: not on the HIP path yet")
-            raise NotImplementedError("PMSQE is third-party (asteroid) arithmetic: parity unpinned, not built")
+    def _main_loss(self, estimated, target):
+        """models.py:315-323 / 558-565."""
         if cfg.loss == 'MSE':
             return tfl.mse(estimated, target)
         elif cfg.loss == 'SDR':
@@ -304,14 +237,17 @@ class DCCRN(nn.Module):
             raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
         inputs = inputs.float()
+        targets = targets.float().contiguous()
         B, L = inputs.shape
         rt = self._runtime(B, L, inputs.device)
         optimizer.bind(self)
         self._flat_nbt += 1
         stream = torch.cuda.current_stream().cuda_stream
         rt.wav.copy_(inputs)
+        if rt.tgt is not None:
+            rt.tgt.copy_(targets)
         rt.run(PHASE_FWD)
-        ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets.float().contiguous(), stream)
+        ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
         rt.g_real.zero_()
         rt.g_imag.zero_()
         tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)
@@ -321,3 +257,173 @@ class DCCRN(nn.Module):
             optimizer.grad_scale = exchange.grad_scale
         optimizer.step_flat()
         return loss
+
+
+# ------------------------------------------------------------------------------------------ the models
+class DCCRN(_SefdModule):
+    """Same constructor as the reference (models.py:17-28)."""
+
+    def __init__(self, rnn_layers=cfg.rnn_layers, rnn_units=cfg.rnn_units, win_len=cfg.win_len, win_inc=cfg.win_inc,
+                 fft_len=cfg.fft_len, win_type=cfg.window, masking_mode=cfg.masking_mode, use_cbn=False, kernel_size=5):
+        super().__init__()
+        if use_cbn:
+            raise NotImplementedError("ComplexBatchNorm (use_cbn=True) is not on the HIP path")
+        self.win_len, self.win_inc, self.fft_len, self.win_type = win_len, win_inc, fft_len, win_type
+        self.rnn_units = rnn_units
+        self.input_dim = self.output_dim = win_len
+        self.hidden_layers = rnn_layers
+        self.kernel_size = kernel_size
+        self.kernel_num = [2] + list(cfg.dccrn_kernel_num)
+        self.masking_mode = masking_mode
+        self.fix = True
+        self.act_dtype = cfg.act_dtype
+        self._lstm_kind = cfg.lstm
+        self._skip = bool(cfg.skip_type)
+        if cfg.lstm != 'complex':
+            raise NotImplementedError("cfg.lstm == 'real' is not on the HIP path yet")
+        self.stft = ConvSTFT(win_len, win_inc, fft_len, win_type, 'complex')
+        self.istft = ConviSTFT(win_len, win_inc, fft_len, win_type, 'complex')
+        self.encoder = nn.ModuleList()
+        self.decoder = nn.ModuleList()
+        kn = self.kernel_num
+        for idx in range(len(kn) - 1):
+            self.encoder.append(nn.Sequential(
+                ComplexConv2d(kn[idx], kn[idx + 1], kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 1)),
+                nn.BatchNorm2d(kn[idx + 1]), nn.PReLU()))
+        hidden_dim = fft_len // (2 ** len(kn))
+        rnns = []
+        for idx in range(rnn_layers):
+            rnns.append(NavieComplexLSTM(
+                input_size=hidden_dim * kn[-1] if idx == 0 else rnn_units, hidden_size=rnn_units,
+                projection_dim=hidden_dim * kn[-1] if idx == rnn_layers - 1 else None))
+        self.enhance = nn.Sequential(*rnns)      # registered here: the reference assigns it before the decoder is filled
+        mult = 2 if cfg.skip_type else 1
+        for idx in range(len(kn) - 1, 0, -1):
+            mods = [ComplexConvTranspose2d(kn[idx] * mult, kn[idx - 1], kernel_size=(kernel_size, 2), stride=(2, 1),
+                                           padding=(2, 0), output_padding=(1, 0))]
+            if idx != 1:
+                mods += [nn.BatchNorm2d(kn[idx - 1]), nn.PReLU()]
+            self.decoder.append(nn.Sequential(*mods))
+        # state_dict order of the reference: stft, istft, encoder, decoder, enhance
+        enh = self._modules.pop('enhance')
+        self._modules['enhance'] = enh
+        self._init_runtime_state()
+
+    def _make_plan(self, B, L, training):
+        return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=self.hidden_layers, rnn_units=self.rnn_units,
+                    win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, masking_mode=self.masking_mode,
+                    lstm=self._lstm_kind, skip_type=self._skip, act_dtype=self.act_dtype, training=training, model="DCCRN")
+
+    # ---- reference surface ----------------------------------------------------------------------------------
+    def forward(self, inputs, targets=0):
+        if self.masking_mode == 'Direct(None make)':
+            raise NotImplementedError("Direct (spectral mapping) mode is not on the HIP path yet")
+        if not inputs.is_cuda:
+            raise RuntimeError("sefd DCCRN runs on the MI355X only (inputs must be a cuda tensor); there is no CPU fallback")
+        inputs = inputs.float().contiguous()
+        B, L = inputs.shape
+        rt = self._runtime(B, L, inputs.device)
+        if self.training:
+            self._flat_nbt += 1
+        params = [p for _, p in self._trainable()]
+        out_real, out_imag, out_wav = _DCCRNFunction.apply(self, rt, inputs, None, *params)
+        return out_real, out_imag, out_wav
+
+    def loss(self, estimated, target, real_spec=0, img_spec=0, perceptual=False):
+        """models.py:303-323."""
+        if perceptual:
+            if cfg.perceptual == 'LMS':
+                raise NotImplementedError("LMS perceptual loss: not on the HIP path yet")
+            raise NotImplementedError("PMSQE is third-party (asteroid) arithmetic: parity unpinned, not built")
+        return self._main_loss(estimated, target)
+
+
+class RealConv2d(nn.Module):
+    """Parameter holder (tools_for_model.py:341-386)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding=[padding[0], 0])
+        nn.init.normal_(self.conv.weight.data, std=0.05)
+        nn.init.constant_(self.conv.bias, 0.)
+
+
+class RealConvTranspose2d(nn.Module):
+    """Parameter holder (tools_for_model.py:389-425)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, output_padding):
+        super().__init__()
+        self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride, padding=padding, output_padding=output_padding)
+        nn.init.normal_(self.conv.weight.data, std=0.05)
+        nn.init.constant_(self.conv.bias, 0.)
+
+
+class CRN(_SefdModule):
+    """Same constructor as the reference (models.py:330-341).  `rnn_layers` is ignored there too (one LSTM layer, Q13)."""
+
+    def __init__(self, rnn_layers=cfg.rnn_layers, rnn_input_size=cfg.rnn_input_size, rnn_units=cfg.rnn_units, win_len=cfg.win_len,
+                 win_inc=cfg.win_inc, fft_len=cfg.fft_len, win_type=cfg.window, masking_mode=cfg.masking_mode, kernel_size=5):
+        super().__init__()
+        self.win_len, self.win_inc, self.fft_len, self.win_type = win_len, win_inc, fft_len, win_type
+        self.rnn_input_size = rnn_input_size
+        self.rnn_units = rnn_units // 2
+        self.input_dim = self.output_dim = win_len
+        self.hidden_layers = rnn_layers
+        self.kernel_size = kernel_size
+        self.kernel_num = [2] + list(cfg.dccrn_kernel_num)
+        self.masking_mode = masking_mode
+        self.act_dtype = cfg.act_dtype
+        self._skip = bool(cfg.skip_type)
+        kn = self.kernel_num
+        self.stft = ConvSTFT(win_len, win_inc, fft_len, win_type, 'real')
+        self.istft = ConviSTFT(win_len, win_inc, fft_len, win_type, 'complex')
+        self.encoder = nn.ModuleList()
+        self.decoder = nn.ModuleList()
+        for idx in range(len(kn) - 1):
+            self.encoder.append(nn.Sequential(
+                RealConv2d(kn[idx] // 2, kn[idx + 1] // 2, kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 1)),
+                nn.BatchNorm2d(kn[idx + 1] // 2), nn.PReLU()))
+        hidden_dim = fft_len // (2 ** len(kn))
+        if hidden_dim * (kn[-1] // 2) != rnn_input_size:
+            raise ValueError("rnn_input_size must equal hidden_dim * kernel_num[-1] // 2 (SURVEY Q13)")
+        self.enhance = nn.LSTM(input_size=rnn_input_size, hidden_size=self.rnn_units, dropout=0.0, bidirectional=False, batch_first=False)
+        self.tranform = nn.Linear(self.rnn_units, rnn_input_size)
+        if not cfg.skip_type:
+            raise NotImplementedError("CRN without skip connections uses full-width nn.ConvTranspose2d in the reference: not on the HIP path")
+        for idx in range(len(kn) - 1, 0, -1):
+            mods = [RealConvTranspose2d(kn[idx], kn[idx - 1] // 2, kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 0),
+                                        output_padding=(1, 0))]
+            if idx != 1:
+                mods += [nn.BatchNorm2d(kn[idx - 1] // 2), nn.PReLU()]
+            self.decoder.append(nn.Sequential(*mods))
+        # reference registration order: stft, istft, encoder, decoder, enhance, tranform
+        for name in ("enhance", "tranform"):
+            self._modules[name] = self._modules.pop(name)
+        self._init_runtime_state()
+
+    def _make_plan(self, B, L, training):
+        if self.masking_mode != 'E':
+            raise NotImplementedError("CRN on the HIP path: T-F masking only (cfg.masking_mode 'E' semantics, models.py:519-526)")
+        return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=1, rnn_units=2 * self.rnn_units, win_len=self.win_len,
+                    win_inc=self.win_inc, fft_len=self.fft_len, masking_mode="E", lstm="real", skip_type=self._skip,
+                    act_dtype=self.act_dtype, training=training, model="CRN")
+
+    def forward(self, inputs, targets=0):
+        """models.py:467-532: returns (est_mags, target_mags, out_wav).  Only out_wav carries gradient."""
+        if not torch.is_tensor(targets):
+            raise AttributeError("CRN.forward needs targets (the reference calls self.stft(targets) unconditionally, models.py:505)")
+        if not inputs.is_cuda:
+            raise RuntimeError("sefd CRN runs on the MI355X only (inputs must be a cuda tensor); there is no CPU fallback")
+        inputs = inputs.float().contiguous()
+        B, L = inputs.shape
+        rt = self._runtime(B, L, inputs.device)
+        if self.training:
+            self._flat_nbt += 1
+        params = [p for _, p in self._trainable()]
+        est_mags, target_mags, out_wav = _DCCRNFunction.apply(self, rt, inputs, targets.float().contiguous(), *params)
+        return est_mags.detach(), target_mags.detach(), out_wav
+
+    def loss(self, estimated, target, out_mags=0, target_mags=0, perceptual=False):
+        if perceptual:
+            raise NotImplementedError("CRN + perceptual loss is unreachable in the reference (SURVEY Q10)")
+        return self._main_loss(estimated, target)

@@ -16,12 +16,12 @@ DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 class Plan:
     def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
                  win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
-                 kernel_size=5, training=True):
+                 kernel_size=5, training=True, model="DCCRN"):
         self.lib = _lib.lib()
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
         cfg = _lib.ModelConfig()
-        cfg.model = 0
+        cfg.model = {"DCCRN": 0, "CRN": 1}[model]
         cfg.B, cfg.L = int(B), int(L)
         cfg.win_len, cfg.hop, cfg.fft_len = win_len, win_inc, fft_len
         cfg.n_layers = len(kernel_num)

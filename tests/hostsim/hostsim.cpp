@@ -360,13 +360,17 @@ void run_op(const Op& op, const AB& ab) {
       for (int64_t f = 0; f < d.frames; ++f)
         for (int slot = 0; slot < NS; ++slot) {
           const int64_t i = f * NS + slot;
-          double er = 0, ei = 0;
+          double er = 0, ei = 0, emag = 0;
           if (slot >= 2) {
             const int64_t b = f / d.T, t = f % d.T;
-            const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * 2;
-            const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = ld(rp(ab, d.mask), d.mdt, mo + 1);
+            const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * d.mch;
+            const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch == 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
             const double sr = spec[i * 2], si = spec[i * 2 + 1];
-            if (d.mode == 0) {
+            if (d.mode == 3) {
+              emag = std::tanh(mr) * std::sqrt(sr * sr + si * si);
+              const double ph = std::atan2(si, sr);
+              er = emag * std::cos(ph); ei = emag * std::sin(ph);
+            } else if (d.mode == 0) {
               const double mag = std::sqrt(sr * sr + si * si + 1e-8), ph = std::atan2(si, sr), mm = std::sqrt(mr * mr + mi * mi);
               const double mph = std::atan2(mi / (mm + 1e-8), mr / (mm + 1e-8));
               const double em = std::tanh(mm) * mag;
@@ -375,6 +379,7 @@ void run_op(const Op& op, const AB& ab) {
             else { er = sr * mr; ei = si * mi; }
           }
           est[i * 2] = (float)er; est[i * 2 + 1] = (float)ei;
+          if (d.mode == 3 && slot >= 1) ((float*)rp(ab, d.estm))[f * d.NF + slot - 1] = (float)emag;
         }
       break;
     }
@@ -388,14 +393,17 @@ void run_op(const Op& op, const AB& ab) {
       for (int64_t b = 0; b < B; ++b)
         for (int u = 0; u < TT; ++u)
           for (int k = 0; k < NB; ++k) {
-            const int64_t mo = b * d.mask_bstride + (int64_t)u * d.mask_fstride + k * 2;
+            const int64_t mo = b * d.mask_bstride + (int64_t)u * d.mask_fstride + k * d.mch;
             double gr = 0, gi = 0;
             if (u >= lead) {
               const int64_t f = b * d.T + (u - lead);
               const int64_t s_ = (f * NS + k + 2) * 2;
               const double sr = spec[s_], si = spec[s_ + 1], der = dest[s_], dei = dest[s_ + 1];
-              const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = ld(rp(ab, d.mask), d.mdt, mo + 1);
-              if (d.mode == 0) {
+              const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch == 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
+              if (d.mode == 3) {
+                const double tm = std::tanh(mr), ph = std::atan2(si, sr);
+                gr = (der * std::cos(ph) + dei * std::sin(ph)) * std::sqrt(sr * sr + si * si) * (1 - tm * tm);
+              } else if (d.mode == 0) {
                 const double mag = std::sqrt(sr * sr + si * si + 1e-8), ph = std::atan2(si, sr), mm = std::sqrt(mr * mr + mi * mi);
                 const double den = mm + 1e-8, rpv = mr / den, ipv = mi / den, mph = std::atan2(ipv, rpv), tm = std::tanh(mm), em = tm * mag;
                 const double sn = std::sin(ph + mph), cs = std::cos(ph + mph);
@@ -411,7 +419,7 @@ void run_op(const Op& op, const AB& ab) {
               else { gr = der * sr; gi = dei * si; }
             }
             st(rp(ab, d.dmask), d.mdt, mo, (float)gr);
-            st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
+            if (d.mch == 2) st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
           }
       break;
     }
@@ -451,16 +459,31 @@ void run_op(const Op& op, const AB& ab) {
       const SpecOut& d = op.so;
       float* est = (float*)rp(ab, d.est);
       float* orr = (float*)rp(ab, d.out_real);
-      float* oi = (float*)rp(ab, d.out_imag);
+      float* oi = d.mode == 0 ? (float*)rp(ab, d.out_imag) : nullptr;
       const int NS = d.NF + 1;
       for (int b = 0; b < d.B; ++b)
         for (int t = 0; t < d.T; ++t)
           for (int k = 0; k < d.NF; ++k) {
             const int64_t e = (((int64_t)b * d.T + t) * NS + k + 1) * 2, o = ((int64_t)b * d.NF + k) * d.T + t;
+            if (op.kind == OP_SPECOUT_FWD && d.mode == 2) { orr[o] = est[((int64_t)b * d.T + t) * d.NF + k]; continue; }
+            if (op.kind == OP_SPECOUT_FWD && d.mode == 1) { orr[o] = std::sqrt(est[e] * est[e] + est[e + 1] * est[e + 1]); continue; }
             if (op.kind == OP_SPECOUT_FWD) { orr[o] = est[e]; oi[o] = est[e + 1]; }
             else if (d.accumulate) { est[e] += orr[o]; est[e + 1] += oi[o]; }
             else { est[e] = orr[o]; est[e + 1] = oi[o]; }
           }
+      break;
+    }
+    case OP_MAGS: {
+      const Mags& d = op.mags;
+      const float* spec = (const float*)rp(ab, d.spec);
+      const int NS = d.NF + 1;
+      for (int64_t f = 0; f < d.frames; ++f)
+        for (int j = 0; j < d.MS; ++j) {
+          const int k = j - d.MO;
+          float v = 0.f;
+          if (k >= 0 && k < d.NF) { const float sr = spec[(f * NS + k + 1) * 2], si = spec[(f * NS + k + 1) * 2 + 1]; v = std::sqrt(sr * sr + si * si); }
+          st(rp(ab, d.mags), d.dt, f * d.MS + j, v);
+        }
       break;
     }
     case OP_MEMSET: std::memset(rp(ab, op.ms.dst), 0, op.ms.bytes); break;

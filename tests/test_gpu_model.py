@@ -159,3 +159,47 @@ def test_cpu_tensor_is_rejected_not_silently_computed():
     m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4000))
+
+
+# ------------------------------------------------------------------------------------------------ CRN (models.py:329-565)
+@pytest.mark.parametrize("name,kn,ru,ri,loss", [("default_E_mse", (32, 64, 128, 256, 256, 256), 256, 512, "MSE"),
+                                               ("small_E_sisnr", (16, 32, 32, 64, 64, 64), 128, 128, "SI-SNR")])
+def test_crn_module_step_against_reference_golden(name, kn, ru, ri, loss):
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    g = load_golden("crn_" + name)
+    B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
+    cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.perceptual, cfg.skip_type, cfg.act_dtype = list(kn), "E", loss, False, True, "fp32"
+    m = models.CRN(rnn_units=ru, rnn_input_size=ri, masking_mode="E")
+    fill_state_dict_(m)
+    m = m.to("cuda").train()
+    x, y = make_signals(B, L)
+    x, y = x.cuda(), y.cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    P0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    est_mags, target_mags, wav = m(x, y)
+    lossv = m.loss(wav, y)
+    opt.zero_grad()
+    lossv.backward()
+    assert rel_err(est_mags, g["g/est_mags"]) < TOL
+    assert rel_err(target_mags, g["g/target_mags"]) < TOL
+    assert rel_err(wav, g["g/out_wav"]) < TOL
+    assert abs(float(lossv) - float(g["g/loss"])) < TOL * max(1.0, abs(float(g["g/loss"])))
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    gn = sub(g, "g/grad_norm")
+    for k, v in gn.items():
+        if not noise_bias(k):
+            assert abs(float(grads[k].double().norm()) - float(v)) <= TOL * float(v) + 1e-7, k
+    for k, v in sub(g, "g/grad").items():
+        if noise_bias(k):
+            continue
+        assert rel_l2(grads[k], v) < (5e-3 if k.endswith(".2.weight") else TOL) and rel_err(grads[k], v) < 5e-3, k
+    opt.step()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for k, v in sub(g, "g/running").items():
+        assert rel_err(sd[k], v) < TOL, k
+    for k, v in sub(g, "g/after_adam").items():
+        if not noise_bias(k):
+            assert np.abs((sd[k].numpy() - P0[k].numpy()) - (v - P0[k].numpy())).max() < 5e-5, k
+    with pytest.raises(AttributeError):
+        m(x)                      # the reference crashes without targets too (models.py:505)

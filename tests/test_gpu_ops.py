@@ -30,22 +30,29 @@ def _typed(t_u8, dt):
     return t_u8.view(torch.bfloat16 if dt == 1 else torch.float32)
 
 
-@pytest.mark.parametrize("B,L,mode,kn,ru,dtype", [(3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
-                                                  (1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "fp32"),
-                                                  (3, 4000, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),
-                                                  (1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16")])
-def test_every_op_against_host_simulator(B, L, mode, kn, ru, dtype):
+@pytest.mark.parametrize("model,B,L,mode,kn,ru,dtype", [("DCCRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
+                                                        ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "fp32"),
+                                                        ("DCCRN", 3, 4000, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),
+                                                        ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
+                                                        ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
+                                                        ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16")])
+def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     """Tolerances: fp32 buffers 1e-3 (observed <= 3e-6); bf16 buffers 1.6e-2 = two bf16 ulps of the largest element
     (simulator and kernel round slightly different fp32 accumulations of the SAME bf16 operands)."""
     from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, sim_run
-    cfg = DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)
-    P = formula_state_dict(dccrn_state_shapes(cfg))
-    plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype)
+    if model == "CRN":
+        from oracle.crn import CRNConfig, crn_state_shapes
+        P = formula_state_dict(crn_state_shapes(CRNConfig(kernel_num=kn, rnn_units=ru, rnn_input_size=4 * (kn[-1] // 2))))
+    else:
+        P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)))
+    plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
     dev = plan.alloc_arenas("cuda")
     host = plan.alloc_arenas("cpu")
     fill_params(plan, dev, P)
     x, y = make_signals(B, L)
     plan.io(dev, "wav", (B, L)).copy_(x)
+    if model == "CRN":
+        plan.io(dev, "tgt", (B, L)).copy_(y)
     torch.manual_seed(1)
     plan.io(dev, "grad_wav", (B, L)).copy_(torch.randn(B, L) * 1e-3)
     plan.io(dev, "grad_real", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
@@ -95,7 +102,7 @@ def test_every_op_against_host_simulator(B, L, mode, kn, ru, dtype):
                          f"err/tol {worst:.3e} stray {stray} {where}")
             if not (worst < 1.0) or stray:
                 bad.append(lines[-1])
-    with open(_report_path(f"ops_report_B{B}_{mode}_{dtype}.txt"), "w") as f:
+    with open(_report_path(f"ops_report_{model}_B{B}_{mode}_{dtype}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])
 

@@ -118,3 +118,52 @@ def test_plan_constants_match_reference_kernels():
     assert rel_err(spec_to_ref(plan.view(ar, "spec"), B, plan.T, plan.NF), conv_stft(x)) < 1e-5
     K = synthesis_kernel()
     assert np.abs(K).max() > 0 and ola_normaliser(plan.T)[300:-300].min() > 1.49
+
+
+# ------------------------------------------------------------------------------------------------ CRN
+def test_crn_hostsim_forward_backward_vs_oracle():
+    from oracle.crn import CRNConfig, crn_forward, crn_state_shapes
+    B, L = 2, 4000
+    kn = (16, 32, 32, 64, 64, 64)
+    cfg = CRNConfig(kernel_num=kn, rnn_units=128, rnn_input_size=128)
+    P = formula_state_dict(crn_state_shapes(cfg))
+    plan = Plan(B, L, kernel_num=kn, rnn_units=128, model="CRN")
+    want = [(k, tuple(v)) for k, v in crn_state_shapes(cfg).items() if is_trainable(k)]
+    assert [(k, shp) for k, (off, shp) in plan.params.items()] == want
+    T, NF = plan.T, plan.NF
+    ar = plan.alloc_arenas("cpu")
+    fill_params(plan, ar, P)
+    x, y = make_signals(B, L)
+    plan.io(ar, "wav", (B, L)).copy_(x)
+    plan.io(ar, "tgt", (B, L)).copy_(y)
+    sim_run(plan, PHASE_FWD, ar)
+    Pg = {k: (v.clone().requires_grad_(True) if is_trainable(k) else v.clone()) for k, v in P.items()}
+    taps = {}
+    (est_mags, tmags, wav), new_stats = crn_forward(Pg, x, y, cfg, train=True, taps=taps)
+    ch = (1,) + tuple(k // 2 for k in kn)
+    F = [256 >> i for i in range(7)]
+    for i in range(6):
+        got = act_to_nchw(plan.view(ar, f"enc{i}.y"), B, T, F[i + 1], ch[i + 1])
+        assert rel_err(got, taps[f"enc{i}.conv"]) < 2e-5, f"enc{i}.conv"
+    for d in range(6):
+        idx = 6 - d
+        got = act_to_nchw(plan.view(ar, f"dec{d}.y"), B, T + 1, 2 * F[idx], ch[idx - 1])
+        assert rel_err(got, taps[f"dec{d}.conv"]) < 5e-5, f"dec{d}.conv"
+    assert rel_err(plan.io(ar, "out_wav", (B, L)), wav) < 5e-5
+    assert rel_err(plan.io(ar, "out_real", (B, NF, T)), est_mags) < 5e-5
+    assert rel_err(plan.io(ar, "out_imag", (B, NF, T)), tmags) < 5e-5
+    got_state = read_params(plan, ar, ARENA_STATE, plan.state)
+    for k, v in new_stats.items():
+        assert rel_err(got_state[k], v) < 1e-5, k
+    lossv = main_loss("SI-SNR", wav, y)
+    names = [k for k in Pg if is_trainable(k)]
+    grads = dict(zip(names, torch.autograd.grad(lossv, [Pg[k] for k in names], retain_graph=True)))
+    gw = torch.autograd.grad(lossv, wav)[0]
+    plan.io(ar, "grad_wav", (B, L)).copy_(gw)
+    sim_run(plan, PHASE_BWD, ar)
+    got = read_params(plan, ar, ARENA_GRAD)
+    for k in names:
+        if k.endswith("conv.bias") and not k.startswith("decoder.5."):
+            assert got[k].abs().max() < 1e-4 * grads[k.replace(".bias", ".weight")].abs().max() + 1e-7, k
+            continue
+        assert rel_err(got[k], grads[k]) < (2e-3 if k.endswith(".2.weight") else 2e-4), k
