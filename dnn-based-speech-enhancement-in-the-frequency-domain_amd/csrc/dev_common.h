@@ -51,6 +51,13 @@ __device__ __forceinline__ void st4(char* base, int dt, int64_t i, float4 v) {
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (s_waitcnt vmcnt(0)); in the per-time-step loops of the LSTM kernels that would expose the full HBM write latency
+// of the saved activations on every one of the 483 steps.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

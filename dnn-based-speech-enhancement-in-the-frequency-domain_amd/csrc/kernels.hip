@@ -353,7 +353,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_kernel(const LstmRec d, con
         cs[row * H + unit] = c[r];
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
       float* lrow = lds + (4 * kq + r) * gs;
       lrow[unit] = di; lrow[H + unit] = df; lrow[2 * H + unit] = dg; lrow[3 * H + unit] = dog;
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
 #pragma unroll
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
 #pragma unroll
       for (int q = 0; q < 4; ++q) pg[r][q] = ng[r][q];
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 

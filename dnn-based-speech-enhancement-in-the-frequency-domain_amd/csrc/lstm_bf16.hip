@@ -97,7 +97,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
         cs[row * H + unit] = c[r];
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
       uint16_t* lrow = ldsh + (4 * kq + r) * gs;
       lrow[unit] = f2bf(di); lrow[H + unit] = f2bf(df); lrow[2 * H + unit] = f2bf(dg); lrow[3 * H + unit] = f2bf(dog);
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
 #pragma unroll
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
 #pragma unroll
       for (int q = 0; q < 4; ++q) pg[r][q] = ng[r][q];
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 

@@ -214,6 +214,29 @@ struct Builder {
 
 int32_t pe(const ParamInfo& p, int64_t idx, int sign = 1) { return (int32_t)(sign * (p.off + idx + 1)); }
 
+// Post-pass over a finished plan: give every RUNGEMM the zero page and mark the ones whose runs are whole, 16-byte aligned
+// chunks (then the kernel uses the LDS-DMA loader).  Arena buffers are 256-byte aligned, so only element offsets matter.
+void finalize_rungemms(Builder& b, Plan* P) {
+  static const char zeros[256] = {0};
+  Ptr z = b.cst(zeros, sizeof(zeros));
+  for (auto* ops : {&P->fwd, &P->bwd})
+    for (Op& op : *ops) {
+      if (op.kind != OP_RUNGEMM) continue;
+      RunGemm& g = op.g;
+      g.zero = z;
+      const int vec = 16 / esize(g.xdt);
+      bool ok = true;
+      for (int s = 0; s < g.nseg && ok; ++s) {
+        const Seg& sg = g.seg[s];
+        if (sg.src < 0) { ok = false; break; }
+        const int q = sg.src;
+        ok = sg.off % vec == 0 && sg.len % vec == 0 && g.fstride[q] % vec == 0 && g.base[q] % vec == 0 && g.rowlen[q] % vec == 0 &&
+             g.tstride[q] % vec == 0 && g.bstride[q] % vec == 0 && (g.x[q].off % 16) == 0;
+      }
+      g.flags = ok ? kRunAligned : 0;
+    }
+}
+
 }  // namespace
 
 // =================================================================================================================
@@ -879,6 +902,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     b.finish_unpack(R);
   }
 
+  finalize_rungemms(b, P);
   P->arena_bytes[A_WS] = b.ws_off;
   P->arena_bytes[A_PARAM] = nparam * 4;
   P->arena_bytes[A_GRAD] = nparam * 4;
@@ -1410,6 +1434,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
     }
     b.finish_unpack(R);
   }
+  finalize_rungemms(b, P);
   P->arena_bytes[A_WS] = b.ws_off;
   P->arena_bytes[A_PARAM] = nparam * 4;
   P->arena_bytes[A_GRAD] = nparam * 4;

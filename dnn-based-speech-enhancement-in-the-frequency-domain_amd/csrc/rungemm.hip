@@ -85,7 +85,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <typename TA, int BN>
+// GLDS = true: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass,
+// which otherwise costs more LDS cycles than the fragment reads); padding chunks are fetched from a zero page, and the
+// XOR swizzle is applied on the SOURCE chunk index because the DMA destination is lane-linear (wave base + lane*16).
+template <typename TA, int BN, bool GLDS>
 __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int VEC = 16 / sizeof(TA);
   constexpr int BK = 8 * VEC;
@@ -127,9 +130,10 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
     rb0[p] = (int64_t)b * d.bstride[0] + d.base[0];
     rb1[p] = (int64_t)b * d.bstride[1] + d.base[1];
   }
+  const int csrc = GLDS ? (c ^ ((r0 >> 1) & 7)) : c;       // chunk of the K-tile this thread fetches
   const TA* wrow[BPASS];
 #pragma unroll
-  for (int p = 0; p < BPASS; ++p) wrow[p] = w + (int64_t)(ntile * BN + r0 + 32 * p) * d.ldw + c * VEC;
+  for (int p = 0; p < BPASS; ++p) wrow[p] = w + (int64_t)(ntile * BN + r0 + 32 * p) * d.ldw + csrc * VEC;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -202,9 +206,6 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) bReg[p] = *reinterpret_cast<const uint4*>(wrow[p] + wseg + kk);
   };
-  enter_run(0);
-  issue_loads(0);
-
   // LDS offsets: the swizzle term ((row >> 1) & 7) is the same for all of a thread's rows (row strides are multiples of 16)
   int woff[4];
 #pragma unroll
@@ -215,20 +216,7 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   for (int kc = 0; kc < 4; ++kc) chs[kc] = ((2 * kc + (lane >> 5)) ^ rsw) * 16;
   const int arow = (wm0 + (lane & 31)) * 128, brow = (wn0 + (lane & 31)) * 128;
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    char* As = smem + (kt & 1) * TILE_BYTES;
-    char* Bs = As + BM * 128;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(As + woff[p]) = aReg[p];
-#pragma unroll
-    for (int p = 0; p < BPASS; ++p) *reinterpret_cast<uint4*>(Bs + woff[p]) = bReg[p];
-    __syncthreads();
-    // advance (run, k0) and prefetch the next tile into registers while this one is consumed from LDS
-    k0 += BK;
-    if (kt + 1 < ntiles) {
-      if (k0 >= seglen) { k0 = 0; ++seg; enter_run(seg); }
-      issue_loads(k0);
-    }
+  auto compute = [&](const char* As, const char* Bs) {
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       uint4 af[MI], bf[NI];
@@ -240,6 +228,56 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) mfma_step<TA>(acc[i][j], af[i], bf[j]);
+    }
+  };
+
+  enter_run(0);
+  if constexpr (GLDS) {
+    const TA* zp = reinterpret_cast<const TA*>(rp(ab, d.zero));
+    const int wbase = __builtin_amdgcn_readfirstlane(wid) * 1024;        // this wave's 8 rows x 128 B inside each 32-row pass
+    auto dma = [&](char* As, char* Bs, int kk) {
+      const int j0 = kk + csrc * VEC;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const TA* src = (j0 >= jlo[p] && j0 + VEC <= jhi[p]) ? rptr[p] + j0 : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + wbase + p * 4096), 16, 0, 0);
+      }
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[p] + wseg + kk),
+                                         (__attribute__((address_space(3))) void*)(Bs + wbase + p * 4096), 16, 0, 0);
+    };
+    dma(smem, smem + BM * 128, 0);
+    __syncthreads();                                   // waits for the DMA (vmcnt(0)) and publishes the tile
+    for (int kt = 0; kt < ntiles; ++kt) {
+      char* As = smem + (kt & 1) * TILE_BYTES;
+      char* An = smem + ((kt + 1) & 1) * TILE_BYTES;
+      k0 += BK;
+      if (kt + 1 < ntiles) {
+        if (k0 >= seglen) { k0 = 0; ++seg; enter_run(seg); }
+        dma(An, An + BM * 128, k0);                    // lands while this tile is multiplied; its buffer was last read in kt-1
+      }
+      compute(As, As + BM * 128);
+      __syncthreads();
+    }
+  } else {
+    issue_loads(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+      char* As = smem + (kt & 1) * TILE_BYTES;
+      char* Bs = As + BM * 128;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(As + woff[p]) = aReg[p];
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) *reinterpret_cast<uint4*>(Bs + woff[p]) = bReg[p];
+      __syncthreads();
+      // advance (run, k0) and prefetch the next tile into registers while this one is consumed from LDS
+      k0 += BK;
+      if (kt + 1 < ntiles) {
+        if (k0 >= seglen) { k0 = 0; ++seg; enter_run(seg); }
+        issue_loads(k0);
+      }
+      compute(As, Bs);
     }
   }
   __syncthreads();
@@ -306,6 +344,25 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   }
 }
 
+// WGRAD workgroup order: all (n, k) tiles of one row split read the SAME activation / gradient rows, so they are placed on
+// ONE XCD (private L2) back to back; the 8 XCDs work on 8 different splits.  Linear id L -> xcd = L % 8 (dispatch order).
+__device__ __forceinline__ void wgrad_block(int gx, int gy, int nsplit, int& ntile, int& ktile, int& split) {
+  const int tiles = gx * gy;
+  const int L = blockIdx.x;
+  const int full = (nsplit / 8) * 8;                       // splits that can be grouped 8 at a time
+  if (L < full * tiles) {
+    const int xcd = L & 7, idx = L >> 3;
+    split = (idx / tiles) * 8 + xcd;
+    const int t = idx - (idx / tiles) * tiles;
+    ntile = t % gx; ktile = t / gx;
+  } else {                                                 // remainder splits: plain order
+    const int r = L - full * tiles;
+    split = full + r / tiles;
+    const int t = r % tiles;
+    ntile = t % gx; ktile = t / gx;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // WGRAD (fp32 MFMA):  part[split][n][k] = sum_{rows m of the split} dy[m][n] * A[m][k]
 // MFMA view: "A operand" = dy^T (i = n, kk = m), "B operand" = gathered activations (kk = m, j = k).
@@ -320,7 +377,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const RunGemm d, const Arena
   __shared__ __attribute__((aligned(16))) float as[2][RS][TK + 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int ntile = blockIdx.x, ktile = blockIdx.y, split = blockIdx.z;
+  int ntile, ktile, split;
+  wgrad_block((d.Npad + TN - 1) / TN, (d.ldw + TK - 1) / TK, d.nsplit, ntile, ktile, split);
   const float* x0 = reinterpret_cast<const float*>(rp(ab, d.x[0]));
   const float* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.x[1])) : x0;
   const float* dy = reinterpret_cast<const float*>(rp(ab, d.y));
@@ -440,7 +498,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const RunGemm d, const 
   __shared__ __attribute__((aligned(16))) uint16_t as[2][RS][PK];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int ntile = blockIdx.x, ktile = blockIdx.y, split = blockIdx.z;
+  int ntile, ktile, split;
+  wgrad_block((d.Npad + TN - 1) / TN, (d.ldw + TK - 1) / TK, d.nsplit, ntile, ktile, split);
   const bf16_t* x0 = reinterpret_cast<const bf16_t*>(rp(ab, d.x[0]));
   const bf16_t* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const bf16_t*>(rp(ab, d.x[1])) : x0;
   const uint16_t* dy = reinterpret_cast<const uint16_t*>(rp(ab, d.y));
@@ -574,9 +633,15 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
   const int bn = bn_of(d.N);
   const int nm = (d.M + kBM - 1) / kBM;
   const int grid = nm * (d.Npad / bn);
-  if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128>), dim3(grid), dim3(256), 0, st, d, ab);
-  else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64>), dim3(grid), dim3(256), 0, st, d, ab);
-  else hipLaunchKernelGGL((rungemm_kernel<TA, 32>), dim3(grid), dim3(256), 0, st, d, ab);
+  if (d.flags & kRunAligned) {
+    if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    else hipLaunchKernelGGL((rungemm_kernel<TA, 32, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    return;
+  }
+  if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128, false>), dim3(grid), dim3(256), 0, st, d, ab);
+  else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64, false>), dim3(grid), dim3(256), 0, st, d, ab);
+  else hipLaunchKernelGGL((rungemm_kernel<TA, 32, false>), dim3(grid), dim3(256), 0, st, d, ab);
 }
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
@@ -587,15 +652,15 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (d.xdt == DT_BF16) {
     if (d.Npad >= 128) {
-      dim3 grid((d.Npad + 127) / 128, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
+      dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
       hipLaunchKernelGGL((wgrad_bf16_kernel<128>), grid, dim3(256), 0, st, d, ab);
     } else {
-      dim3 grid((d.Npad + 63) / 64, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
+      dim3 grid(((d.Npad + 63) / 64) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
       hipLaunchKernelGGL((wgrad_bf16_kernel<64>), grid, dim3(256), 0, st, d, ab);
     }
     return;
   }
-  dim3 grid((d.Npad + kWgTN - 1) / kWgTN, (d.ldw + kWgTK - 1) / kWgTK, d.nsplit);
+  dim3 grid(((d.Npad + kWgTN - 1) / kWgTN) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
   hipLaunchKernelGGL((wgrad_kernel<float>), grid, dim3(256), 0, st, d, ab);
 }
 

@@ -60,8 +60,10 @@ struct RunGemm {
   int32_t y_tstride, y_fstride, y_off;   // y index = b*y_bstride + u*y_tstride + fo*y_fstride + y_off + n
   Ptr stats;               // A_NONE or fp32 partial sums [gridM][2][Npad] (sum, sum of squares of the stored value)
   int32_t nsplit;          // WGRAD only: number of row splits
-  int32_t relu_;           // unused, keeps the struct 8-byte aligned
+  int32_t flags;           // bit 0: every run is 16-byte aligned and a whole number of 16-byte chunks -> LDS-DMA loader
+  Ptr zero;                // >= 16 zero bytes (A_CONST): source of padding chunks for the LDS-DMA loader
 };
+constexpr int kRunAligned = 1;
 
 // PACK: dst[i] = sum_{e < width} sign(tab[i*width+e]) * src[|tab[i*width+e]|-1]   (entry 0 -> nothing).  Table int32 in A_CONST.
 // width 1: packed conv / LSTM weights ; width 2: combined biases (b_r - b_i | b_r + b_i), (b_ih + b_hh).

@@ -81,6 +81,18 @@ int32_t sefd_loss_forward(int kind, const float* est, const float* tgt, int32_t 
 int32_t sefd_loss_backward(int kind, const float* est, const float* tgt, int32_t B, int32_t L, const float* ws,
                            const float* grad_scale, float* grad_est, void* stream);
 
+/* ---- LMS log-mel perceptual loss (tools_for_loss.py:120-249 + the magnitude step of models.py:306-312) ------------
+ * clean_* / est_*: fp32 [B][NF][T] device (reference layout).  If the *_i pointers are NULL the *_r arrays are magnitudes
+ * already (get_array_lms_loss(clean_mags, est_mags) signature); otherwise mag = sqrt(r^2 + i^2 + 1e-7) is fused in.
+ * bands: int32 [nbands][4] = {first bin, taps, weight offset, scale index}; weights: the triangle taps (melFilterBank);
+ * scale_sizes_host: HOST int32[nscales] = filters per scale (16, 32, 64).  rowloss_ws: fp32 [B*T] device scratch. */
+int32_t sefd_lms_forward(const float* clean_r, const float* clean_i, const float* est_r, const float* est_i, int32_t B, int32_t NF, int32_t T,
+                         const int32_t* bands, const float* weights, int32_t nbands, const int32_t* scale_sizes_host, int32_t nscales,
+                         int32_t nfft, float* rowloss_ws, float* loss_out, void* stream);
+int32_t sefd_lms_backward(const float* clean_r, const float* clean_i, const float* est_r, const float* est_i, int32_t B, int32_t NF, int32_t T,
+                          const int32_t* bands, const float* weights, int32_t nbands, const int32_t* scale_sizes_host, int32_t nscales,
+                          int32_t nfft, const float* grad_scale, float* grad_est_r, float* grad_est_i, void* stream);
+
 /* ---- Adam (torch.optim.Adam defaults, train_interface.py:59) on flat fp32 buffers ------------------
  * step is 1-based. */
 int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,

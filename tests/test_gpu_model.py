@@ -113,8 +113,9 @@ def test_fused_train_step_matches_oracle_two_steps():
         for k in r["new_stats"]:
             if step > 1 and k.endswith("running_mean"):
                 # the conv bias in front of a BatchNorm random-walks by +-lr per step on the sign of a rounding-noise
-                # gradient (same in the reference); it shifts the batch mean by up to 2*lr, the running mean by 0.1 of that
-                assert float((sd[k] - P[k]).abs().max()) < 3e-4, (step, k)
+                # gradient (same in the reference).  The complex conv's effective bias is b_r -+ b_i, so it can differ by up to
+                # 4*lr from the oracle's, the batch mean with it, and the running mean by 0.1 of that (4e-4)
+                assert float((sd[k] - P[k]).abs().max()) < 8e-4, (step, k)
             else:
                 assert rel_err(sd[k], P[k]) < TOL, (step, k)
         # Adam's step is lr * m/(sqrt(v)+eps) ~ lr * sign(g) on the first steps: compare the parameters where the oracle
