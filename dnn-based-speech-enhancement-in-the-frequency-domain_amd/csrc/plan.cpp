@@ -1444,6 +1444,59 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   return P;
 }
 
-Plan* build_plan(const ModelConfig& cfg) { return cfg.model == 1 ? build_crn_plan(cfg) : build_dccrn_plan(cfg); }
+// =================================================================================================================
+// Front end only (model 2): ConvSTFT 'complex' of io.wav in the reference layout -> io.out_real / io.out_imag [B][NF][T].
+// Used by DCCRN.loss for the clean spectrum of the LMS loss (models.py:306-309).
+Plan* build_frontend_plan(const ModelConfig& cfg) {
+  Plan* P = new Plan();
+  P->cfg = cfg;
+  Builder b;
+  b.P = P;
+  b.c = cfg;
+  const int B = cfg.B, L = cfg.L, W = cfg.win_len, hop = cfg.hop, NFFT = cfg.fft_len;
+  const int trim = W - hop;
+  const int T = (L + 2 * trim - W) / hop + 1;
+  const int NF = NFFT / 2 + 1, NS = NF + 1, SW = NS * 2;
+  P->T = T;
+  P->NF = NF;
+  Ptr io_wav = b.io("wav", (int64_t)B * L);
+  Ptr io_or = b.io("out_real", (int64_t)B * NF * T);
+  Ptr io_oi = b.io("out_imag", (int64_t)B * NF * T);
+  std::vector<double> win(W);
+  for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
+  RunGemm g = Builder::gemm0();
+  g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
+  g.bstride[0] = L; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
+  g.M = B * T; g.Tout = 1; g.Fo = T;
+  g.nseg = 1; g.seg[0] = Seg{0, 0, -trim, W, 0};
+  g.N = SW;
+  Builder::layout_segs(g);
+  {
+    std::vector<float> wt((size_t)g.Npad * g.ldw, 0.f);
+    for (int nn = 2; nn < g.N; ++nn)
+      for (int j = 0; j < W; ++j) {
+        const double ang = 2.0 * kPi * (double)(((int64_t)(nn / 2 - 1) * j) % NFFT) / NFFT;
+        wt[(size_t)nn * g.ldw + j] = (float)(((nn & 1) == 0 ? std::cos(ang) : -std::sin(ang)) * win[j]);
+      }
+    g.w = b.cst(wt.data(), (int64_t)wt.size() * 4);
+  }
+  g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+  b.push(P->fwd, OP_RUNGEMM, 1).g = g;
+  SpecOut so;
+  std::memset(&so, 0, sizeof(so));
+  so.est = spec; so.out_real = io_or; so.out_imag = io_oi; so.B = B; so.T = T; so.NF = NF;
+  b.push(P->fwd, OP_SPECOUT_FWD, 2).so = so;
+  finalize_rungemms(b, P);
+  P->arena_bytes[A_WS] = b.ws_off;
+  P->arena_bytes[A_PARAM] = 4; P->arena_bytes[A_GRAD] = 4; P->arena_bytes[A_STATE] = 4;
+  P->arena_bytes[A_CONST] = (int64_t)P->consts.size();
+  P->arena_bytes[A_IO] = b.io_off;
+  return P;
+}
+
+Plan* build_plan(const ModelConfig& cfg) {
+  return cfg.model == 2 ? build_frontend_plan(cfg) : (cfg.model == 1 ? build_crn_plan(cfg) : build_dccrn_plan(cfg));
+}
 
 }  // namespace sefd

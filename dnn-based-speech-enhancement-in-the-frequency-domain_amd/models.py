@@ -333,9 +333,25 @@ class DCCRN(_SefdModule):
         """models.py:303-323."""
         if perceptual:
             if cfg.perceptual == 'LMS':
-                raise NotImplementedError("LMS perceptual loss: not on the HIP path yet")
+                clean_real, clean_imag = self._stft_ref(target)          # self.stft(target), models.py:306-308
+                return tfl.lms_from_spectra(clean_real, clean_imag, real_spec, img_spec)
             raise NotImplementedError("PMSQE is third-party (asteroid) arithmetic: parity unpinned, not built")
         return self._main_loss(estimated, target)
+
+    def _stft_ref(self, wav):
+        """ConvSTFT 'complex' of a waveform batch in the reference layout: ([B,257,T] real, [B,257,T] imag), no grad."""
+        wav = wav.detach().float().contiguous()
+        B, L = wav.shape
+        key = ("stft", B, L, str(wav.device))
+        fe = self._runtimes.get(key)
+        if fe is None:
+            plan = Plan(B, L, win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, model="STFT")
+            fe = (plan, plan.alloc_arenas(wav.device))
+            self._runtimes[key] = fe
+        plan, ar = fe
+        plan.io(ar, "wav", (B, L)).copy_(wav)
+        plan.run(PHASE_FWD, ar, torch.cuda.current_stream().cuda_stream)
+        return plan.io(ar, "out_real", (B, plan.NF, plan.T)).clone(), plan.io(ar, "out_imag", (B, plan.NF, plan.T)).clone()
 
 
 class RealConv2d(nn.Module):

@@ -21,7 +21,7 @@ class Plan:
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
         cfg = _lib.ModelConfig()
-        cfg.model = {"DCCRN": 0, "CRN": 1}[model]
+        cfg.model = {"DCCRN": 0, "CRN": 1, "STFT": 2}[model]
         cfg.B, cfg.L = int(B), int(L)
         cfg.win_len, cfg.hop, cfg.fft_len = win_len, win_inc, fft_len
         cfg.n_layers = len(kernel_num)
@@ -47,7 +47,7 @@ class Plan:
         self.arena_bytes = [self.lib.sefd_plan_arena_bytes(self.h, a) for a in range(ARENA_COUNT)]
         self.params = self._param_table(0)
         self.state = self._param_table(1)
-        self.n_param = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.params.values())
+        self.n_param = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.params.values()) if self.params else 0
         self.n_state = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.state.values())
 
     def _param_table(self, kind):

@@ -5,10 +5,13 @@ backward - one elementwise kernel `grad = ca[b]*est + cb[b]*target`.  Same call 
 reference (`sdr(s1, s2)`, `si_snr(s1, s2)`, `si_sdr(reference, estimation)`); cuda fp32 tensors only.
 """
 import ctypes as C
+import math
 
+import numpy as np
 import torch
 
 from . import _lib
+from . import config as cfg
 
 LOSS_KINDS = {"MSE": 0, "SDR": 1, "SI-SNR": 2, "SI-SDR": 3}
 
@@ -77,3 +80,102 @@ def si_snr(s1, s2, eps=1e-8):
 def si_sdr(reference, estimation, eps=1e-8):
     """tools_for_loss.py:47-94."""
     return -_Loss.apply(3, estimation, reference)
+
+
+# ------------------------------------------------------------------------------------------ LMS (tools_for_loss.py:120-249)
+MEL_SCALES = [16, 32, 64]        # cfg.perceptual == 'LMS' (tools_for_loss.py:114-115)
+
+
+def freqToMel(freq):
+    return 1127.01048 * math.log(1 + freq / 700.0)
+
+
+def melToFreq(mel):
+    return 700 * (math.exp(mel / 1127.01048) - 1)
+
+
+def melFilterBank(numCoeffs, fftSize=None):
+    """Host-side constant, same construction as the reference (float32 centre array, floor-binned edges; :140-184)."""
+    maxHz = cfg.fs / 2
+    numFFTBins = cfg.win_len if fftSize is None else int(fftSize / 2) + 1
+    maxMel, minMel = freqToMel(maxHz), freqToMel(0)
+    centers = np.array(range(numCoeffs + 2)).astype(np.float32) * (maxMel - minMel) / (numCoeffs + 1) + minMel
+    for i in range(numCoeffs + 2):
+        centers[i] = melToFreq(centers[i])
+        centers[i] = math.floor(numFFTBins * centers[i] / maxHz)
+    mat = np.zeros((numCoeffs, numFFTBins))
+    for i in range(1, numCoeffs + 1):
+        s, m, e = int(centers[i - 1]), int(centers[i]), int(centers[i + 1])
+        for j in range(s, m):
+            mat[i - 1][j] = (float(j) - s) / (m - s)
+        for j in range(m, e):
+            mat[i - 1][j] = 1 - ((float(j) - m) / (e - m))
+    return mat
+
+
+_BANK_CACHE = {}
+
+
+def _banks(device, nfft):
+    """Sparse (start, taps, offset, scale) table + tap weights of the three mel banks on `device`."""
+    key = (str(device), nfft)
+    if key not in _BANK_CACHE:
+        bands, weights = [], []
+        for si, nb in enumerate(MEL_SCALES):
+            fb = melFilterBank(nb, nfft).astype(np.float32)          # [nb, NF]
+            for n in range(nb):
+                nz = np.nonzero(fb[n])[0]
+                st, ln = (int(nz[0]), int(nz[-1] - nz[0] + 1)) if len(nz) else (0, 0)
+                bands.append([st, ln, len(weights), si])
+                weights.extend(fb[n, st:st + ln].tolist())
+        _BANK_CACHE[key] = (torch.tensor(bands, dtype=torch.int32, device=device).contiguous(),
+                            torch.tensor(weights or [0.0], dtype=torch.float32, device=device), len(bands),
+                            (C.c_int32 * len(MEL_SCALES))(*MEL_SCALES))
+    return _BANK_CACHE[key]
+
+
+class _LMS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clean_r, clean_i, est_r, est_i):
+        if not est_r.is_cuda:
+            raise RuntimeError("sefd LMS loss runs on the MI355X only (cuda tensors); there is no CPU fallback")
+        L_ = _lib.lib()
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        clean_r, clean_i, er, ei = f(clean_r), f(clean_i), f(est_r), f(est_i)
+        B, NF, T = er.shape
+        nfft = cfg.fft_len
+        bands, weights, nbands, sizes = _banks(er.device, nfft)
+        ws = torch.empty(B * T, dtype=torch.float32, device=er.device)
+        out = torch.empty((), dtype=torch.float32, device=er.device)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = L_.sefd_lms_forward(_vp(clean_r), _vp(clean_i), _vp(er), _vp(ei), B, NF, T, _vp(bands), _vp(weights), nbands, sizes,
+                                 len(MEL_SCALES), nfft, _vp(ws), _vp(out), stream)
+        if rc != 0:
+            raise RuntimeError(f"sefd_lms_forward failed ({rc})")
+        ctx.t = (clean_r, clean_i, er, ei)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L_ = _lib.lib()
+        clean_r, clean_i, er, ei = ctx.t
+        B, NF, T = er.shape
+        bands, weights, nbands, sizes = _banks(er.device, cfg.fft_len)
+        gr = torch.empty_like(er)
+        gi = torch.empty_like(er) if ei is not None else None
+        gs = g.float().contiguous().view(1)
+        rc = L_.sefd_lms_backward(_vp(clean_r), _vp(clean_i), _vp(er), _vp(ei), B, NF, T, _vp(bands), _vp(weights), nbands, sizes,
+                                  len(MEL_SCALES), cfg.fft_len, _vp(gs), _vp(gr), _vp(gi), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sefd_lms_backward failed ({rc})")
+        return None, None, gr, gi
+
+
+def get_array_lms_loss(clean_array, est_array):
+    """tools_for_loss.py:242-249: magnitudes [B, 257, T] in, scalar out (flat re-view quirk Q8 reproduced)."""
+    return _LMS.apply(clean_array, None, est_array, None)
+
+
+def lms_from_spectra(clean_real, clean_imag, est_real, est_imag):
+    """models.py:306-312 fused: mags = sqrt(re^2 + im^2 + 1e-7) on both sides, then get_array_lms_loss."""
+    return _LMS.apply(clean_real, clean_imag, est_real, est_imag)

@@ -204,3 +204,62 @@ def test_crn_module_step_against_reference_golden(name, kn, ru, ri, loss):
             assert np.abs((sd[k].numpy() - P0[k].numpy()) - (v - P0[k].numpy())).max() < 5e-5, k
     with pytest.raises(AttributeError):
         m(x)                      # the reference crashes without targets too (models.py:505)
+
+
+# ------------------------------------------------------------------------------------------------ LMS (tools_for_loss.py:120-249)
+def test_lms_loss_kernel_vs_oracle():
+    import sefd_amd  # noqa: F401
+    from sefd_amd import tools_for_loss as tfl
+    from oracle import losses as ol
+    torch.manual_seed(5)
+    B, NF, T = 3, 257, 43
+    cr, ci, er, ei = [torch.randn(B, NF, T) * 3 for _ in range(4)]
+    er_, ei_ = er.clone().requires_grad_(True), ei.clone().requires_grad_(True)
+    cm = torch.sqrt(cr ** 2 + ci ** 2 + 1e-7)
+    em = torch.sqrt(er_ ** 2 + ei_ ** 2 + 1e-7)
+    ref = ol.lms_loss(cm, em)
+    ref.backward()
+    d = lambda t: t.cuda()
+    erd, eid = d(er).requires_grad_(True), d(ei).requires_grad_(True)
+    out = tfl.lms_from_spectra(d(cr), d(ci), erd, eid)
+    (out * 0.5).backward()
+    assert abs(float(out) - float(ref)) < 1e-4 * abs(float(ref))
+    assert rel_l2(erd.grad.cpu(), 0.5 * er_.grad) < TOL and rel_l2(eid.grad.cpu(), 0.5 * ei_.grad) < TOL
+    # magnitude signature get_array_lms_loss(clean_mags, est_mags)
+    emd = d(em.detach()).requires_grad_(True)
+    out2 = tfl.get_array_lms_loss(d(cm), emd)
+    out2.backward()
+    em2 = em.detach().clone().requires_grad_(True)
+    ref2 = ol.lms_loss(cm, em2)
+    ref2.backward()
+    assert abs(float(out2) - float(ref2)) < 1e-4 * abs(float(ref2))
+    assert rel_l2(emd.grad.cpu(), em2.grad) < TOL
+
+
+def test_dccrn_lms_joint_step_against_reference_golden():
+    """model_perceptual_train (trainer.py:45-82): loss = (SI-SNR + LMS) / 2, forward called without targets."""
+    g = load_golden("dccrn_small_E_sisnr_lms")
+    from sefd_amd import config as cfg
+    m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")
+    cfg.perceptual = "LMS"
+    try:
+        m.train()
+        x, y = make_signals(2, 4000)
+        x, y = x.cuda(), y.cuda()
+        real_spec, img_spec, wav = m(x)
+        main = m.loss(wav, y)
+        perc = m.loss(wav, y, real_spec, img_spec, perceptual=True)
+        lossv = (main + perc) / 2
+        lossv.backward()
+    finally:
+        cfg.perceptual = False
+    assert abs(float(main) - float(g["g/main_loss"])) < TOL * abs(float(g["g/main_loss"]))
+    assert abs(float(perc) - float(g["g/perc_loss"])) < TOL * abs(float(g["g/perc_loss"]))
+    assert abs(float(lossv) - float(g["g/loss"])) < TOL * abs(float(g["g/loss"]))
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    for k, v in sub(g, "g/grad_norm").items():
+        if not noise_bias(k):
+            assert abs(float(grads[k].double().norm()) - float(v)) <= 2 * TOL * float(v) + 1e-7, k
+    for k, v in sub(g, "g/grad").items():
+        if not noise_bias(k):
+            assert rel_l2(grads[k], v) < (5e-3 if k.endswith(".2.weight") else 2 * TOL), k
