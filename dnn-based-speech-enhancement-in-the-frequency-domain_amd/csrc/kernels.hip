@@ -284,7 +284,6 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_kernel(const LstmRec d, con
   float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
   float* cs = reinterpret_cast<float*>(rp(ab, d.c));
   const int hs = H + 2;                      // LDS row stride (floats): conflict-free A-fragment reads
-  float* hbuf[2] = {lds, lds + 16 * hs};
   const int KS = H / 4;
   const int unit = 16 * w + (lane & 15);
   const int kq = lane >> 4;
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_kernel(const LstmRec d, con
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        gxv[q][r] = rvalid[r] ? gx[(rowbt[r] + t) * d.gx_ld + q * H + unit] : 0.f;
+        gxv[q][r] = gx[(rowbt[r] + t) * d.gx_ld + q * H + unit];     // rows >= B alias row 0, never stored
   };
   load_gx(0);
   const int64_t GBT = (int64_t)d.B * T;
@@ -325,24 +324,24 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_kernel(const LstmRec d, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[q][r] = gxv[q][r];
     if (t + 1 < T) load_gx(t + 1);
-    const float* hp = hbuf[t & 1];
+    const int hp = (t & 1) * 16 * hs;          // LDS offsets, not pointers: keeps the accesses ds_* instead of flat_*
     if (t > 0) {
 #pragma unroll
       for (int ks = 0; ks < HMAX / 4; ++ks) {
         if (ks < KS) {
-          const float a = hp[(lane & 15) * hs + 4 * ks + kq];
+          const float a = lds[hp + (lane & 15) * hs + 4 * ks + kq];
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[q][ks], acc[q], 0, 0, 0);
         }
       }
     }
-    float* hn = hbuf[(t + 1) & 1];
+    const int hn = ((t + 1) & 1) * 16 * hs;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf_(acc[2][r]), og = sigmoidf_(acc[3][r]);
       c[r] = fg * c[r] + ig * gg;
       const float h = og * tanhf_(c[r]);
-      hn[(4 * kq + r) * hs + unit] = h;
+      lds[hn + (4 * kq + r) * hs + unit] = h;
       if (rvalid[r]) {
         const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
         st_elem(hout, d.hdt, row * H + unit, h);
@@ -398,14 +397,14 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
     for (int r = 0; r < 4; ++r) {
       const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) g4[r][q] = rvalid[r] ? gates[row * 4 * H + q * H + unit] : 0.f;
-      cp[r] = (rvalid[r] && t > 0) ? cs[(row - 1) * H + unit] : 0.f;
-      dhv[r] = rvalid[r] ? dh[row * H + unit] : 0.f;
+      for (int q = 0; q < 4; ++q) g4[r][q] = gates[row * 4 * H + q * H + unit];      // rows >= B alias row 0, results unused
+      cp[r] = cs[(row - (t > 0 ? 1 : 0)) * H + unit];
+      dhv[r] = dh[row * H + unit];
     }
   };
   fetch(T - 1, pg, pcp, pdh);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pct[r] = rvalid[r] ? cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit] : 0.f;
+  for (int r = 0; r < 4; ++r) pct[r] = cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit];
   for (int t = T - 1; t >= 0; --t) {
     if (t > 0) fetch(t - 1, ng, ncp, ndh);
 #pragma unroll
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
       if (rvalid[r]) {
         const float ig = pg[r][0], fg = pg[r][1], gg = pg[r][2], og = pg[r][3];
         const float ct = pct[r];
-        const float cp = pcp[r];
+        const float cp = t > 0 ? pcp[r] : 0.f;
         const float dht = pdh[r] + dhrec[r];
         const float tc = tanhf_(ct);
         dog = dht * tc * og * (1.f - og);

@@ -22,7 +22,6 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
   float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
   float* cs = reinterpret_cast<float*>(rp(ab, d.c));
   const int hs = H + 8;                       // LDS row stride in bf16 elements (16-byte aligned rows, rotating 16-B slots)
-  uint16_t* hbuf[2] = {ldsh, ldsh + 16 * hs};
   const int KS = H / 32;
   const int unit = 16 * w + (lane & 15);
   const int kq = lane >> 4;
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gxv[q][r] = rvalid[r] ? gx[(rowbt[r] + t) * d.gx_ld + q * H + unit] : 0.f;
+      for (int r = 0; r < 4; ++r) gxv[q][r] = gx[(rowbt[r] + t) * d.gx_ld + q * H + unit];   // rows >= B alias row 0, never stored
   };
   load_gx(0);
   const int64_t GBT = (int64_t)d.B * T;
@@ -68,25 +67,25 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[q][r] = gxv[q][r];
     if (t + 1 < T) load_gx(t + 1);
-    const uint16_t* hp = hbuf[t & 1];
+    const int hp = (t & 1) * 16 * hs;            // LDS offsets, not pointers: keeps the accesses in the LDS address space (ds_*, not flat_*)
     if (t > 0) {
 #pragma unroll
       for (int ks = 0; ks < HMAX / 32; ++ks) {
         if (ks < KS) {
-          const uint4 a = *reinterpret_cast<const uint4*>(hp + (lane & 15) * hs + 32 * ks + 8 * kq);
+          const uint4 a = *reinterpret_cast<const uint4*>(&ldsh[hp + (lane & 15) * hs + 32 * ks + 8 * kq]);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wreg[q][ks]), acc[q], 0, 0, 0);
         }
       }
     }
-    uint16_t* hn = hbuf[(t + 1) & 1];
+    const int hn = ((t + 1) & 1) * 16 * hs;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf_(acc[2][r]), og = sigmoidf_(acc[3][r]);
       c[r] = fg * c[r] + ig * gg;
       const uint16_t hb = f2bf(og * tanhf_(c[r]));
-      hn[(4 * kq + r) * hs + unit] = hb;
+      ldsh[hn + (4 * kq + r) * hs + unit] = hb;
       if (rvalid[r]) {
         const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
         hout[row * H + unit] = hb;
@@ -148,14 +147,14 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
     for (int r = 0; r < 4; ++r) {
       const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) g4[r][q] = rvalid[r] ? gates[row * 4 * H + q * H + unit] : 0.f;
-      cp[r] = (rvalid[r] && t > 0) ? cs[(row - 1) * H + unit] : 0.f;
-      dhv[r] = rvalid[r] ? dh[row * H + unit] : 0.f;
+      for (int q = 0; q < 4; ++q) g4[r][q] = gates[row * 4 * H + q * H + unit];      // rows >= B alias row 0, results unused
+      cp[r] = cs[(row - (t > 0 ? 1 : 0)) * H + unit];
+      dhv[r] = dh[row * H + unit];
     }
   };
   fetch(T - 1, pg, pcp, pdh);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pct[r] = rvalid[r] ? cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit] : 0.f;
+  for (int r = 0; r < 4; ++r) pct[r] = cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit];
   for (int t = T - 1; t >= 0; --t) {
     if (t > 0) fetch(t - 1, ng, ncp, ndh);
 #pragma unroll
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
       if (rvalid[r]) {
         const float ig = pg[r][0], fg = pg[r][1], gg = pg[r][2], og = pg[r][3];
         const float ct = pct[r];
-        const float cp = pcp[r];
+        const float cp = t > 0 ? pcp[r] : 0.f;
         const float dht = pdh[r] + dhrec[r];
         const float tc = tanhf_(ct);
         dog = dht * tc * og * (1.f - og);

@@ -217,22 +217,27 @@ int32_t pe(const ParamInfo& p, int64_t idx, int sign = 1) { return (int32_t)(sig
 // Post-pass over a finished plan: give every RUNGEMM the zero page and mark the ones whose runs are whole, 16-byte aligned
 // chunks (then the kernel uses the LDS-DMA loader).  Arena buffers are 256-byte aligned, so only element offsets matter.
 void finalize_rungemms(Builder& b, Plan* P) {
-  static const char zeros[256] = {0};
-  Ptr z = b.cst(zeros, sizeof(zeros));
+  // page 0: 256 zero bytes ; page 1: bf16 (1, 0, 0, ...) for the bias "ones" run of the LDS-DMA WGRAD
+  char pages[512] = {0};
+  pages[256] = (char)0x80; pages[257] = (char)0x3f;
+  Ptr z = b.cst(pages, sizeof(pages));
   for (auto* ops : {&P->fwd, &P->bwd})
     for (Op& op : *ops) {
-      if (op.kind != OP_RUNGEMM) continue;
+      if (op.kind != OP_RUNGEMM && op.kind != OP_WGRAD) continue;
       RunGemm& g = op.g;
       g.zero = z;
       const int vec = 16 / esize(g.xdt);
       bool ok = true;
       for (int s = 0; s < g.nseg && ok; ++s) {
         const Seg& sg = g.seg[s];
-        if (sg.src < 0) { ok = false; break; }
+        if (sg.src < 0) { ok = op.kind == OP_WGRAD; continue; }          // the ones run exists only in WGRAD
         const int q = sg.src;
         ok = sg.off % vec == 0 && sg.len % vec == 0 && g.fstride[q] % vec == 0 && g.base[q] % vec == 0 && g.rowlen[q] % vec == 0 &&
              g.tstride[q] % vec == 0 && g.bstride[q] % vec == 0 && (g.x[q].off % 16) == 0;
       }
+      if (op.kind == OP_WGRAD)      // the upstream-gradient operand must be chunk aligned as well
+        ok = ok && g.xdt == DT_BF16 && g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&
+             g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
       g.flags = ok ? kRunAligned : 0;
     }
 }

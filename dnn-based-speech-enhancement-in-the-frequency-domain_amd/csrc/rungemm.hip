@@ -628,6 +628,157 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const RunGemm d, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// WGRAD (bf16 MFMA), LDS-DMA variant for aligned layers: both operand tiles go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass - the write pass cost more LDS cycles than the MFMAs took).
+// LDS rows are unpadded (lane-linear DMA destination); bank conflicts of the transpose reads are avoided by XOR-ing the
+// 32-byte piece index with the row (applied on the SOURCE chunk index: position p of row r holds chunk p ^ ((r & m) << 1)).
+// Padding / out-of-range rows come from a zero page, the bias "ones" run from a ones page (1.0, 0, 0, ...).
+template <int TN>
+__device__ __forceinline__ bf16x8 tr_frag_swz(const uint16_t* tile, int col0, int lane) {
+  constexpr int MASK = TN == 64 ? 3 : 7;           // 32-byte pieces per row: 4 (128-byte rows) or 8 (256-byte rows)
+  const int g = lane >> 4, i = lane & 15;
+  const int r = 4 * g + (i >> 2);
+  const int piece = ((col0 >> 4) + 0);             // col0 is a multiple of 16 elements = one 32-byte piece
+  const uint16_t* p0 = tile + r * TN + (((piece) ^ (r & MASK)) << 4) + 4 * (i & 3);
+  const int r1 = r + 16;
+  const uint16_t* p1 = tile + r1 * TN + (((piece) ^ (r1 & MASK)) << 4) + 4 * (i & 3);
+  Frag8 f;
+  f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+  f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+  return __builtin_bit_cast(bf16x8, f);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, const ArenaBases ab) {
+  constexpr int TK = kWgTK, RS = kWgRows;
+  constexpr int NT = TN / 32;
+  constexpr int DMASK = TN == 64 ? 3 : 7;
+  __shared__ __attribute__((aligned(16))) uint16_t dys[2][RS * TN];
+  __shared__ __attribute__((aligned(16))) uint16_t as[2][RS * TK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int ntile, ktile, split;
+  wgrad_block((d.Npad + TN - 1) / TN, (d.ldw + TK - 1) / TK, d.nsplit, ntile, ktile, split);
+  const uint16_t* x0 = reinterpret_cast<const uint16_t*>(rp(ab, d.x[0]));
+  const uint16_t* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const uint16_t*>(rp(ab, d.x[1])) : x0;
+  const uint16_t* dy = reinterpret_cast<const uint16_t*>(rp(ab, d.y));
+  const uint16_t* zp = reinterpret_cast<const uint16_t*>(rp(ab, d.zero));
+  const uint16_t* onep = zp + 128;                 // second 256-byte page: bf16 (1, 0, 0, ...)
+  float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)split * d.Npad * d.ldw;
+
+  const int nsteps_total = (d.M + RS - 1) / RS;
+  const int per = (nsteps_total + d.nsplit - 1) / d.nsplit;
+  const int step0 = split * per;
+  const int step1 = min(nsteps_total, step0 + per);
+  const int TF = d.Tout * d.Fo;
+  const int fsh = (d.Fo & (d.Fo - 1)) == 0 ? __ffs(d.Fo) - 1 : -1;
+
+  // A tile: 16 chunks per row, thread -> (row ra + 16p, LDS position pa); it fetches source chunk qa = pa ^ ((row & 7) << 1)
+  const int pa = tid & 15, ra = tid >> 4;
+  const int qa = pa ^ ((ra & 7) << 1);
+  const int kcol = ktile * TK + qa * 8;
+  int sgi = -1, j0 = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const int plen = (d.seg[s].len + 63) / 64 * 64;
+    if (kcol >= d.seg[s].koff && kcol < d.seg[s].koff + plen) { sgi = s; j0 = kcol - d.seg[s].koff; }
+  }
+  Seg sg;
+  if (sgi >= 0) sg = d.seg[sgi]; else { sg.src = 0; sg.dt = 0; sg.off = 0; sg.len = 0; sg.koff = 0; }
+  const bool a_real = sgi >= 0 && sg.src >= 0 && j0 + 8 <= sg.len;
+  const bool a_ones = sgi >= 0 && sg.src < 0 && j0 == 0;
+  const int asrc = sg.src > 0 ? 1 : 0;
+  const uint16_t* xs = asrc ? x1 : x0;
+  // dy tile: TN/8 chunks per row
+  constexpr int DCH = TN / 8;
+  constexpr int DROWS = 256 / DCH;                 // rows per pass (16 or 32)
+  constexpr int DPASS = RS / DROWS;
+  const int pd = tid % DCH, rd = tid / DCH;
+  const int qd = pd ^ ((rd & DMASK) << 1);
+  const int ncol = ntile * TN + qd * 8;
+  const bool d_ok = ncol + 8 <= d.N;
+
+  struct RowPos { int b, q; };
+  auto init_pos = [&](int m) { RowPos r; r.b = m / TF; r.q = m - r.b * TF; return r; };
+  auto advance = [&](RowPos& r) { r.q += RS; while (r.q >= TF) { r.q -= TF; ++r.b; } };
+  RowPos apos[2], dpos[DPASS];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) apos[p] = init_pos(step0 * RS + ra + 16 * p);
+#pragma unroll
+  for (int p = 0; p < DPASS; ++p) dpos[p] = init_pos(step0 * RS + rd + DROWS * p);
+  const int wbase = __builtin_amdgcn_readfirstlane(wid) * 512;          // elements: this wave's 1 KiB inside each 4 KiB pass
+
+  auto dma = [&](int buf, int step) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = step * RS + ra + 16 * p;
+      const uint16_t* src = zp;
+      if (m < d.M) {
+        if (a_real) {
+          const int u = fsh >= 0 ? (apos[p].q >> fsh) : (apos[p].q / d.Fo);
+          const int fo = apos[p].q - u * d.Fo;
+          const int tt = u + sg.dt;
+          const int rr = sg.off + fo * d.fstride[asrc] + j0;
+          if (tt >= 0 && tt < d.Tin[asrc] && rr >= 0 && rr + 8 <= d.rowlen[asrc])
+            src = xs + (int64_t)apos[p].b * d.bstride[asrc] + d.base[asrc] + (int64_t)tt * d.tstride[asrc] + rr;
+        } else if (a_ones) {
+          src = onep;
+        }
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&as[buf][p * 2048 + wbase]), 16, 0, 0);
+      advance(apos[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) {
+      const int m = step * RS + rd + DROWS * p;
+      const uint16_t* src = zp;
+      if (m < d.M && d_ok) {
+        const int u = fsh >= 0 ? (dpos[p].q >> fsh) : (dpos[p].q / d.Fo);
+        const int fo = dpos[p].q - u * d.Fo;
+        src = dy + (int64_t)dpos[p].b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off + ncol;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&dys[buf][p * 2048 + wbase]), 16, 0, 0);
+      advance(dpos[p]);
+    }
+  };
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wn = (wid >> 1) * (TN / 2), wk = (wid & 1) * 64;
+
+  if (step0 < step1) dma(0, step0);
+  __syncthreads();
+  for (int st = step0; st < step1; ++st) {
+    const int buf = (st - step0) & 1;
+    if (st + 1 < step1) dma(buf ^ 1, st + 1);
+    bf16x8 af[NT], bfr[4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) af[a] = tr_frag_swz<TN>(&dys[buf][0], wn + a * 16, lane);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bfr[b] = tr_frag_swz<TK>(&as[buf][0], wk + b * 16, lane);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = ntile * TN + wn + a * 16 + 4 * (lane >> 4) + r;
+        const int k = ktile * TK + wk + b * 16 + (lane & 15);
+        if (n < d.Npad && k < d.ldw) part[(int64_t)n * d.ldw + k] = acc[a][b][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 template <typename TA>
 static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   const int bn = bn_of(d.N);
@@ -650,6 +801,16 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 }
 
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (d.xdt == DT_BF16 && (d.flags & kRunAligned)) {
+    if (d.Npad >= 128) {
+      dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128>), grid, dim3(256), 0, st, d, ab);
+    } else {
+      dim3 grid(((d.Npad + 63) / 64) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<64>), grid, dim3(256), 0, st, d, ab);
+    }
+    return;
+  }
   if (d.xdt == DT_BF16) {
     if (d.Npad >= 128) {
       dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 KIND = {1: "RUNGEMM", 2: "WGRAD", 3: "PACK", 4: "UNPACK", 5: "BN_FINALIZE", 6: "BN_APPLY", 7: "BN_BWD_REDUCE", 8: "BN_BWD_APPLY",
         9: "LSTM_FWD", 10: "LSTM_BWD", 11: "COMBINE_FWD", 12: "COMBINE_BWD", 13: "MASK_FWD", 14: "MASK_BWD", 15: "OLA_FWD",
-        16: "OLA_BWD", 17: "SPECOUT_FWD", 18: "SPECOUT_BWD", 19: "MEMSET", 20: "SPLITSUM", 21: "BN_BWD_FINALIZE"}
+        16: "OLA_BWD", 17: "SPECOUT_FWD", 18: "SPECOUT_BWD", 19: "MEMSET", 20: "SPLITSUM", 21: "BN_BWD_FINALIZE", 22: "MAGS"}
 
 
 def _report_path(name):
@@ -98,7 +98,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
                             worst, where = err / tol, f"{name} err {err:.2e} tol {tol:.0e}"
                 # stray writes: bytes outside every region the simulator touched must be unchanged on the device
                 stray += int(((g8 != before[a]) & ~touched).sum())
-            lines.append(f"phase {phase} op {i:3d} {KIND.get(int(kinds[i]), kinds[i]):16s} tag {int(tags[i]):4d} elems {nchg:9d} "
+            lines.append(f"phase {phase} op {i:3d} {KIND.get(int(kinds[i]), str(int(kinds[i]))):16s} tag {int(tags[i]):4d} elems {nchg:9d} "
                          f"err/tol {worst:.3e} stray {stray} {where}")
             if not (worst < 1.0) or stray:
                 bad.append(lines[-1])
