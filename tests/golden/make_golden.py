@@ -171,6 +171,38 @@ def crn_case(cfg, models, name, kernel_num, rnn_units, rnn_input, mask, loss, B,
     print(f"crn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
 
 
+def fsn_case(cfg, models, tfm, name, B, L, hidden=(512, 384)):
+    """FullSubNet train step with the LSTM inter-layer dropout patched to 0 (p = 0.8 makes train mode stochastic)."""
+    cfg.loss = "MSE"
+    torch.manual_seed(0)
+    m = models.FullSubNet(fb_model_hidden_size=hidden[0], sb_model_hidden_size=hidden[1])
+    fill_state_dict_(m)
+    m.train()
+    m.fb_model.sequence_model.dropout = 0.0
+    m.sb_model.sequence_model.dropout = 0.0
+    x, y = test_signals(B, L)
+    nc, cc = tfm.stft(x), tfm.stft(y)
+    noisy_mag, _ = tfm.mag_phase(nc)
+    cirm = tfm.build_complex_ideal_ratio_mask(nc, cc)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    crm = m(noisy_mag)
+    lossv = m.loss(cirm, crm)
+    opt.zero_grad()
+    lossv.backward()
+    g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    opt.step()
+    sd = m.state_dict()
+    small = lambda k: "bias" in k or k.startswith("sb_model.fc_output_layer")
+    rec = dict(meta=dict(B=B, L=L, fb_hidden=hidden[0], sb_hidden=hidden[1]),
+               noisy_mag=noisy_mag.numpy()[:, ::4, ::3], cirm=cirm.numpy()[:, ::4, ::3], crm=crm.detach().numpy(), loss=float(lossv),
+               grad_norm={k: float(v.double().norm()) for k, v in g.items()},
+               grad={k: v.numpy() for k, v in g.items() if small(k)},
+               grad_samp={k: sample(v, 211)["samp"] for k, v in g.items() if not small(k)},
+               after_adam={k: sd[k].numpy().copy() for k in g if small(k)})
+    np.savez_compressed(os.path.join(HERE, f"fsn_{name}.npz"), **flat(rec, "g"))
+    print(f"fsn_{name}: loss {float(lossv):.6f}")
+
+
 def frontend_and_losses(cfg, models, tfm, tfl):
     out = {}
     K, _ = tfm.init_kernels(400, 100, 512, "hann")
@@ -243,6 +275,8 @@ def main():
     dccrn_case(cfg, models, "default_C_sisnr_full", dflt, 256, "C", "SI-SNR", False, 1, 48000, store_taps=False)
     crn_case(cfg, models, "default_E_mse", dflt, 256, 512, "E", "MSE", 2, 4000)
     crn_case(cfg, models, "small_E_sisnr", small, 128, 128, "E", "SI-SNR", 2, 4000)
+    fsn_case(cfg, models, tfm, "default_mse", 2, 6000)
+    fsn_case(cfg, models, tfm, "small_mse", 2, 6000, hidden=(128, 64))
 
 
 if __name__ == "__main__":
