@@ -72,6 +72,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
+void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);
 

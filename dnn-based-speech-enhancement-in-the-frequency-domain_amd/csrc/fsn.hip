@@ -1,0 +1,253 @@
+// FullSubNet glue kernels (reference models.py:626-672, tools_for_model.py:806-837, 997-1011): everything around the
+// per-time-step LSTM GEMMs is HBM-bound element-wise / gather work on time-major tensors.
+#include <hip/hip_runtime.h>
+#include "sefd_desc.h"
+#include "dev_common.h"
+
+namespace sefd {
+
+static inline int gridn(int64_t n, int cap = 16384) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
+#define GSL(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------------------------- LSTM cell (one time step)
+__global__ __launch_bounds__(256) void cell_fwd_kernel(const LstmCell d, const ArenaBases ab) {
+  float* g = reinterpret_cast<float*>(rp(ab, d.gates));
+  const float* cp = d.first ? nullptr : reinterpret_cast<const float*>(rp(ab, d.c_prev));
+  float* c = reinterpret_cast<float*>(rp(ab, d.c));
+  char* h = rp(ab, d.h);
+  const int H = d.H;
+  GSL(i, d.rows * H) {
+    const int64_t r = i / H;
+    const int j = (int)(i - r * H);
+    float* gr = g + r * 4 * H;
+    const float ig = sigmoidf_(gr[j]), fg = sigmoidf_(gr[H + j]), gg = tanhf_(gr[2 * H + j]), og = sigmoidf_(gr[3 * H + j]);
+    const float cn = fg * (cp ? cp[i] : 0.f) + ig * gg;
+    gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = gg; gr[3 * H + j] = og;
+    c[i] = cn;
+    st_elem(h, d.hdt, i, og * tanhf_(cn));
+  }
+}
+
+__global__ __launch_bounds__(256) void cell_bwd_kernel(const LstmCell d, const ArenaBases ab) {
+  const float* g = reinterpret_cast<const float*>(rp(ab, d.gates));
+  const float* cp = d.c_prev.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.c_prev)) : nullptr;
+  const float* c = reinterpret_cast<const float*>(rp(ab, d.c));
+  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
+  float* dc = reinterpret_cast<float*>(rp(ab, d.dc));
+  char* dg = rp(ab, d.dgates);
+  const int H = d.H;
+  GSL(i, d.rows * H) {
+    const int64_t r = i / H;
+    const int j = (int)(i - r * H);
+    const float* gr = g + r * 4 * H;
+    const float ig = gr[j], fg = gr[H + j], gg = gr[2 * H + j], og = gr[3 * H + j];
+    const float tc = tanhf_(c[i]);
+    const float dht = dh[i];
+    const float dcv = dht * og * (1.f - tc * tc) + (d.first ? 0.f : dc[i]);
+    const int64_t o = r * 4 * H + j;
+    st_elem(dg, d.gdt, o, dcv * gg * ig * (1.f - ig));
+    st_elem(dg, d.gdt, o + H, dcv * (cp ? cp[i] : 0.f) * fg * (1.f - fg));
+    st_elem(dg, d.gdt, o + 2 * H, dcv * ig * (1.f - gg * gg));
+    st_elem(dg, d.gdt, o + 3 * H, dht * tc * og * (1.f - og));
+    dc[i] = dcv * fg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dropout
+__device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x632BE5ABu) * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float keep_scale(const Dropout& d, const uint32_t* seed, int64_t i) {
+  if (d.keep >= 1.f) return 1.f;
+  const uint32_t r = mix32(seed[0] + (uint32_t)d.layer * 0x51ED27u, seed[1] ^ (uint32_t)(i >> 32), (uint32_t)i);
+  return ((r >> 8) * (1.f / 16777216.f)) < d.keep ? 1.f / d.keep : 0.f;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const Dropout d, const ArenaBases ab) {   // forward and backward are the same map
+  const char* x = rp(ab, d.x);
+  char* y = rp(ab, d.y);
+  const uint32_t* seed = reinterpret_cast<const uint32_t*>(rp(ab, d.seed));
+  GSL(i, d.n) st_elem(y, d.dt, i, ld_elem(x, d.dt, i) * keep_scale(d, seed, i));
+}
+
+// ---------------------------------------------------------------------------------------------- input / normalisation
+__global__ __launch_bounds__(256) void fsn_in_kernel(const Fsn d, const ArenaBases ab) {       // one workgroup per (b, f-chunk)
+  const float* in = reinterpret_cast<const float*>(rp(ab, d.in));       // [B][F][T]
+  float* mt = reinterpret_cast<float*>(rp(ab, d.out));                 // [TP][B][F]
+  float* sums = reinterpret_cast<float*>(rp(ab, d.sums));              // [B][F]  partial sums (one per (b, f))
+  const int b = blockIdx.y;
+  for (int f = blockIdx.x; f < d.F; f += gridDim.x) {
+    float s = 0.f;
+    for (int t = threadIdx.x; t < d.TP; t += 256) {
+      const float v = t < d.T ? in[((int64_t)b * d.F + f) * d.T + t] : 0.f;
+      mt[((int64_t)t * d.B + b) * d.F + f] = v;
+      s += v;
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[b * d.F + f] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ float utt_mean(const float* sums, int b, int F, double count) {    // serial sum of F partials: deterministic
+  double s = 0.0;
+  for (int f = 0; f < F; ++f) s += sums[b * F + f];
+  return (float)(s / count);
+}
+__global__ __launch_bounds__(256) void fsn_scale_kernel(const Fsn d, const ArenaBases ab) {
+  const float* mt = reinterpret_cast<const float*>(rp(ab, d.in));
+  char* out = rp(ab, d.out);                                             // [TP][B][FP]
+  const float* mu = reinterpret_cast<const float*>(rp(ab, d.sums));     // [B] means (finalised)
+  GSL(i, (int64_t)d.TP * d.B * d.FP) {
+    const int f = (int)(i % d.FP);
+    const int64_t tb = i / d.FP;
+    const int b = (int)(tb % d.B);
+    st_elem(out, d.dt, i, f < d.F ? mt[tb * d.F + f] / (mu[b] + 1e-5f) : 0.f);
+  }
+}
+// means: sums [B][nper] -> aux2[B] = sum / count
+__global__ void fsn_mean_kernel(const Fsn d, const ArenaBases ab, double count, int nper) {
+  const float* sums = reinterpret_cast<const float*>(rp(ab, d.sums));
+  float* mu = reinterpret_cast<float*>(rp(ab, d.aux2));
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < d.B) mu[b] = utt_mean(sums, b, nper, count);
+}
+
+__device__ __forceinline__ int reflect_idx(int f, int F) { return f < 0 ? -f : (f >= F ? 2 * (F - 1) - f : f); }
+
+// un-normalised sub-band input element (tools_for_model.py:806-837 + models.py:649-655), k < NB: neighbour f - n + k, k == NB: full band
+__device__ __forceinline__ float sb_raw(const Fsn& d, const float* mt, const float* fbo, int t, int b, int f, int k) {
+  const int n = (d.NB - 1) / 2;
+  if (k < d.NB) return mt[((int64_t)t * d.B + b) * d.F + reflect_idx(f - n + k, d.F)];
+  return fbo[((int64_t)t * d.B + b) * d.FP + f];
+}
+__global__ __launch_bounds__(256) void fsn_sbsum_kernel(const Fsn d, const ArenaBases ab) {    // grid (F, B): sums[b][f] over (k, t)
+  const float* mt = reinterpret_cast<const float*>(rp(ab, d.in));
+  const float* fbo = reinterpret_cast<const float*>(rp(ab, d.aux));
+  float* sums = reinterpret_cast<float*>(rp(ab, d.sums));
+  const int f = blockIdx.x, b = blockIdx.y, W = d.NB + 1;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < d.TP * W; i += 256) s += sb_raw(d, mt, fbo, i / W, b, f, i % W);
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[b * d.F + f] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void fsn_sbbuild_kernel(const Fsn d, const ArenaBases ab) {
+  const float* mt = reinterpret_cast<const float*>(rp(ab, d.in));
+  const float* fbo = reinterpret_cast<const float*>(rp(ab, d.aux));
+  const float* mu = reinterpret_cast<const float*>(rp(ab, d.sums));
+  char* out = rp(ab, d.out);                                            // [TP][B*F][NB+1]
+  const int W = d.NB + 1;
+  GSL(i, (int64_t)d.TP * d.B * d.F * W) {
+    const int k = (int)(i % W);
+    const int64_t r = i / W;
+    const int f = (int)(r % d.F);
+    const int64_t tb = r / d.F;
+    const int b = (int)(tb % d.B), t = (int)(tb / d.B);
+    st_elem(out, d.dt, i, sb_raw(d, mt, fbo, t, b, f, k) / (mu[b] + 1e-5f));
+  }
+}
+__global__ __launch_bounds__(256) void fsn_out_kernel(const Fsn d, const ArenaBases ab) {      // crm [B][F][T][2] <- sbo [TP][B*F][2]
+  const float* sbo = reinterpret_cast<const float*>(rp(ab, d.in));
+  float* crm = reinterpret_cast<float*>(rp(ab, d.out));
+  GSL(i, (int64_t)d.B * d.F * d.T * 2) {
+    const int cch = (int)(i & 1);
+    const int64_t q = i >> 1;
+    const int t = (int)(q % d.T);
+    const int64_t bf = q / d.T;
+    crm[i] = sbo[(((int64_t)(t + d.LA)) * d.B * d.F + bf) * 2 + cch];
+  }
+}
+__global__ __launch_bounds__(256) void fsn_out_bwd_kernel(const Fsn d, const ArenaBases ab) {  // d_sbo [TP][B*F][2] (dtype dt) <- grad_crm
+  const float* g = reinterpret_cast<const float*>(rp(ab, d.in));
+  char* ds = rp(ab, d.out);
+  GSL(i, (int64_t)d.TP * d.B * d.F * 2) {
+    const int cch = (int)(i & 1);
+    const int64_t q = i >> 1;
+    const int64_t bf = q % ((int64_t)d.B * d.F);
+    const int t = (int)(q / ((int64_t)d.B * d.F));
+    st_elem(ds, d.dt, i, t >= d.LA ? g[(bf * d.T + (t - d.LA)) * 2 + cch] : 0.f);
+  }
+}
+// S[b][f] = sum_{k,t} d_sbin * sbin   (in = d_sbin fp32 [TP][B*F][W], aux = sbin dtype dt)
+__global__ __launch_bounds__(256) void fsn_sbbwd_sum_kernel(const Fsn d, const ArenaBases ab) {
+  const float* dsb = reinterpret_cast<const float*>(rp(ab, d.in));
+  const char* sb = rp(ab, d.aux);
+  float* sums = reinterpret_cast<float*>(rp(ab, d.sums));
+  const int f = blockIdx.x, b = blockIdx.y, W = d.NB + 1;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < d.TP * W; i += 256) {
+    const int t = i / W, k = i % W;
+    const int64_t o = (((int64_t)t * d.B + b) * d.F + f) * W + k;
+    s += dsb[o] * ld_elem(sb, d.dt, o);
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[b * d.F + f] = red[0] + red[1] + red[2] + red[3];
+}
+// d_fb_pre [TP][B][FP] (dtype dt) = relu'(fbo) * ( d_sbin[..][NB] / (mu+eps) - S_b / (N (mu+eps)) )     aux = fbo, aux2 = mu_sb, sums = S_b (mean form)
+__global__ __launch_bounds__(256) void fsn_sbbwd_apply_kernel(const Fsn d, const ArenaBases ab) {
+  const float* dsb = reinterpret_cast<const float*>(rp(ab, d.in));
+  const float* fbo = reinterpret_cast<const float*>(rp(ab, d.aux));
+  const float* mu = reinterpret_cast<const float*>(rp(ab, d.aux2));
+  const float* Sm = reinterpret_cast<const float*>(rp(ab, d.sums));     // S_b / N  (finalised as a "mean")
+  char* out = rp(ab, d.out);
+  const int W = d.NB + 1;
+  GSL(i, (int64_t)d.TP * d.B * d.FP) {
+    const int f = (int)(i % d.FP);
+    const int64_t tb = i / d.FP;
+    const int b = (int)(tb % d.B);
+    float v = 0.f;
+    if (f < d.F) {
+      const float den = mu[b] + 1e-5f;
+      v = dsb[(tb * d.F + f) * W + d.NB] / den - Sm[b] / den;
+      const float y = fbo[i];
+      if (d.act == 1) v = y > 0.f ? v : 0.f;                     // ReLU
+      else if (d.act == 2) v *= (1.f - y * y);                   // Tanh
+      else if (d.act == 3) v = (y > 0.f && y < 6.f) ? v : 0.f;   // ReLU6
+    }
+    st_elem(out, d.dt, i, v);
+  }
+}
+
+void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
+  switch (op.kind) {
+    case OP_CELL_FWD: hipLaunchKernelGGL(cell_fwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
+    case OP_CELL_BWD: hipLaunchKernelGGL(cell_bwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
+    case OP_DROPOUT_FWD:
+    case OP_DROPOUT_BWD: hipLaunchKernelGGL(dropout_kernel, dim3(gridn(op.drop.n)), dim3(256), 0, st, op.drop, ab); break;
+    case OP_FSN_IN: {
+      const Fsn& d = op.fsn;
+      hipLaunchKernelGGL(fsn_in_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
+      hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP, d.F);
+      break;
+    }
+    case OP_FSN_SCALE: hipLaunchKernelGGL(fsn_scale_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.FP)), dim3(256), 0, st, op.fsn, ab); break;
+    case OP_FSN_SBSUM: {
+      const Fsn& d = op.fsn;
+      hipLaunchKernelGGL(fsn_sbsum_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
+      hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
+      break;
+    }
+    case OP_FSN_SBBUILD: hipLaunchKernelGGL(fsn_sbbuild_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.F * (op.fsn.NB + 1))), dim3(256), 0, st, op.fsn, ab); break;
+    case OP_FSN_OUT: hipLaunchKernelGGL(fsn_out_kernel, dim3(gridn((int64_t)op.fsn.B * op.fsn.F * op.fsn.T * 2)), dim3(256), 0, st, op.fsn, ab); break;
+    case OP_FSN_OUT_BWD: hipLaunchKernelGGL(fsn_out_bwd_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.F * 2)), dim3(256), 0, st, op.fsn, ab); break;
+    case OP_FSN_SBBWD_SUM: {
+      const Fsn& d = op.fsn;
+      hipLaunchKernelGGL(fsn_sbbwd_sum_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
+      hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
+      break;
+    }
+    case OP_FSN_SBBWD_APPLY: hipLaunchKernelGGL(fsn_sbbwd_apply_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.FP)), dim3(256), 0, st, op.fsn, ab); break;
+    default: break;
+  }
+}
+
+}  // namespace sefd

@@ -762,7 +762,7 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
       hipLaunchKernelGGL(mags_kernel, dim3(grid_for(op.mags.frames * op.mags.MS)), dim3(256), 0, st, op.mags, ab); break;
     case OP_MEMSET:
       (void)hipMemsetAsync(rp(ab, op.ms.dst), 0, op.ms.bytes, st); break;
-    default: break;
+    default: launch_fsn(op, ab, st); break;
   }
 }
 

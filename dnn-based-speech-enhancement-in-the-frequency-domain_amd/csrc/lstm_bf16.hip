@@ -10,10 +10,13 @@ namespace sefd {
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
+// H is a compile-time constant (32 / 64 / 96 / 128): with run-time trip counts hipcc guards every MFMA with a branch and
+// drains the software-prefetched loads before the matrix section, which serialises the 483-step loop.
 template <int HMAX>
 __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d, const ArenaBases ab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];
-  const int H = d.H, T = d.T;
+  constexpr int H = HMAX;
+  const int T = d.T;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = blockIdx.y, b0 = blockIdx.x * 16;
   const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
@@ -21,8 +24,8 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
   uint16_t* hout = reinterpret_cast<uint16_t*>(rp(ab, d.h));
   float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
   float* cs = reinterpret_cast<float*>(rp(ab, d.c));
-  const int hs = H + 8;                       // LDS row stride in bf16 elements (16-byte aligned rows, rotating 16-B slots)
-  const int KS = H / 32;
+  constexpr int hs = H + 8;                       // LDS row stride in bf16 elements (16-byte aligned rows, rotating 16-B slots)
+  constexpr int KS = H / 32;
   const int unit = 16 * w + (lane & 15);
   const int kq = lane >> 4;
 
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
 template <int HMAX>
 __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d, const ArenaBases ab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];
-  const int H = d.H, T = d.T;
+  constexpr int H = HMAX;
+  const int T = d.T;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = blockIdx.y, b0 = blockIdx.x * 16;
   const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
   const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
   char* dgo = rp(ab, d.dgates);
-  const int gs = 4 * H + 8;
+  constexpr int gs = 4 * H + 8;
   const int unit = 16 * w + (lane & 15);
   const int kq = lane >> 4;
-  const int KS = 4 * H / 32;
+  constexpr int KS = 4 * H / 32;
 
   uint4 wreg[HMAX / 8];                       // B[k = n][j = unit] = W_hh[n][unit], n = 32*ks + 8*kq + e
 #pragma unroll
@@ -173,10 +177,8 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
         dg = dc * ig * (1.f - gg * gg);
         dcarry[r] = dc * fg;
         const int64_t o = d.gx_goff[g] + (rowbt[r] + t) * d.gx_ld;
-        st_elem(dgo, d.gdt, o + unit, di);
-        st_elem(dgo, d.gdt, o + H + unit, df);
-        st_elem(dgo, d.gdt, o + 2 * H + unit, dg);
-        st_elem(dgo, d.gdt, o + 3 * H + unit, dog);
+        uint16_t* dgp = reinterpret_cast<uint16_t*>(dgo) + o + unit;      // bf16 mode: dgates are stored bf16 (planner sets gdt)
+        dgp[0] = f2bf(di); dgp[H] = f2bf(df); dgp[2 * H] = f2bf(dg); dgp[3 * H] = f2bf(dog);
       }
       uint16_t* lrow = ldsh + (4 * kq + r) * gs;
       lrow[unit] = f2bf(di); lrow[H + unit] = f2bf(df); lrow[2 * H + unit] = f2bf(dg); lrow[3 * H + unit] = f2bf(dog);
@@ -214,8 +216,12 @@ static void launch_t(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
 }
 
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
-  if (d.H <= 64) launch_t<64>(d, ab, st, fwd);
-  else launch_t<128>(d, ab, st, fwd);
+  switch (d.H) {          // planner guarantees H % 32 == 0, H <= 128 and gdt == bf16 in bf16 mode
+    case 32: launch_t<32>(d, ab, st, fwd); break;
+    case 64: launch_t<64>(d, ab, st, fwd); break;
+    case 96: launch_t<96>(d, ab, st, fwd); break;
+    default: launch_t<128>(d, ab, st, fwd); break;
+  }
 }
 
 }  // namespace sefd

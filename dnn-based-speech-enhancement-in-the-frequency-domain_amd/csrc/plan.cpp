@@ -238,7 +238,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
       if (op.kind == OP_WGRAD)      // the upstream-gradient operand must be chunk aligned as well
         ok = ok && g.xdt == DT_BF16 && g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&
              g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
-      g.flags = ok ? kRunAligned : 0;
+      g.flags = (g.flags & ~kRunAligned) | (ok ? kRunAligned : 0);
     }
 }
 

@@ -310,8 +310,10 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
       for (int e = 0; e < 16; ++e) {
         const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         const int64_t o = rowoff[row];
-        const float v = acc[i][j][e] + bv;
+        float v = acc[i][j][e] + bv;
         if (o >= 0 && n < d.N) {
+          if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yb)[o + n];
+          if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
           if (d.ydt == DT_BF16) reinterpret_cast<uint16_t*>(yb)[o + n] = f2bf(v);
           else reinterpret_cast<float*>(yb)[o + n] = v;
           s1 += v;

@@ -63,7 +63,9 @@ struct RunGemm {
   int32_t flags;           // bit 0: every run is 16-byte aligned and a whole number of 16-byte chunks -> LDS-DMA loader
   Ptr zero;                // >= 16 zero bytes (A_CONST): source of padding chunks for the LDS-DMA loader
 };
-constexpr int kRunAligned = 1;
+constexpr int kRunAligned = 1;   // LDS-DMA loader usable
+constexpr int kRunAccum = 2;     // y += result (fp32 y): recurrent term added onto the hoisted input GEMM / gradient accumulation
+constexpr int kRunRelu = 4;      // y = max(result, 0)
 
 // PACK: dst[i] = sum_{e < width} sign(tab[i*width+e]) * src[|tab[i*width+e]|-1]   (entry 0 -> nothing).  Table int32 in A_CONST.
 // width 1: packed conv / LSTM weights ; width 2: combined biases (b_r - b_i | b_r + b_i), (b_ih + b_hh).
@@ -181,10 +183,43 @@ struct Memset {
   int64_t bytes;
 };
 
+// ---------------------------------------------------------------------------------------------- FullSubNet (models.py:568-682)
+// Time-major sequence tensors [T][rows][feat]: one LSTM time step is one dense GEMM over all rows (rows = B for the
+// full-band model, B*257 for the sub-band model) followed by an element-wise cell kernel.
+struct LstmCell {            // forward : gates slab holds pre-activations (input GEMM + recurrent GEMM) -> overwritten by i,f,g,o
+  Ptr gates;                 //           fp32 [rows][4H]
+  Ptr c_prev, c;             //           fp32 [rows][H]   (c_prev = A_NONE at t == 0)
+  Ptr h;                     //           [rows][H] dtype hdt
+  Ptr dh, dc, dgates;        // backward: dh fp32 [rows][H] (total upstream), dc fp32 [rows][H] carry (in/out), dgates out dtype gdt
+  int64_t rows;
+  int32_t H, hdt, gdt, first;     // first: t == 0 (no previous cell state) / backward: t == T-1 (no carry yet)
+};
+// Inverted dropout between the LSTM layers (nn.LSTM(dropout=0.8), tools_for_model.py:746): counter-based hash RNG on
+// (seed, element index); backward re-derives the mask from the same seed.  keep == 1 -> identity copy.
+struct Dropout {
+  Ptr x, y, seed;            // seed: two uint32 in A_IO ("io.seed"), advanced by the host every step
+  int64_t n;
+  float keep;
+  int32_t dt, layer, pad_;   // dt of x / y ; layer id decorrelates the masks of different layers
+};
+// FSN_IN: noisy_mag [B][F][T] fp32 -> mag_t [TP][B][F] fp32 (zero for the look-ahead frames t >= T) and per-utterance sums.
+// FSN_SCALE: fb_in[t][b][f < F] = mag_t / (sum_b / (F*TP) + 1e-5), zero padded to FP columns, dtype dt.
+// FSN_SBSUM: per-utterance sum of the un-normalised sub-band input (31 reflected neighbours + full-band output).
+// FSN_SBBUILD: sb_in [TP][B*F][NB+1] = that input / (mean + 1e-5).
+// FSN_OUT: crm [B][F][T][2] = sb_out[t + LA][b*F + f][:] ; FSN_OUT_BWD the reverse (zero for t < LA).
+// FSN_SBBWD_SUM / _APPLY: gradient of the normalised concat w.r.t. the full-band output (through value and mean), x ReLU'.
+struct Fsn {
+  Ptr in, out, aux, aux2, sums;
+  int32_t B, F, T, TP, FP, NB, LA, dt;
+  int32_t act, pad_;
+};
+
 enum OpKind : int32_t {
   OP_RUNGEMM = 1, OP_WGRAD, OP_PACK, OP_UNPACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD_REDUCE, OP_BN_BWD_APPLY,
   OP_LSTM_FWD, OP_LSTM_BWD, OP_COMBINE_FWD, OP_COMBINE_BWD, OP_MASK_FWD, OP_MASK_BWD, OP_OLA_FWD, OP_OLA_BWD,
-  OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE, OP_MAGS
+  OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE, OP_MAGS,
+  OP_CELL_FWD, OP_CELL_BWD, OP_DROPOUT_FWD, OP_DROPOUT_BWD, OP_FSN_IN, OP_FSN_SCALE, OP_FSN_SBSUM, OP_FSN_SBBUILD, OP_FSN_OUT,
+  OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY
 };
 
 struct Op {
@@ -205,6 +240,9 @@ struct Op {
     SpecOut so;
     Memset ms;
     Mags mags;
+    LstmCell cell;
+    Dropout drop;
+    Fsn fsn;
   };
 };
 

@@ -56,7 +56,9 @@ void rungemm(const RunGemm& d, const AB& ab) {
     for (int n = 0; n < d.N; ++n) {
       double acc = 0.0;
       for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, (int64_t)n * d.ldw + k);
-      const float v = (float)acc + (bias ? bias[n] : 0.f);
+      float v = (float)acc + (bias ? bias[n] : 0.f);
+      if (d.flags & kRunAccum) v += ((const float*)y)[o + n];
+      if (d.flags & kRunRelu) v = v > 0.f ? v : 0.f;
       st(y, d.ydt, o + n, v);
       if (d.stats.arena >= 0) { s1[(size_t)(m / kBM) * d.Npad + n] += v; s2[(size_t)(m / kBM) * d.Npad + n] += (double)v * v; }
     }
@@ -108,7 +110,184 @@ inline void load_dz(const BnBwdReduce& d, const AB& ab, int64_t r, int c, double
   if (d.dz1.arena >= 0) *g += ld(rp(ab, d.dz1), d.dt, r * d.C + c);
 }
 
+
+inline float sgm(double x) { return (float)(1.0 / (1.0 + std::exp(-x))); }
+inline uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x632BE5ABu) * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+inline int reflect_idx(int f, int F) { return f < 0 ? -f : (f >= F ? 2 * (F - 1) - f : f); }
+inline float sb_raw(const Fsn& d, const float* mt, const float* fbo, int t, int b, int f, int k) {
+  const int n = (d.NB - 1) / 2;
+  if (k < d.NB) return mt[((int64_t)t * d.B + b) * d.F + reflect_idx(f - n + k, d.F)];
+  return fbo[((int64_t)t * d.B + b) * d.FP + f];
+}
+void means(const Fsn& d, const AB& ab, double count) {
+  const float* sums = (const float*)rp(ab, d.sums);
+  float* mu = (float*)rp(ab, d.aux2);
+  for (int b = 0; b < d.B; ++b) { double s = 0; for (int f = 0; f < d.F; ++f) s += sums[b * d.F + f]; mu[b] = (float)(s / count); }
+}
+
+bool run_fsn(const Op& op, const AB& ab) {
+  switch (op.kind) {
+    case OP_CELL_FWD: {
+      const LstmCell& d = op.cell;
+      float* g = (float*)rp(ab, d.gates);
+      const float* cp = d.first ? nullptr : (const float*)rp(ab, d.c_prev);
+      float* c = (float*)rp(ab, d.c);
+      for (int64_t i = 0; i < d.rows * d.H; ++i) {
+        const int64_t r = i / d.H; const int j = (int)(i % d.H);
+        float* gr = g + r * 4 * d.H;
+        const double ig = sgm(gr[j]), fg = sgm(gr[d.H + j]), gg = std::tanh((double)gr[2 * d.H + j]), og = sgm(gr[3 * d.H + j]);
+        const double cn = fg * (cp ? cp[i] : 0.0) + ig * gg;
+        gr[j] = (float)ig; gr[d.H + j] = (float)fg; gr[2 * d.H + j] = (float)gg; gr[3 * d.H + j] = (float)og;
+        c[i] = (float)cn;
+        st(rp(ab, d.h), d.hdt, i, (float)(og * std::tanh(cn)));
+      }
+      return true;
+    }
+    case OP_CELL_BWD: {
+      const LstmCell& d = op.cell;
+      const float* g = (const float*)rp(ab, d.gates);
+      const float* cp = d.c_prev.arena >= 0 ? (const float*)rp(ab, d.c_prev) : nullptr;
+      const float* c = (const float*)rp(ab, d.c);
+      const float* dh = (const float*)rp(ab, d.dh);
+      float* dc = (float*)rp(ab, d.dc);
+      for (int64_t i = 0; i < d.rows * d.H; ++i) {
+        const int64_t r = i / d.H; const int j = (int)(i % d.H);
+        const float* gr = g + r * 4 * d.H;
+        const double ig = gr[j], fg = gr[d.H + j], gg = gr[2 * d.H + j], og = gr[3 * d.H + j];
+        const double tc = std::tanh((double)c[i]), dht = dh[i];
+        const double dcv = dht * og * (1 - tc * tc) + (d.first ? 0.0 : dc[i]);
+        const int64_t o = r * 4 * d.H + j;
+        st(rp(ab, d.dgates), d.gdt, o, (float)(dcv * gg * ig * (1 - ig)));
+        st(rp(ab, d.dgates), d.gdt, o + d.H, (float)(dcv * (cp ? cp[i] : 0.0) * fg * (1 - fg)));
+        st(rp(ab, d.dgates), d.gdt, o + 2 * d.H, (float)(dcv * ig * (1 - gg * gg)));
+        st(rp(ab, d.dgates), d.gdt, o + 3 * d.H, (float)(dht * tc * og * (1 - og)));
+        dc[i] = (float)(dcv * fg);
+      }
+      return true;
+    }
+    case OP_DROPOUT_FWD:
+    case OP_DROPOUT_BWD: {
+      const Dropout& d = op.drop;
+      const uint32_t* seed = (const uint32_t*)rp(ab, d.seed);
+      for (int64_t i = 0; i < d.n; ++i) {
+        float sc = 1.f;
+        if (d.keep < 1.f) {
+          const uint32_t r = mix32(seed[0] + (uint32_t)d.layer * 0x51ED27u, seed[1] ^ (uint32_t)(i >> 32), (uint32_t)i);
+          sc = ((r >> 8) * (1.f / 16777216.f)) < d.keep ? 1.f / d.keep : 0.f;
+        }
+        st(rp(ab, d.y), d.dt, i, ld(rp(ab, d.x), d.dt, i) * sc);
+      }
+      return true;
+    }
+    case OP_FSN_IN: {
+      const Fsn& d = op.fsn;
+      const float* in = (const float*)rp(ab, d.in);
+      float* mt = (float*)rp(ab, d.out);
+      float* sums = (float*)rp(ab, d.sums);
+      for (int b = 0; b < d.B; ++b)
+        for (int f = 0; f < d.F; ++f) {
+          double s = 0;
+          for (int t = 0; t < d.TP; ++t) {
+            const float v = t < d.T ? in[((int64_t)b * d.F + f) * d.T + t] : 0.f;
+            mt[((int64_t)t * d.B + b) * d.F + f] = v;
+            s += v;
+          }
+          sums[b * d.F + f] = (float)s;
+        }
+      means(d, ab, (double)d.F * d.TP);
+      return true;
+    }
+    case OP_FSN_SCALE: {
+      const Fsn& d = op.fsn;
+      const float* mt = (const float*)rp(ab, d.in);
+      const float* mu = (const float*)rp(ab, d.sums);
+      for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.FP; ++i) {
+        const int f = (int)(i % d.FP); const int64_t tb = i / d.FP; const int b = (int)(tb % d.B);
+        st(rp(ab, d.out), d.dt, i, f < d.F ? mt[tb * d.F + f] / (mu[b] + 1e-5f) : 0.f);
+      }
+      return true;
+    }
+    case OP_FSN_SBSUM:
+    case OP_FSN_SBBWD_SUM: {
+      const Fsn& d = op.fsn;
+      const int W = d.NB + 1;
+      float* sums = (float*)rp(ab, d.sums);
+      for (int b = 0; b < d.B; ++b)
+        for (int f = 0; f < d.F; ++f) {
+          double s = 0;
+          for (int t = 0; t < d.TP; ++t)
+            for (int k = 0; k < W; ++k) {
+              if (op.kind == OP_FSN_SBSUM) s += sb_raw(d, (const float*)rp(ab, d.in), (const float*)rp(ab, d.aux), t, b, f, k);
+              else {
+                const int64_t o = (((int64_t)t * d.B + b) * d.F + f) * W + k;
+                s += (double)((const float*)rp(ab, d.in))[o] * ld(rp(ab, d.aux), d.dt, o);
+              }
+            }
+          sums[b * d.F + f] = (float)s;
+        }
+      means(d, ab, (double)d.F * d.TP * W);
+      return true;
+    }
+    case OP_FSN_SBBUILD: {
+      const Fsn& d = op.fsn;
+      const int W = d.NB + 1;
+      const float* mu = (const float*)rp(ab, d.sums);
+      for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.F * W; ++i) {
+        const int k = (int)(i % W); const int64_t r = i / W; const int f = (int)(r % d.F); const int64_t tb = r / d.F;
+        const int b = (int)(tb % d.B), t = (int)(tb / d.B);
+        st(rp(ab, d.out), d.dt, i, sb_raw(d, (const float*)rp(ab, d.in), (const float*)rp(ab, d.aux), t, b, f, k) / (mu[b] + 1e-5f));
+      }
+      return true;
+    }
+    case OP_FSN_OUT: {
+      const Fsn& d = op.fsn;
+      const float* sbo = (const float*)rp(ab, d.in);
+      float* crm = (float*)rp(ab, d.out);
+      for (int64_t i = 0; i < (int64_t)d.B * d.F * d.T * 2; ++i) {
+        const int cch = (int)(i & 1); const int64_t q = i >> 1; const int t = (int)(q % d.T); const int64_t bf = q / d.T;
+        crm[i] = sbo[(((int64_t)(t + d.LA)) * d.B * d.F + bf) * 2 + cch];
+      }
+      return true;
+    }
+    case OP_FSN_OUT_BWD: {
+      const Fsn& d = op.fsn;
+      const float* g = (const float*)rp(ab, d.in);
+      for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.F * 2; ++i) {
+        const int cch = (int)(i & 1); const int64_t q = i >> 1; const int64_t bf = q % ((int64_t)d.B * d.F); const int t = (int)(q / ((int64_t)d.B * d.F));
+        st(rp(ab, d.out), d.dt, i, t >= d.LA ? g[(bf * d.T + (t - d.LA)) * 2 + cch] : 0.f);
+      }
+      return true;
+    }
+    case OP_FSN_SBBWD_APPLY: {
+      const Fsn& d = op.fsn;
+      const float* dsb = (const float*)rp(ab, d.in);
+      const float* fbo = (const float*)rp(ab, d.aux);
+      const float* mu = (const float*)rp(ab, d.aux2);
+      const float* Sm = (const float*)rp(ab, d.sums);
+      const int W = d.NB + 1;
+      for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.FP; ++i) {
+        const int f = (int)(i % d.FP); const int64_t tb = i / d.FP; const int b = (int)(tb % d.B);
+        float v = 0.f;
+        if (f < d.F) {
+          const float den = mu[b] + 1e-5f;
+          v = dsb[(tb * d.F + f) * W + d.NB] / den - Sm[b] / den;
+          const float y = fbo[i];
+          if (d.act == 1) v = y > 0.f ? v : 0.f; else if (d.act == 2) v *= (1.f - y * y); else if (d.act == 3) v = (y > 0.f && y < 6.f) ? v : 0.f;
+        }
+        st(rp(ab, d.out), d.dt, i, v);
+      }
+      return true;
+    }
+    default: return false;
+  }
+}
+
 void run_op(const Op& op, const AB& ab) {
+  if (run_fsn(op, ab)) return;
   switch (op.kind) {
     case OP_RUNGEMM: rungemm(op.g, ab); break;
     case OP_WGRAD: wgrad(op.g, ab); break;
