@@ -217,8 +217,21 @@ __global__ __launch_bounds__(256) void fsn_sbbwd_apply_kernel(const Fsn d, const
   }
 }
 
+__global__ __launch_bounds__(256) void reflectpad_kernel(const ReflectPad d, const ArenaBases ab) {
+  const float* src = reinterpret_cast<const float*>(rp(ab, d.src));
+  float* dst = reinterpret_cast<float*>(rp(ab, d.dst));
+  const int Lp = d.L + 2 * d.pad;
+  GSL(i, (int64_t)d.B * Lp) {
+    const int64_t b = i / Lp;
+    int j = (int)(i - b * Lp) - d.pad;
+    j = j < 0 ? -j : (j >= d.L ? 2 * (d.L - 1) - j : j);
+    dst[i] = src[b * d.L + j];
+  }
+}
+
 void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
   switch (op.kind) {
+    case OP_REFLECTPAD: hipLaunchKernelGGL(reflectpad_kernel, dim3(gridn((int64_t)op.rpad.B * (op.rpad.L + 2 * op.rpad.pad))), dim3(256), 0, st, op.rpad, ab); break;
     case OP_CELL_FWD: hipLaunchKernelGGL(cell_fwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
     case OP_CELL_BWD: hipLaunchKernelGGL(cell_bwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
     case OP_DROPOUT_FWD:
@@ -250,4 +263,31 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- training targets
+// trainer.py:100-104: noisy_mag = |noisy| ; cIRM = compress(complex ratio mask)   (tools_for_model.py:683-717), interleaved complex in.
+__global__ __launch_bounds__(256) void fsn_targets_kernel(const float* noisy, const float* clean, int64_t n, float* mag, float* phase, float* cirm) {
+  GSL(i, n) {
+    const float nr = noisy[2 * i], ni = noisy[2 * i + 1];
+    if (mag) mag[i] = sqrtf(nr * nr + ni * ni);
+    if (phase) phase[i] = atan2f(ni, nr);
+    if (cirm) {
+      const float cr = clean[2 * i], ci = clean[2 * i + 1];
+      const float den = nr * nr + ni * ni + 1.1920929e-07f;          // np.finfo(np.float32).eps
+      float m[2] = {(nr * cr + ni * ci) / den, (nr * ci - ni * cr) / den};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float v = m[e] <= -100.f ? -100.f : m[e];
+        const float ex = expf(-0.1f * v);
+        cirm[2 * i + e] = 10.f * (1.f - ex) / (1.f + ex);
+      }
+    }
+  }
+}
+
 }  // namespace sefd
+
+extern "C" int32_t sefd_fsn_targets(const float* noisy_c64, const float* clean_c64, int64_t n, float* mag, float* phase, float* cirm, void* stream) {
+  using namespace sefd;
+  hipLaunchKernelGGL(fsn_targets_kernel, dim3(gridn(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), noisy_c64, clean_c64, n, mag, phase, cirm);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -667,8 +667,11 @@ __global__ __launch_bounds__(256) void specout_fwd_kernel(const SpecOut d, const
     const int k = k0 + r, t = t0 + tx;
     if (t < d.T && k < d.NF) {
       const int64_t o = ((int64_t)b * d.NF + k) * d.T + t;
-      outr[o] = tr[tx][r];
-      if (d.mode == 0) outi[o] = ti[tx][r];
+      if (d.mode == 3) { outr[2 * o] = tr[tx][r]; outr[2 * o + 1] = ti[tx][r]; }
+      else {
+        outr[o] = tr[tx][r];
+        if (d.mode == 0) outi[o] = ti[tx][r];
+      }
     }
   }
 }

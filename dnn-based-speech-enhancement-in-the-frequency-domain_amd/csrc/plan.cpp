@@ -1500,7 +1500,334 @@ Plan* build_frontend_plan(const ModelConfig& cfg) {
   return P;
 }
 
+// =================================================================================================================
+// FullSubNet (reference models.py:568-682; SequenceModel tools_for_model.py:726-795).  model == 3.
+// Config fields reused: kernel_num = {sb_num_neighbors, fb_num_neighbors(=0), look_ahead, fb_hidden, sb_hidden,
+//                                     fb activation (0 none, 1 ReLU, 2 Tanh, 3 ReLU6), sb activation, dropout keep in 1/1000};
+// T = frames of the input magnitude (passed in cfg.L as T, cfg.fft_len/2+1 = F).  I/O: io.mag [B][F][T] -> io.crm [B][F][T][2];
+// backward: io.grad_crm -> A_GRAD.
+// Every LSTM layer = one hoisted input GEMM over all T' steps + per step {recurrent GEMM accumulating onto the gate
+// slab, cell kernel}; with B*257 = 8224 rows (B = 32) each step GEMM is a full-chip 8224 x 1536 x 384 problem.
+Plan* build_fsn_plan(const ModelConfig& cfg) {
+  Plan* P = new Plan();
+  P->cfg = cfg;
+  Builder b;
+  b.P = P;
+  b.c = cfg;
+  const int B = cfg.B, T = cfg.L, F = cfg.fft_len / 2 + 1;
+  const int nsb = cfg.kernel_num[0], nfb = cfg.kernel_num[1], LA = cfg.kernel_num[2];
+  const int Hf = cfg.kernel_num[3], Hs = cfg.kernel_num[4], actf = cfg.kernel_num[5], acts = cfg.kernel_num[6];
+  const float keep = cfg.training ? cfg.kernel_num[7] / 1000.f : 1.f;
+  const int adt = cfg.act_dtype;
+  const int TP = T + LA, NB = 2 * nsb + 1, W = NB + 1;
+  const int FP = (int)rup(F, 8);
+  P->T = T;
+  P->NF = F;
+  if (nfb != 0 || acts != 0) { P->error = "FullSubNet: fb_num_neighbors must be 0 and the sub-band output activation None"; return P; }
+  if (Hf % 8 || Hs % 8 || W % 8) { P->error = "FullSubNet: hidden sizes and sub-band width must be multiples of 8"; return P; }
+  struct Net { std::string name; int I, H, O; };
+  Net nets[2] = {{"fb_model", F, Hf, F}, {"sb_model", W, Hs, 2}};
+  for (auto& nt : nets) {
+    for (int l = 0; l < 2; ++l) {
+      const std::string p = nt.name + ".sequence_model.";
+      b.add_param(p + "weight_ih_l" + std::to_string(l), {4 * nt.H, l == 0 ? nt.I : nt.H}, true);
+      b.add_param(p + "weight_hh_l" + std::to_string(l), {4 * nt.H, nt.H}, true);
+      b.add_param(p + "bias_ih_l" + std::to_string(l), {4 * nt.H}, true);
+      b.add_param(p + "bias_hh_l" + std::to_string(l), {4 * nt.H}, true);
+    }
+    b.add_param(nt.name + ".fc_output_layer.weight", {nt.O, nt.H}, true);
+    b.add_param(nt.name + ".fc_output_layer.bias", {nt.O}, true);
+  }
+  const int64_t nparam = P->params.back().off + P->params.back().numel;
+  b.inv.resize(nparam);
+  Ptr io_mag = b.io("mag", (int64_t)B * F * T);
+  Ptr io_crm = b.io("crm", (int64_t)B * F * T * 2);
+  Ptr io_gcrm = b.io("grad_crm", (int64_t)B * F * T * 2);
+  Ptr io_seed = b.io("seed", 2);
+  std::vector<Op>& Fw = P->fwd;
+  std::vector<Op>& R = P->bwd;
+
+  auto fsn0 = [&]() { Fsn f; std::memset(&f, 0, sizeof(f)); f.in = f.out = f.aux = f.aux2 = f.sums = b.none();
+                      f.B = B; f.F = F; f.T = T; f.TP = TP; f.FP = FP; f.NB = NB; f.LA = LA; f.dt = adt; f.act = actf; return f; };
+  // time-major GEMM over all steps: rows (t, r), source [TP][rows][feat]
+  auto seq_gemm = [&](Ptr x, int xdt, int64_t rows, int feat, int off, int len, int N, int ydt) {
+    RunGemm g = Builder::gemm0();
+    g.x[0] = x; g.xdt = xdt; g.ydt = ydt;
+    g.bstride[0] = 0; g.tstride[0] = (int)(rows * feat); g.base[0] = 0; g.rowlen[0] = (int)(rows * feat); g.fstride[0] = feat; g.Tin[0] = TP;
+    g.M = (int)(TP * rows); g.Tout = TP; g.Fo = (int)rows;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, off, len, 0};
+    g.N = N;
+    Builder::layout_segs(g);
+    return g;
+  };
+  auto set_y = [&](RunGemm& g, Ptr y, int64_t rows, int ld, int yoff) {
+    g.y = y; g.y_bstride = 0; g.y_tstride = (int)(rows * ld); g.y_fstride = ld; g.y_off = yoff;
+  };
+  // one time step: rows (r), source slab [rows][feat] at step t
+  auto step_gemm = [&](Ptr x, int xdt, int64_t rows, int feat, int t, int N, Ptr y, int ld, int64_t yslab_elems, int ydt, int flags) {
+    RunGemm g = Builder::gemm0();
+    g.x[0] = b.mk(A_WS, x.off + (int64_t)t * rows * feat * esize(xdt)); g.xdt = xdt; g.ydt = ydt;
+    g.tstride[0] = 0; g.rowlen[0] = (int)(rows * feat); g.fstride[0] = feat; g.Tin[0] = 1;
+    g.M = (int)rows; g.Tout = 1; g.Fo = (int)rows;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, 0, feat, 0};
+    g.N = N;
+    Builder::layout_segs(g);
+    g.y = b.mk(A_WS, y.off + yslab_elems * esize(ydt)); g.y_fstride = ld; g.flags = flags;
+    return g;
+  };
+
+  // ---- input: transpose, laplace norm (models.py:640-645)
+  Ptr mag_t = b.ws("mag_t", (int64_t)TP * B * F, DT_F32);
+  Ptr sum_fb = b.ws("sum_fb", (int64_t)B * F, DT_F32);
+  Ptr mu_fb = b.ws("mu_fb", B, DT_F32);
+  Ptr fb_in = b.ws("fb_in", (int64_t)TP * B * FP, adt);
+  { Fsn f = fsn0(); f.in = io_mag; f.out = mag_t; f.sums = sum_fb; f.aux2 = mu_fb; b.push(Fw, OP_FSN_IN, 1).fsn = f; }
+  { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
+
+  struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; };
+  std::vector<LayerRt> layers;
+  auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
+    LayerRt L;
+    L.nm = netname + ".l" + std::to_string(l); L.lid = lid; L.x = x; L.xfeat = xfeat; L.xlen = xlen; L.rows = rows; L.H = H;
+    const std::string pp = netname + ".sequence_model.";
+    const ParamInfo &Wih = b.par(pp + "weight_ih_l" + std::to_string(l)), &Whh = b.par(pp + "weight_hh_l" + std::to_string(l));
+    const ParamInfo &bih = b.par(pp + "bias_ih_l" + std::to_string(l)), &bhh = b.par(pp + "bias_hh_l" + std::to_string(l));
+    L.Whh = &Whh;
+    const int I = (int)Wih.shape[1];
+    L.gates = b.ws(L.nm + ".gates", (int64_t)TP * rows * 4 * H, DT_F32);
+    L.c = b.ws(L.nm + ".c", (int64_t)TP * rows * H, DT_F32);
+    L.h = b.ws(L.nm + ".h", (int64_t)TP * rows * H, adt);
+    RunGemm g = seq_gemm(x, adt, rows, xfeat, 0, xlen, 4 * H, DT_F32);
+    L.cgx = [=](int nn, int s, int j) -> int32_t { return j < I ? pe(Wih, (int64_t)nn * I + j, 1) : 0; };
+    L.bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, nn, 1); o[1] = pe(bhh, nn, 1); };
+    b.pack_weights(Fw, g, L.cgx, L.nm + ".ih", tag, &L.bgx);
+    set_y(g, L.gates, rows, 4 * H, 0);
+    b.push(Fw, OP_RUNGEMM, tag).g = g;
+    L.gx = g;
+    // recurrent weights, packed once per step list
+    RunGemm rec0 = step_gemm(L.h, adt, rows, H, 0, 4 * H, L.gates, 4 * H, 0, DT_F32, kRunAccum);
+    Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(Whh, (int64_t)nn * H + j, 1); };
+    b.pack_weights(Fw, rec0, chh, L.nm + ".hh", tag);
+    L.rec = rec0;
+    for (int t = 0; t < TP; ++t) {
+      if (t > 0) {
+        RunGemm r = step_gemm(L.h, adt, rows, H, t - 1, 4 * H, L.gates, 4 * H, (int64_t)t * rows * 4 * H, DT_F32, kRunAccum);
+        r.w = rec0.w;
+        b.push(Fw, OP_RUNGEMM, tag).g = r;
+      }
+      Op& op = b.push(Fw, OP_CELL_FWD, tag);
+      LstmCell& cl = op.cell;
+      cl.gates = b.mk(A_WS, L.gates.off + (int64_t)t * rows * 4 * H * 4);
+      cl.c = b.mk(A_WS, L.c.off + (int64_t)t * rows * H * 4);
+      cl.c_prev = t > 0 ? b.mk(A_WS, L.c.off + (int64_t)(t - 1) * rows * H * 4) : b.none();
+      cl.h = b.mk(A_WS, L.h.off + (int64_t)t * rows * H * esize(adt));
+      cl.dh = cl.dc = cl.dgates = b.none();
+      cl.rows = rows; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == 0;
+    }
+    L.hd = L.h;
+    if (l == 0) {               // inter-layer dropout (nn.LSTM(dropout=0.8)): only after the first of the two layers
+      L.hd = keep < 1.f ? b.ws(L.nm + ".hd", (int64_t)TP * rows * H, adt) : L.h;
+      if (keep < 1.f) {
+        Op& op = b.push(Fw, OP_DROPOUT_FWD, tag);
+        op.drop.x = L.h; op.drop.y = L.hd; op.drop.seed = io_seed; op.drop.n = (int64_t)TP * rows * H; op.drop.keep = keep; op.drop.dt = adt; op.drop.layer = lid;
+      }
+    }
+    layers.push_back(L);
+    return L.hd;
+  };
+  struct FcRt { RunGemm g; Builder::Coef coef; std::function<void(int, int32_t*)> bias; };
+  auto fc_forward = [&](const std::string& netname, Ptr x, int64_t rows, int H, int O, Ptr y, int ld, int flags, int tag) -> FcRt {
+    const ParamInfo &Wf = b.par(netname + ".fc_output_layer.weight"), &bf = b.par(netname + ".fc_output_layer.bias");
+    FcRt fc;
+    fc.g = seq_gemm(x, adt, rows, H, 0, H, O, DT_F32);
+    fc.coef = [=](int nn, int s, int j) -> int32_t { return pe(Wf, (int64_t)nn * H + j, 1); };
+    fc.bias = [=](int nn, int32_t* o) { o[0] = pe(bf, nn, 1); o[1] = 0; };
+    b.pack_weights(Fw, fc.g, fc.coef, netname + ".fc", tag, &fc.bias);
+    set_y(fc.g, y, rows, ld, 0);
+    fc.g.flags = flags;
+    b.push(Fw, OP_RUNGEMM, tag).g = fc.g;
+    return fc;
+  };
+
+  // ---- full-band model
+  Ptr h0 = lstm_forward("fb_model", 0, 0, fb_in, FP, FP, B, Hf, 100);
+  Ptr h1 = lstm_forward("fb_model", 1, 1, h0, Hf, Hf, B, Hf, 101);
+  Ptr fbo = b.ws("fbo", (int64_t)TP * B * FP, DT_F32);
+  { Op& m = b.push(Fw, OP_MEMSET, 102); m.ms.dst = fbo; m.ms.bytes = (int64_t)TP * B * FP * 4; }   // pad columns F..FP-1 stay 0
+  FcRt fcf = fc_forward("fb_model", h1, B, Hf, F, fbo, FP, actf == 1 ? kRunRelu : 0, 102);
+  if (actf > 1) { P->error = "FullSubNet: only ReLU / None full-band activations are on the HIP path"; return P; }
+
+  // ---- sub-band input (models.py:647-665)
+  const int64_t rs = (int64_t)B * F;
+  Ptr sum_sb = b.ws("sum_sb", (int64_t)B * F, DT_F32);
+  Ptr mu_sb = b.ws("mu_sb", B, DT_F32);
+  Ptr sb_in = b.ws("sb_in", (int64_t)TP * rs * W, adt);
+  { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.sums = sum_sb; f.aux2 = mu_sb; b.push(Fw, OP_FSN_SBSUM, 200).fsn = f; }
+  { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.sums = mu_sb; f.out = sb_in; b.push(Fw, OP_FSN_SBBUILD, 201).fsn = f; }
+  Ptr h2 = lstm_forward("sb_model", 0, 2, sb_in, W, W, rs, Hs, 202);
+  Ptr h3 = lstm_forward("sb_model", 1, 3, h2, Hs, Hs, rs, Hs, 203);
+  Ptr sbo = b.ws("sbo", (int64_t)TP * rs * 2, DT_F32);
+  FcRt fcs = fc_forward("sb_model", h3, rs, Hs, 2, sbo, 2, 0, 204);
+  { Fsn f = fsn0(); f.in = sbo; f.out = io_crm; b.push(Fw, OP_FSN_OUT, 205).fsn = f; }
+
+  // =================================================================================================== backward
+  if (cfg.training) {
+    auto lstm_backward = [&](LayerRt& L, Ptr dh, bool need_dx, Ptr dx, int dx_ld, int dx_off, int dx_N, int dx_dt, int tag) {
+      const int H = L.H;
+      const int64_t rows = L.rows;
+      Ptr dgates = b.ws(L.nm + ".dgates", (int64_t)TP * rows * 4 * H, adt);
+      Ptr dc = b.ws(L.nm + ".dc", rows * H, DT_F32);
+      // dh_{t-1} += dgates_t . W_hh : packed transposed recurrent weights
+      RunGemm rb0 = step_gemm(dgates, adt, rows, 4 * H, 0, H, dh, H, 0, DT_F32, kRunAccum);
+      const ParamInfo* Whh = L.Whh;
+      Builder::Coef cT = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)j * H + nn, 1); };
+      b.pack_weights(R, rb0, cT, L.nm + ".hhT", tag);
+      for (int t = TP - 1; t >= 0; --t) {
+        Op& op = b.push(R, OP_CELL_BWD, tag);
+        LstmCell& cl = op.cell;
+        cl.gates = b.mk(A_WS, L.gates.off + (int64_t)t * rows * 4 * H * 4);
+        cl.c = b.mk(A_WS, L.c.off + (int64_t)t * rows * H * 4);
+        cl.c_prev = t > 0 ? b.mk(A_WS, L.c.off + (int64_t)(t - 1) * rows * H * 4) : b.none();
+        cl.h = b.none();
+        cl.dh = b.mk(A_WS, dh.off + (int64_t)t * rows * H * 4);
+        cl.dc = dc;
+        cl.dgates = b.mk(A_WS, dgates.off + (int64_t)t * rows * 4 * H * esize(adt));
+        cl.rows = rows; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == TP - 1;
+        if (t > 0) {
+          RunGemm r = step_gemm(dgates, adt, rows, 4 * H, t, H, dh, H, (int64_t)(t - 1) * rows * H, DT_F32, kRunAccum);
+          r.w = rb0.w;
+          b.push(R, OP_RUNGEMM, tag).g = r;
+        }
+      }
+      // weight gradients over all steps
+      RunGemm fw = L.gx;
+      fw.ydt = adt;
+      b.wgrad(R, fw, dgates, L.cgx, tag, &L.bgx);
+      RunGemm fh = seq_gemm(L.h, adt, rows, H, 0, H, 4 * H, adt);
+      fh.seg[0].dt = -1;                                   // h_{t-1}
+      set_y(fh, dgates, rows, 4 * H, 0);
+      Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)nn * H + j, 1); };
+      b.wgrad(R, fh, dgates, chh, tag, nullptr);
+      if (need_dx) {
+        RunGemm g = seq_gemm(dgates, adt, rows, 4 * H, 0, 4 * H, dx_N, dx_dt);
+        const Builder::Coef cf = L.cgx;
+        Builder::Coef coef = [=](int nn, int s, int j) -> int32_t { return cf(j, 0, nn); };
+        b.pack_weights(R, g, coef, L.nm + ".dx", tag);
+        set_y(g, dx, rows, dx_ld, dx_off);
+        b.push(R, OP_RUNGEMM, tag).g = g;
+      }
+    };
+    auto fc_backward = [&](FcRt& fc, Ptr dy, Ptr x, int64_t rows, int H, int O, int ld, Ptr dh, int tag, const std::string& nm) {
+      RunGemm fw = fc.g;
+      fw.ydt = adt; fw.flags = 0;
+      b.wgrad(R, fw, dy, fc.coef, tag, &fc.bias);
+      RunGemm g = seq_gemm(dy, adt, rows, ld, 0, O, H, DT_F32);
+      const Builder::Coef cf = fc.coef;
+      Builder::Coef coef = [=](int nn, int s, int j) -> int32_t { return cf(j, 0, nn); };
+      b.pack_weights(R, g, coef, nm + ".fc.dg", tag);
+      set_y(g, dh, rows, H, 0);
+      b.push(R, OP_RUNGEMM, tag).g = g;
+    };
+    auto dropout_bwd = [&](LayerRt& L, Ptr dxd, int tag) -> Ptr {      // gradient wrt the un-dropped h (fp32, in place semantics via a copy)
+      if (!(keep < 1.f)) return dxd;
+      Ptr dhu = b.ws(L.nm + ".dhu", (int64_t)TP * L.rows * L.H, DT_F32);
+      Op& op = b.push(R, OP_DROPOUT_BWD, tag);
+      op.drop.x = dxd; op.drop.y = dhu; op.drop.seed = io_seed; op.drop.n = (int64_t)TP * L.rows * L.H; op.drop.keep = keep; op.drop.dt = DT_F32; op.drop.layer = L.lid;
+      return dhu;
+    };
+    LayerRt &Lf0 = layers[0], &Lf1 = layers[1], &Ls0 = layers[2], &Ls1 = layers[3];
+    // sub-band head
+    Ptr d_sbo = b.ws("d_sbo", (int64_t)TP * rs * 2, adt);
+    { Fsn f = fsn0(); f.in = io_gcrm; f.out = d_sbo; b.push(R, OP_FSN_OUT_BWD, 205).fsn = f; }
+    Ptr dh3 = b.ws("dh3", (int64_t)TP * rs * Hs, DT_F32);
+    fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model");
+    Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, DT_F32);
+    lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, DT_F32, 203);
+    Ptr dh2 = dropout_bwd(Ls0, dh2d, 202);
+    Ptr d_sbin = b.ws("d_sbin", (int64_t)TP * rs * W, DT_F32);
+    lstm_backward(Ls0, dh2, true, d_sbin, W, 0, W, DT_F32, 202);
+    // through the normalised concat into the full-band output
+    Ptr sumS = b.ws("sum_S", (int64_t)B * F, DT_F32);
+    Ptr Sm = b.ws("Sm", B, DT_F32);
+    Ptr d_fb = b.ws("d_fb", (int64_t)TP * B * FP, adt);
+    { Fsn f = fsn0(); f.in = d_sbin; f.aux = sb_in; f.sums = sumS; f.aux2 = Sm; b.push(R, OP_FSN_SBBWD_SUM, 201).fsn = f; }
+    { Fsn f = fsn0(); f.in = d_sbin; f.aux = fbo; f.aux2 = mu_sb; f.sums = Sm; f.out = d_fb; b.push(R, OP_FSN_SBBWD_APPLY, 200).fsn = f; }
+    Ptr dh1 = b.ws("dh1", (int64_t)TP * B * Hf, DT_F32);
+    fc_backward(fcf, d_fb, h1, B, Hf, F, FP, dh1, 102, "fb_model");
+    Ptr dh0d = b.ws("dh0d", (int64_t)TP * B * Hf, DT_F32);
+    lstm_backward(Lf1, dh1, true, dh0d, Hf, 0, Hf, DT_F32, 101);
+    Ptr dh0 = dropout_bwd(Lf0, dh0d, 100);
+    lstm_backward(Lf0, dh0, false, b.none(), 0, 0, 0, DT_F32, 100);
+    b.finish_unpack(R);
+  }
+  finalize_rungemms(b, P);
+  P->arena_bytes[A_WS] = b.ws_off;
+  P->arena_bytes[A_PARAM] = nparam * 4;
+  P->arena_bytes[A_GRAD] = nparam * 4;
+  P->arena_bytes[A_STATE] = 4;
+  P->arena_bytes[A_CONST] = (int64_t)P->consts.size();
+  P->arena_bytes[A_IO] = b.io_off;
+  return P;
+}
+
+// =================================================================================================================
+// torch.stft front end of FullSubNet (model 4; tools_for_model.py:628-648): centre / reflect padding, hop = cfg.hop,
+// periodic Hann(win_len) zero-padded to fft_len in the middle.  io.wav [B][L] -> io.spec = complex64 image [B][NF][T][2].
+Plan* build_torchstft_plan(const ModelConfig& cfg) {
+  Plan* P = new Plan();
+  P->cfg = cfg;
+  Builder b;
+  b.P = P;
+  b.c = cfg;
+  const int B = cfg.B, L = cfg.L, W = cfg.win_len, hop = cfg.hop, NFFT = cfg.fft_len;
+  const int pad = NFFT / 2, Lp = L + 2 * pad;
+  const int T = 1 + L / hop;
+  const int NF = NFFT / 2 + 1, NS = NF + 1, SW = NS * 2;
+  P->T = T;
+  P->NF = NF;
+  if (hop % 4 != 0 || pad >= L) { P->error = "torch.stft plan: hop must be a multiple of 4 and the clip longer than fft_len/2"; return P; }
+  Ptr io_wav = b.io("wav", (int64_t)B * L);
+  Ptr io_spec = b.io("spec", (int64_t)B * NF * T * 2);
+  Ptr wpad = b.ws("wpad", (int64_t)B * Lp, DT_F32);
+  Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
+  { Op& op = b.push(P->fwd, OP_REFLECTPAD, 1); op.rpad.src = io_wav; op.rpad.dst = wpad; op.rpad.B = B; op.rpad.L = L; op.rpad.pad = pad; }
+  std::vector<double> win(NFFT, 0.0);
+  const int left = (NFFT - W) / 2;
+  for (int j = 0; j < W; ++j) win[left + j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  RunGemm g = Builder::gemm0();
+  g.x[0] = wpad; g.xdt = DT_F32; g.ydt = DT_F32;
+  g.bstride[0] = Lp; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
+  g.M = B * T; g.Tout = 1; g.Fo = T;
+  g.nseg = 1; g.seg[0] = Seg{0, 0, 0, NFFT, 0};
+  g.N = SW;
+  Builder::layout_segs(g);
+  {
+    std::vector<float> wt((size_t)g.Npad * g.ldw, 0.f);
+    for (int nn = 2; nn < g.N; ++nn)
+      for (int j = 0; j < NFFT; ++j) {
+        const double ang = 2.0 * kPi * (double)(((int64_t)(nn / 2 - 1) * j) % NFFT) / NFFT;
+        wt[(size_t)nn * g.ldw + j] = (float)(((nn & 1) == 0 ? std::cos(ang) : -std::sin(ang)) * win[j]);
+      }
+    g.w = b.cst(wt.data(), (int64_t)wt.size() * 4);
+  }
+  g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+  b.push(P->fwd, OP_RUNGEMM, 2).g = g;
+  SpecOut so;
+  std::memset(&so, 0, sizeof(so));
+  so.est = spec; so.out_real = io_spec; so.out_imag = b.none(); so.B = B; so.T = T; so.NF = NF; so.mode = 3;
+  b.push(P->fwd, OP_SPECOUT_FWD, 3).so = so;
+  finalize_rungemms(b, P);
+  P->arena_bytes[A_WS] = b.ws_off;
+  P->arena_bytes[A_PARAM] = 4; P->arena_bytes[A_GRAD] = 4; P->arena_bytes[A_STATE] = 4;
+  P->arena_bytes[A_CONST] = (int64_t)P->consts.size();
+  P->arena_bytes[A_IO] = b.io_off;
+  return P;
+}
+
 Plan* build_plan(const ModelConfig& cfg) {
+  if (cfg.model == 4) return build_torchstft_plan(cfg);
+  if (cfg.model == 3) return build_fsn_plan(cfg);
   return cfg.model == 2 ? build_frontend_plan(cfg) : (cfg.model == 1 ? build_crn_plan(cfg) : build_dccrn_plan(cfg));
 }
 

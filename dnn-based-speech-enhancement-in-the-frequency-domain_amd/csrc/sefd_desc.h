@@ -172,6 +172,7 @@ struct Ola {
 
 // est spec [B][T][NF+1][2] (fp32, slot layout above) <-> reference layout out_real/out_imag [B][NF][T] fp32
 // mode 1: out_real = |est| (magnitude of the pairs, CRN target_mags) ; mode 2: est is a plain [B*T][NF] fp32 array -> out_real
+// mode 3: out_real receives the interleaved complex tensor [B][NF][T][2] (memory image of torch.complex64 [B, NF, T])
 struct SpecOut {
   Ptr est, out_real, out_imag; // forward: est -> out_*   ; backward: dest += d(out_*)
   int32_t B, T, NF, accumulate;
@@ -181,6 +182,11 @@ struct SpecOut {
 struct Memset {
   Ptr dst;
   int64_t bytes;
+};
+// torch.stft(center=True, pad_mode='reflect'): dst[b][i] = src[b][reflect(i - pad)], i < L + 2*pad
+struct ReflectPad {
+  Ptr src, dst;
+  int32_t B, L, pad, pad_;
 };
 
 // ---------------------------------------------------------------------------------------------- FullSubNet (models.py:568-682)
@@ -219,7 +225,7 @@ enum OpKind : int32_t {
   OP_LSTM_FWD, OP_LSTM_BWD, OP_COMBINE_FWD, OP_COMBINE_BWD, OP_MASK_FWD, OP_MASK_BWD, OP_OLA_FWD, OP_OLA_BWD,
   OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE, OP_MAGS,
   OP_CELL_FWD, OP_CELL_BWD, OP_DROPOUT_FWD, OP_DROPOUT_BWD, OP_FSN_IN, OP_FSN_SCALE, OP_FSN_SBSUM, OP_FSN_SBBUILD, OP_FSN_OUT,
-  OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY
+  OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY, OP_REFLECTPAD
 };
 
 struct Op {
@@ -243,6 +249,7 @@ struct Op {
     LstmCell cell;
     Dropout drop;
     Fsn fsn;
+    ReflectPad rpad;
   };
 };
 

@@ -16,15 +16,24 @@ DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 class Plan:
     def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
                  win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
-                 kernel_size=5, training=True, model="DCCRN"):
+                 kernel_size=5, training=True, model="DCCRN", fsn=None):
         self.lib = _lib.lib()
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
         cfg = _lib.ModelConfig()
-        cfg.model = {"DCCRN": 0, "CRN": 1, "STFT": 2}[model]
+        cfg.model = {"DCCRN": 0, "CRN": 1, "STFT": 2, "FullSubNet": 3, "TorchSTFT": 4}[model]
         cfg.B, cfg.L = int(B), int(L)
+        if model == "FullSubNet":
+            # L = number of STFT frames T; kernel_num carries (sb_neighbors, fb_neighbors, look_ahead, fb_hidden, sb_hidden,
+            #                                                   fb_act, sb_act, dropout keep probability in 1/1000)
+            f = dict(sb_num_neighbors=15, fb_num_neighbors=0, look_ahead=2, fb_hidden=512, sb_hidden=384, fb_act="ReLU",
+                     sb_act=None, keep=0.2)
+            f.update(fsn or {})
+            acts = {None: 0, "None": 0, "ReLU": 1, "Tanh": 2, "ReLU6": 3}
+            kernel_num = (f["sb_num_neighbors"], f["fb_num_neighbors"], f["look_ahead"], f["fb_hidden"], f["sb_hidden"],
+                          acts[f["fb_act"]], acts[f["sb_act"]], int(round(f["keep"] * 1000)))
         cfg.win_len, cfg.hop, cfg.fft_len = win_len, win_inc, fft_len
-        cfg.n_layers = len(kernel_num)
+        cfg.n_layers = len(kernel_num) if model != "FullSubNet" else 0
         for i, k in enumerate(kernel_num):
             cfg.kernel_num[i] = int(k)
         cfg.rnn_layers, cfg.rnn_units = rnn_layers, rnn_units
@@ -108,6 +117,10 @@ class Plan:
         ar[ARENA_CONST] = torch.from_numpy(self.const_image()).to(dev)
         ar[ARENA_IO] = torch.zeros(self.arena_bytes[ARENA_IO], dtype=torch.uint8, device=dev)
         return ar
+
+    def set_seed(self, arenas, seed):
+        """FullSubNet dropout: (seed lo, seed hi) for the counter-based mask hash; advance it every step."""
+        self.view(arenas, "io.seed").view(torch.int32)[:2].copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32))
 
     def view(self, arenas, name):
         """Typed 1-D view of a named buffer inside its arena."""

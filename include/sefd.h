@@ -23,7 +23,7 @@ typedef struct sefd_plan sefd_plan;
 
 /* Mirror of the config.py knobs that shape DCCRN (config.py:35-68) plus batch geometry. */
 typedef struct sefd_model_config {
-  int32_t model;          /* 0 = DCCRN */
+  int32_t model;          /* 0 DCCRN, 1 CRN, 2 ConvSTFT front end, 3 FullSubNet, 4 torch.stft front end (see csrc/plan.cpp) */
   int32_t B, L;           /* batch, samples per clip */
   int32_t win_len, hop, fft_len;
   int32_t n_layers;
@@ -92,6 +92,11 @@ int32_t sefd_lms_forward(const float* clean_r, const float* clean_i, const float
 int32_t sefd_lms_backward(const float* clean_r, const float* clean_i, const float* est_r, const float* est_i, int32_t B, int32_t NF, int32_t T,
                           const int32_t* bands, const float* weights, int32_t nbands, const int32_t* scale_sizes_host, int32_t nscales,
                           int32_t nfft, const float* grad_scale, float* grad_est_r, float* grad_est_i, void* stream);
+
+/* ---- FullSubNet training targets (trainer.py:100-104; tools_for_model.py:683-717) -------------------------------------
+ * noisy_c64 / clean_c64: interleaved complex64 [n] (the torch.stft outputs).  Any of mag / phase / cirm may be NULL.
+ * mag = |noisy| (mag_phase), phase = angle(noisy), cirm [n][2] = compress_cIRM(build_complex_ideal_ratio_mask(noisy, clean)). */
+int32_t sefd_fsn_targets(const float* noisy_c64, const float* clean_c64, int64_t n, float* mag, float* phase, float* cirm, void* stream);
 
 /* ---- Adam (torch.optim.Adam defaults, train_interface.py:59) on flat fp32 buffers ------------------
  * step is 1-based. */

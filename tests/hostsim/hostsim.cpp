@@ -262,6 +262,15 @@ bool run_fsn(const Op& op, const AB& ab) {
       }
       return true;
     }
+    case OP_REFLECTPAD: {
+      const ReflectPad& d = op.rpad;
+      const float* src = (const float*)rp(ab, d.src);
+      float* dst = (float*)rp(ab, d.dst);
+      const int Lp = d.L + 2 * d.pad;
+      for (int b = 0; b < d.B; ++b)
+        for (int i = 0; i < Lp; ++i) { int j = i - d.pad; j = j < 0 ? -j : (j >= d.L ? 2 * (d.L - 1) - j : j); dst[(int64_t)b * Lp + i] = src[(int64_t)b * d.L + j]; }
+      return true;
+    }
     case OP_FSN_SBBWD_APPLY: {
       const Fsn& d = op.fsn;
       const float* dsb = (const float*)rp(ab, d.in);
@@ -644,6 +653,7 @@ void run_op(const Op& op, const AB& ab) {
         for (int t = 0; t < d.T; ++t)
           for (int k = 0; k < d.NF; ++k) {
             const int64_t e = (((int64_t)b * d.T + t) * NS + k + 1) * 2, o = ((int64_t)b * d.NF + k) * d.T + t;
+            if (op.kind == OP_SPECOUT_FWD && d.mode == 3) { orr[2 * o] = est[e]; orr[2 * o + 1] = est[e + 1]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 2) { orr[o] = est[((int64_t)b * d.T + t) * d.NF + k]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 1) { orr[o] = std::sqrt(est[e] * est[e] + est[e + 1] * est[e + 1]); continue; }
             if (op.kind == OP_SPECOUT_FWD) { orr[o] = est[e]; oi[o] = est[e + 1]; }
