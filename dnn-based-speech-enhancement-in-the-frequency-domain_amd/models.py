@@ -161,8 +161,9 @@ class _SefdModule(nn.Module):
         ps = self._trainable()
         first, last = ps[0][1], ps[-1][1]
         off_last, n_last, _ = self._param_slices[-1]
+        bn = self._bn_buffers()
         return (first.data_ptr() == fp.data_ptr() and last.data_ptr() == fp.data_ptr() + 4 * off_last
-                and self._bn_buffers()[0][1].data_ptr() == self._flat_state.data_ptr())
+                and (not bn or bn[0][1].data_ptr() == self._flat_state.data_ptr()))
 
     def _flatten(self, device):
         """Re-home every parameter / BatchNorm buffer as a view of one flat fp32 tensor (the C ABI's arenas)."""
@@ -443,3 +444,125 @@ class CRN(_SefdModule):
         if perceptual:
             raise NotImplementedError("CRN + perceptual loss is unreachable in the reference (SURVEY Q10)")
         return self._main_loss(estimated, target)
+
+
+# ------------------------------------------------------------------------------------------ FullSubNet (models.py:568-682)
+class SequenceModel(nn.Module):
+    """Parameter holder (tools_for_model.py:726-777): 2-layer nn.LSTM(dropout=0.8) + Linear (+ activation)."""
+
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="LSTM", output_activate_function="Tanh"):
+        super().__init__()
+        if sequence_model != "LSTM" or bidirectional or num_layers != 2:
+            raise NotImplementedError("only the 2-layer unidirectional LSTM SequenceModel is on the HIP path (cfg.sequence_model == 'LSTM')")
+        self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True,
+                                      bidirectional=False, dropout=0.8)
+        self.fc_output_layer = nn.Linear(hidden_size, output_size)
+        self.output_activate_function = output_activate_function
+
+
+class _FSNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, rt, noisy_mag, *params):
+        plan, ar = rt
+        B, F, T = noisy_mag.shape
+        plan.io(ar, "mag", (B, F, T)).copy_(noisy_mag)
+        plan.view(ar, "io.seed").view(torch.int32)[:1].add_(1)        # fresh dropout masks every forward (device-side counter)
+        plan.run(PHASE_FWD, ar, torch.cuda.current_stream().cuda_stream)
+        ctx.owner, ctx.rt, ctx.shape = owner, rt, (B, F, T)
+        return plan.io(ar, "crm", (B, F, T, 2)).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, ar = ctx.rt
+        B, F, T = ctx.shape
+        plan.io(ar, "grad_crm", (B, F, T, 2)).copy_(g)
+        plan.run(PHASE_BWD, ar, torch.cuda.current_stream().cuda_stream)
+        flat = ctx.owner._flat_grad.clone()
+        return (None, None, None) + tuple(flat[off:off + n].view(shape) for (off, n, shape) in ctx.owner._param_slices)
+
+
+class FullSubNet(_SefdModule):
+    """Same constructor as the reference (models.py:569-581)."""
+
+    def __init__(self, sb_num_neighbors=cfg.sb_num_neighbors, fb_num_neighbors=cfg.fb_num_neighbors, num_freqs=cfg.num_freqs,
+                 look_ahead=cfg.look_ahead, sequence_model=cfg.sequence_model, fb_output_activate_function=cfg.fb_output_activate_function,
+                 sb_output_activate_function=cfg.sb_output_activate_function, fb_model_hidden_size=cfg.fb_model_hidden_size,
+                 sb_model_hidden_size=cfg.sb_model_hidden_size, weight_init=cfg.weight_init, norm_type=cfg.norm_type):
+        super().__init__()
+        assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
+        if norm_type != "offline_laplace_norm":
+            raise NotImplementedError("only offline_laplace_norm (the config.py default) is on the HIP path")
+        if weight_init:
+            raise NotImplementedError("weight_init=True is not mirrored (config.py default is False)")
+        self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model, fb_output_activate_function)
+        self.sb_model = SequenceModel((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), 2, sb_model_hidden_size, 2, False,
+                                      sequence_model, sb_output_activate_function)
+        self.sb_num_neighbors, self.fb_num_neighbors, self.look_ahead, self.num_freqs = sb_num_neighbors, fb_num_neighbors, look_ahead, num_freqs
+        self._fsn = dict(sb_num_neighbors=sb_num_neighbors, fb_num_neighbors=fb_num_neighbors, look_ahead=look_ahead,
+                         fb_hidden=fb_model_hidden_size, sb_hidden=sb_model_hidden_size, fb_act=fb_output_activate_function,
+                         sb_act=sb_output_activate_function)
+        self.dropout_keep = 0.2                      # nn.LSTM(dropout=0.8); tests set 1.0 to compare with the dropout-free goldens
+        self.masking_mode, self.act_dtype = "cIRM", cfg.act_dtype
+        self._init_runtime_state()
+
+    def _fsn_runtime(self, B, T, device):
+        if not self._flat_ok(device):
+            self._flatten(device)
+        keep = self.dropout_keep if self.training else 1.0
+        key = ("fsn", B, T, bool(self.training), keep, self.act_dtype)
+        rt = self._runtimes.get(key)
+        if rt is None:
+            plan = Plan(B, T, fft_len=2 * (self.num_freqs - 1), act_dtype=self.act_dtype, training=True, model="FullSubNet",
+                        fsn=dict(self._fsn, keep=keep))
+            assert [n for n, _ in self._trainable()] == list(plan.params.keys()), "parameter order differs from the plan"
+            ar = [None] * ARENA_COUNT
+            ar[ARENA_WS] = torch.zeros(max(plan.arena_bytes[ARENA_WS], 256), dtype=torch.uint8, device=device)
+            ar[ARENA_CONST] = torch.from_numpy(plan.const_image()).to(device)
+            ar[ARENA_IO] = torch.zeros(plan.arena_bytes[ARENA_IO], dtype=torch.uint8, device=device)
+            ar[ARENA_PARAM], ar[ARENA_GRAD], ar[ARENA_STATE] = self._flat_param, self._flat_grad, self._flat_state
+            rt = (plan, ar)
+            self._runtimes[key] = rt
+        return rt
+
+    def forward(self, noisy_mag):
+        """models.py:626-672: noisy_mag [B, F, T] (or [B, 1, F, T]) -> cRM [B, F, T, 2]."""
+        if noisy_mag.dim() == 4:
+            assert noisy_mag.shape[1] == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
+            noisy_mag = noisy_mag[:, 0]
+        if not noisy_mag.is_cuda:
+            raise RuntimeError("sefd FullSubNet runs on the MI355X only (cuda tensors); there is no CPU fallback")
+        noisy_mag = noisy_mag.detach().float().contiguous()
+        B, F, T = noisy_mag.shape
+        rt = self._fsn_runtime(B, T, noisy_mag.device)
+        return _FSNFunction.apply(self, rt, noisy_mag, *[p for _, p in self._trainable()])
+
+    def loss(self, estimated, target):
+        """models.py:674-682.  cfg.loss == 'MSE' is the configuration the reference trains FullSubNet with."""
+        if cfg.loss != 'MSE':
+            raise NotImplementedError("FullSubNet.loss: only cfg.loss == 'MSE' is on the HIP path")
+        return tfl.mse(estimated.reshape(estimated.shape[0], -1), target.reshape(target.shape[0], -1))
+
+    def train_step(self, inputs, targets, optimizer, loss_kind=None, exchange=None):
+        """fullsubnet_train body (trainer.py:95-111), fused: stft x2 -> |.|, cIRM -> forward -> MSE -> backward -> Adam."""
+        from . import tools_for_model as tools
+        from .optim import Adam
+        if not isinstance(optimizer, Adam):
+            raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
+        noisy_complex, clean_complex = tools.stft(inputs), tools.stft(targets)
+        noisy_mag, _, cirm = tools._targets(noisy_complex, clean_complex, True, False, True)
+        B, F, T = noisy_mag.shape
+        plan, ar = self._fsn_runtime(B, T, noisy_mag.device)
+        optimizer.bind(self)
+        stream = torch.cuda.current_stream().cuda_stream
+        plan.io(ar, "mag", (B, F, T)).copy_(noisy_mag)
+        plan.view(ar, "io.seed").view(torch.int32)[:1].add_(1)
+        plan.run(PHASE_FWD, ar, stream)
+        crm = plan.io(ar, "crm", (B, F * T * 2))
+        ws, loss = tfl.loss_forward_raw(0, crm, cirm.view(B, -1), stream)
+        tfl.loss_backward_raw(0, crm, cirm.view(B, -1), ws, None, plan.io(ar, "grad_crm", (B, F * T * 2)), stream)
+        plan.run(PHASE_BWD, ar, stream)
+        if exchange is not None and exchange.world > 1:
+            exchange.all_reduce(self._flat_grad)
+            optimizer.grad_scale = exchange.grad_scale
+        optimizer.step_flat()
+        return loss

@@ -51,3 +51,30 @@ def model_perceptual_train(model, optimizer, train_loader, DEVICE):
         train_perc += perceptual_loss.detach()
     n = max(batch_num, 1)
     return train_loss / n, train_main / n, train_perc / n
+
+
+def fullsubnet_train(model, optimizer, train_loader, DEVICE):
+    """trainer.py:85-118."""
+    from . import tools_for_model as tools
+    train_loss = torch.zeros((), device=DEVICE)
+    batch_num = 0
+    model.train()
+    fused = isinstance(optimizer, Adam)
+    for inputs, targets in train_loader:
+        batch_num += 1
+        inputs = inputs.float().to(DEVICE)
+        targets = targets.float().to(DEVICE)
+        if fused:
+            loss = model.train_step(inputs, targets, optimizer)
+        else:
+            noisy_complex = tools.stft(inputs)
+            clean_complex = tools.stft(targets)
+            noisy_mag, _ = tools.mag_phase(noisy_complex)
+            cIRM = tools.build_complex_ideal_ratio_mask(noisy_complex, clean_complex)
+            cRM = model(noisy_mag)
+            loss = model.loss(cIRM, cRM)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        train_loss += loss.detach()
+    return train_loss / max(batch_num, 1)

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 KIND = {1: "RUNGEMM", 2: "WGRAD", 3: "PACK", 4: "UNPACK", 5: "BN_FINALIZE", 6: "BN_APPLY", 7: "BN_BWD_REDUCE", 8: "BN_BWD_APPLY",
         9: "LSTM_FWD", 10: "LSTM_BWD", 11: "COMBINE_FWD", 12: "COMBINE_BWD", 13: "MASK_FWD", 14: "MASK_BWD", 15: "OLA_FWD",
-        16: "OLA_BWD", 17: "SPECOUT_FWD", 18: "SPECOUT_BWD", 19: "MEMSET", 20: "SPLITSUM", 21: "BN_BWD_FINALIZE", 22: "MAGS"}
+        16: "OLA_BWD", 17: "SPECOUT_FWD", 18: "SPECOUT_BWD", 19: "MEMSET", 20: "SPLITSUM", 21: "BN_BWD_FINALIZE", 22: "MAGS", 23: "CELL_FWD", 24: "CELL_BWD", 25: "DROPOUT_FWD", 26: "DROPOUT_BWD", 27: "FSN_IN", 28: "FSN_SCALE", 29: "FSN_SBSUM",
+        30: "FSN_SBBUILD", 31: "FSN_OUT", 32: "FSN_OUT_BWD", 33: "FSN_SBBWD_SUM", 34: "FSN_SBBWD_APPLY", 35: "REFLECTPAD"}
 
 
 def _report_path(name):
@@ -35,28 +36,40 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 3, 4000, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),
                                                         ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
-                                                        ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16")])
+                                                        ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),
+                                                        ("FullSubNet", 2, 13, "E", (128, 64), 0, "fp32"),
+                                                        ("FullSubNet", 2, 9, "E", (64, 32), 0, "bf16")])
 def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     """Tolerances: fp32 buffers 1e-3 (observed <= 3e-6); bf16 buffers 1.6e-2 = two bf16 ulps of the largest element
     (simulator and kernel round slightly different fp32 accumulations of the SAME bf16 operands)."""
     from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, sim_run
-    if model == "CRN":
+    if model == "FullSubNet":              # L = STFT frames, kn = (fb_hidden, sb_hidden); dropout keep 0.2 exercises the mask hash
+        from oracle.fullsubnet import FSNConfig, fsn_state_shapes
+        P = formula_state_dict(fsn_state_shapes(FSNConfig(fb_hidden=kn[0], sb_hidden=kn[1])))
+        plan = Plan(B, L, act_dtype=dtype, model="FullSubNet", fsn=dict(fb_hidden=kn[0], sb_hidden=kn[1], keep=0.2))
+    elif model == "CRN":
         from oracle.crn import CRNConfig, crn_state_shapes
         P = formula_state_dict(crn_state_shapes(CRNConfig(kernel_num=kn, rnn_units=ru, rnn_input_size=4 * (kn[-1] // 2))))
     else:
         P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)))
-    plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
+    if model != "FullSubNet":
+        plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
     dev = plan.alloc_arenas("cuda")
     host = plan.alloc_arenas("cpu")
     fill_params(plan, dev, P)
-    x, y = make_signals(B, L)
-    plan.io(dev, "wav", (B, L)).copy_(x)
-    if model == "CRN":
-        plan.io(dev, "tgt", (B, L)).copy_(y)
     torch.manual_seed(1)
-    plan.io(dev, "grad_wav", (B, L)).copy_(torch.randn(B, L) * 1e-3)
-    plan.io(dev, "grad_real", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
-    plan.io(dev, "grad_imag", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
+    if model == "FullSubNet":
+        plan.io(dev, "mag", (B, 257, L)).copy_(torch.rand(B, 257, L) * 3)
+        plan.io(dev, "grad_crm", (B, 257, L, 2)).copy_(torch.randn(B, 257, L, 2) * 1e-3)
+        plan.set_seed(dev, 77)
+    else:
+        x, y = make_signals(B, L)
+        plan.io(dev, "wav", (B, L)).copy_(x)
+        if model == "CRN":
+            plan.io(dev, "tgt", (B, L)).copy_(y)
+        plan.io(dev, "grad_wav", (B, L)).copy_(torch.randn(B, L) * 1e-3)
+        plan.io(dev, "grad_real", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
+        plan.io(dev, "grad_imag", (B, plan.NF, plan.T)).copy_(torch.randn(B, plan.NF, plan.T) * 1e-4)
     # region table: (arena, byte offset, bytes, dtype, name); GRAD / STATE arenas are single fp32 regions
     regions = []
     for name in plan.buffer_names():

