@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=3.0)
-    ap.add_argument("--dtype", default=os.environ.get("SEFD_BENCH_DTYPE", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("SEFD_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -90,13 +90,13 @@ def cpu_baseline(L, kn, ru):
     x, y = make_batch(Bc, L, 0, "cpu")
     dccrn_train_step(P, cfgo, x, y, loss_kind="SI-SNR")          # warm-up
     ts = []
-    for _ in range(3):
+    for _ in range(2):
         t0 = time.time()
         dccrn_train_step(P, cfgo, x, y, loss_kind="SI-SNR")
         ts.append(time.time() - t0)
     med = sorted(ts)[len(ts) // 2]
     return dict(value=round(Bc / med, 3), unit="utt/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle DCCRN train step, B={Bc}, 3 timed steps (median {med:.2f} s/step), fp32")
+                sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + 2 timed steps (median {med:.2f} s/step), fp32")
 
 
 def main():

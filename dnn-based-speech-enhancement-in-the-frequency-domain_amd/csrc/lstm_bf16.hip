@@ -54,14 +54,17 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
   }
   float c[4] = {0.f, 0.f, 0.f, 0.f};
-  float gxv[4][4];
-  auto load_gx = [&](int t) {
+  // gate pre-activations are prefetched TWO steps ahead: one step (~1 us) does not cover an HBM round trip under load
+  float gxv[4][4], gx1[4][4], gx2[4][4];
+  auto load_gx = [&](int t, float (&dst)[4][4]) {
+    const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gxv[q][r] = gx[(rowbt[r] + t) * d.gx_ld + q * H + unit];   // rows >= B alias row 0, never stored
+      for (int r = 0; r < 4; ++r) dst[q][r] = gx[(rowbt[r] + tc) * d.gx_ld + q * H + unit];   // rows >= B alias row 0, never stored
   };
-  load_gx(0);
+  load_gx(0, gxv);
+  load_gx(1, gx1);
   const int64_t GBT = (int64_t)d.B * T;
   for (int t = 0; t < T; ++t) {
     f32x4 acc[4];
@@ -69,7 +72,11 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[q][r] = gxv[q][r];
-    if (t + 1 < T) load_gx(t + 1);
+    load_gx(t + 2, gx2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { gxv[q][r] = gx1[q][r]; gx1[q][r] = gx2[q][r]; }
     const int hp = (t & 1) * 16 * hs;            // LDS offsets, not pointers: keeps the accesses in the LDS address space (ds_*, not flat_*)
     if (t > 0) {
 #pragma unroll
@@ -145,8 +152,10 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
   f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
   // software prefetch: the saved activations of step t-1 are fetched while step t computes (all addresses are known)
   float pg[4][4], pct[4], pcp[4], pdh[4];       // gates i,f,g,o ; c_t ; c_{t-1} ; upstream dh   for the current step
-  float ng[4][4], ncp[4], ndh[4];               // the same for the next (t-1) step
-  auto fetch = [&](int t, float (&g4)[4][4], float (&cp)[4], float (&dhv)[4]) {
+  float ng[4][4], ncp[4], ndh[4];               // the same for step t-1
+  float mg[4][4], mcp[4], mdh[4];               // ... and for step t-2 (two steps of look-ahead cover the HBM latency)
+  auto fetch = [&](int t_, float (&g4)[4][4], float (&cp)[4], float (&dhv)[4]) {
+    const int t = t_ > 0 ? t_ : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
@@ -157,10 +166,11 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
     }
   };
   fetch(T - 1, pg, pcp, pdh);
+  fetch(T - 2, ng, ncp, ndh);
 #pragma unroll
   for (int r = 0; r < 4; ++r) pct[r] = cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit];
   for (int t = T - 1; t >= 0; --t) {
-    if (t > 0) fetch(t - 1, ng, ncp, ndh);
+    fetch(t - 2, mg, mcp, mdh);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float di = 0.f, df = 0.f, dg = 0.f, dog = 0.f;
@@ -200,8 +210,9 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       pct[r] = pcp[r]; pcp[r] = ncp[r]; pdh[r] = ndh[r];
+      ncp[r] = mcp[r]; ndh[r] = mdh[r];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pg[r][q] = ng[r][q];
+      for (int q = 0; q < 4; ++q) { pg[r][q] = ng[r][q]; ng[r][q] = mg[r][q]; }
     }
     lds_barrier();
   }

@@ -64,6 +64,10 @@ class _Loss(torch.autograd.Function):
 
 
 def mse(estimated, target):
+    """F.mse_loss(estimated, target): symmetric, so the operand that needs a gradient is fed as the differentiated one
+    (FullSubNet calls model.loss(cIRM, cRM) with the network output in the `target` slot, trainer.py:107)."""
+    if target.requires_grad and not estimated.requires_grad:
+        estimated, target = target, estimated
     return _Loss.apply(0, estimated, target)
 
 
