@@ -15,12 +15,14 @@ struct ArenaBases { char* p[A_COUNT]; };
 
 __host__ __device__ __forceinline__ char* rp(const ArenaBases& ab, const Ptr& q) { return ab.p[q.arena] + q.off; }
 
-__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, on the gfx950 conversion unit: ONE v_cvt_pk_bf16_f32 packs two values (the software
+// sequence is 6 VALU ops per value and dominated the epilogues / the LSTM step loops).  No HIP builtin exists: inline asm.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)pack_bf16x2(f, 0.f); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 template <int DT> struct Elem;
@@ -43,8 +45,8 @@ __device__ __forceinline__ float4 ld4(const char* base, int dt, int64_t i) {
 __device__ __forceinline__ void st4(char* base, int dt, int64_t i, float4 v) {
   if (dt == DT_BF16) {
     uint2 r;
-    r.x = f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    r.y = f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    r.x = pack_bf16x2(v.x, v.y);
+    r.y = pack_bf16x2(v.z, v.w);
     *reinterpret_cast<uint2*>(base + i * 2) = r;
   } else {
     *reinterpret_cast<float4*>(base + i * 4) = v;

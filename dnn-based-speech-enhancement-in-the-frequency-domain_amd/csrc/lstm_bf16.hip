@@ -8,7 +8,7 @@
 
 namespace sefd {
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 // H is a compile-time constant (32 / 64 / 96 / 128): with run-time trip counts hipcc guards every MFMA with a branch and
 // drains the software-prefetched loads before the matrix section, which serialises the 483-step loop.
@@ -186,14 +186,24 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
         df = dc * cp * fg * (1.f - fg);
         dg = dc * ig * (1.f - gg * gg);
         dcarry[r] = dc * fg;
-        const int64_t o = d.gx_goff[g] + (rowbt[r] + t) * d.gx_ld;
-        uint16_t* dgp = reinterpret_cast<uint16_t*>(dgo) + o + unit;      // bf16 mode: dgates are stored bf16 (planner sets gdt)
-        dgp[0] = f2bf(di); dgp[H] = f2bf(df); dgp[2 * H] = f2bf(dg); dgp[3 * H] = f2bf(dog);
       }
       uint16_t* lrow = ldsh + (4 * kq + r) * gs;
       lrow[unit] = f2bf(di); lrow[H + unit] = f2bf(df); lrow[2 * H + unit] = f2bf(dg); lrow[3 * H + unit] = f2bf(dog);
     }
     lds_barrier();
+    // dgates_t leave through the LDS tile with 16-byte stores (2 per thread) instead of sixteen 2-byte stores per lane
+    {
+      constexpr int CPR = 4 * H / 8;                       // 16-byte chunks per row
+      for (int ch = threadIdx.x; ch < 16 * CPR; ch += HMAX * 4) {
+        const int row = ch / CPR, c8 = ch - row * CPR;
+        const int b = b0 + row;
+        if (b < d.B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(ldsh + row * gs + c8 * 8);
+          uint16_t* dst = reinterpret_cast<uint16_t*>(dgo) + d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld + c8 * 8;
+          *reinterpret_cast<uint4*>(dst) = v;
+        }
+      }
+    }
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
 #pragma unroll
