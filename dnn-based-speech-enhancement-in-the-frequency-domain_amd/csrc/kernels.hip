@@ -494,7 +494,7 @@ __global__ void mask_fwd_kernel(const Mask d, const ArenaBases ab) {
     if (slot >= 2) {                           // bins >= 1 ; bin 0 (slot 1) has a zero mask (models.py:255-256) -> est = 0
       const int64_t b = f / d.T, t = f - b * d.T;
       const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * d.mch;
-      const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch == 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
+      const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch >= 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
       const float sr = spec[i * 2], si = spec[i * 2 + 1];
       if (d.mode == 3) {                         // CRN (models.py:519-526): est_mags = tanh(out) * mags, noisy phase re-attached
         const float em = tanhf(mr) * sqrtf(sr * sr + si * si);
@@ -546,7 +546,7 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
       const int64_t si_ = (f * NS + k + 2) * 2;
       const float sr = spec[si_], si = spec[si_ + 1];
       const float der = dest[si_], dei = dest[si_ + 1];
-      const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch == 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
+      const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch >= 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
       if (d.mode == 3) {
         const float tm = tanhf(mr);
         float sn, cs;
@@ -579,7 +579,7 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
       }
     }
     st_elem(dmask, d.mdt, mo, gr);
-    if (d.mch == 2) st_elem(dmask, d.mdt, mo + 1, gi);
+    if (d.mch >= 2) st_elem(dmask, d.mdt, mo + 1, gi);
   }
 }
 
@@ -597,6 +597,19 @@ __global__ void mags_kernel(const Mags d, const ArenaBases ab) {
       v = sqrtf(sr * sr + si * si);
     }
     st_elem(mags, d.dt, i, v);
+  }
+}
+
+// Channel-padded copy of the spectrogram for the first encoder layer: C = 2 would make every run of that layer a 4/8-byte
+// fragment; padded to 8 channels the layer uses the same 16-byte LDS-DMA path as all the others (weights of the pad are 0).
+__global__ void specpad_kernel(const Mags d, const ArenaBases ab) {
+  const float* spec = reinterpret_cast<const float*>(rp(ab, d.spec));
+  char* out = rp(ab, d.mags);
+  const int64_t n = d.frames * d.NF * d.MS;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % d.MS);
+    const int64_t slot = i / d.MS;
+    st_elem(out, d.dt, i, ch < 2 ? spec[slot * 2 + ch] : 0.f);
   }
 }
 
@@ -761,6 +774,8 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
       else hipLaunchKernelGGL(specout_bwd_kernel, grid, dim3(256), 0, st, op.so, ab);
       break;
     }
+    case OP_SPECPAD:
+      hipLaunchKernelGGL(specpad_kernel, dim3(grid_for(op.mags.frames * op.mags.NF * op.mags.MS)), dim3(256), 0, st, op.mags, ab); break;
     case OP_MAGS:
       hipLaunchKernelGGL(mags_kernel, dim3(grid_for(op.mags.frames * op.mags.MS)), dim3(256), 0, st, op.mags, ab); break;
     case OP_MEMSET:

@@ -391,11 +391,13 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kun(nn & 1, nn / 2 - 1, j) * win[j]; });
     g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_tstride = 0; g.y_fstride = SW; g.y_off = 0;
     b.push(F, OP_RUNGEMM, 1).g = g;
-    if (adt == DT_BF16) {      // bf16 mode: the encoder reads a bf16 copy of the spectrogram (second epilogue of the same GEMM)
-      spec_lp = b.ws("spec.bf16", (int64_t)B * T * SW, DT_BF16);
-      g.y = spec_lp; g.ydt = DT_BF16;
-      b.push(F, OP_RUNGEMM, 1).g = g;
-    }
+  }
+  // encoder input: spectrogram with the 2 channels padded to CP (aligned 16-byte runs for the thin first layer), act dtype
+  const int CP = 8;
+  {
+    spec_lp = b.ws("xin", (int64_t)B * T * NS * CP, adt);
+    Op& op = b.push(F, OP_SPECPAD, 1);
+    op.mags.spec = spec; op.mags.mags = spec_lp; op.mags.frames = (int64_t)B * T; op.mags.NF = NS; op.mags.MS = CP; op.mags.MO = 0; op.mags.dt = adt;
   }
 
   // ------------------------------------------------------------------ encoder
@@ -405,6 +407,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   Ptr prev = spec_lp;
   for (int i = 0; i < n; ++i) {
     const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
+    const int Cib = i == 0 ? CP : Ci;             // channels of the input BUFFER (first layer: padded)
     const std::string nm = "enc" + std::to_string(i);
     const std::string pp = "encoder." + std::to_string(i);
     const ParamInfo &Wr = b.par(pp + ".0.real_conv.weight"), &Wi = b.par(pp + ".0.imag_conv.weight");
@@ -413,18 +416,19 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     g.x[0] = prev;
     g.xdt = adt;
     g.ydt = adt;
-    if (i == 0) { g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.base[0] = 4; }
+    if (i == 0) { g.bstride[0] = (int64_t)T * NS * CP; g.tstride[0] = NS * CP; g.base[0] = 2 * CP; }
     else { g.bstride[0] = (int64_t)T * Fi * Ci; g.tstride[0] = Fi * Ci; g.base[0] = 0; }
-    g.rowlen[0] = Fi * Ci; g.fstride[0] = 2 * Ci; g.Tin[0] = T;
+    g.rowlen[0] = Fi * Cib; g.fstride[0] = 2 * Cib; g.Tin[0] = T;
     g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;
     g.nseg = 2;
-    g.seg[0] = Seg{0, -1, -2 * Ci, KS * Ci, 0};   // kw = 0 : frame t-1
-    g.seg[1] = Seg{0, 0, -2 * Ci, KS * Ci, 0};    // kw = 1 : frame t
+    g.seg[0] = Seg{0, -1, -2 * Cib, KS * Cib, 0};   // kw = 0 : frame t-1
+    g.seg[1] = Seg{0, 0, -2 * Cib, KS * Cib, 0};    // kw = 1 : frame t
     g.N = Co;
     Builder::layout_segs(g);
     const int Ci2 = Ci / 2, Co2 = Co / 2;
     Builder::Coef coef = [=](int nn, int s, int j) -> int32_t {
-      const int kw = s, kh = j / Ci, ci = j % Ci;
+      const int kw = s, kh = j / Cib, ci = j % Cib;
+      if (ci >= Ci) return 0;                       // pad channel
       const bool oi = nn >= Co2, ii = ci >= Ci2;
       const int co2 = oi ? nn - Co2 : nn, ci2 = ii ? ci - Ci2 : ci;
       const int64_t idx = (((int64_t)co2 * Ci2 + ci2) * KS + kh) * 2 + kw;
@@ -567,13 +571,14 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
     const int Fi = Fe[idx], Fo = 2 * Fi;
     const bool last = (idx == 1);
+    const int Cob = last ? std::max(Co, CP) : Co;   // channels of the output BUFFER (mask layer: 2 -> 8, pad stays 0)
     const std::string nm = "dec" + std::to_string(d);
     const std::string pp = "decoder." + std::to_string(d);
     const ParamInfo &Wr = b.par(pp + ".0.real_conv.weight"), &Wi = b.par(pp + ".0.imag_conv.weight");
     const ParamInfo &br = b.par(pp + ".0.real_conv.bias"), &bi = b.par(pp + ".0.imag_conv.bias");
     const int Co2 = Co / 2, Cin2 = (C0 + C1) / 2;
     const int64_t Rr = (int64_t)B * (T + 1) * Fo;
-    decy[d] = b.ws(nm + ".y", Rr * Co, adt);
+    decy[d] = b.ws(nm + ".y", Rr * Cob, adt);
     if (!last) { decz[d] = b.ws(nm + ".z", Rr * Co, adt); dec_mi[d] = b.ws(nm + ".mi", 2 * Co, DT_F32); }
     // reference input-channel index (within the real or imag half) of channel c of source s (complex_cat order)
     auto refc = [=](int s, int cc, bool& imag) {
@@ -583,6 +588,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       return s == 0 ? q : C0 / 2 + q;
     };
     std::function<int32_t(int, int, int, int, int)> wcoef = [=](int nn, int s, int cc, int kh, int kw) -> int32_t {
+      if (nn >= Co) return 0;                        // pad output channel
       bool ii;
       const int rc = refc(s, cc, ii);
       const bool oi = nn >= Co2;
@@ -592,7 +598,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       return ii ? pe(Wr, ix, 1) : pe(Wi, ix, 1);
     };
     std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) {
-      if (nn < Co2) { o[0] = pe(br, nn, 1); o[1] = pe(bi, nn, -1); }
+      if (nn >= Co) { o[0] = o[1] = 0; }
+      else if (nn < Co2) { o[0] = pe(br, nn, 1); o[1] = pe(bi, nn, -1); }
       else { o[0] = pe(br, nn - Co2, 1); o[1] = pe(bi, nn - Co2, 1); }
     };
     (void)Cin2;
@@ -613,7 +620,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         for (int kw = 0; kw < 2; ++kw) g.seg[g.nseg++] = Seg{s, -kw, par == 0 ? -src[s].C : 0, ntap * src[s].C, 0};
       }
       g.M = B * (T + 1) * Fi; g.Tout = T + 1; g.Fo = Fi;
-      g.N = Co;
+      g.N = Cob;
       Builder::layout_segs(g);
       const int c0 = C0, c1 = C1;
       Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
@@ -625,7 +632,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       };
       b.pack_weights(F, g, coef, nm + ".p" + std::to_string(par), 400 + d, par == 0 ? &bias : nullptr);
       if (par == 1) g.bias = dec[d].f[0].bias;
-      g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Co; g.y_tstride = Fo * Co; g.y_fstride = 2 * Co; g.y_off = par * Co;
+      g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Cob; g.y_tstride = Fo * Cob; g.y_fstride = 2 * Cob; g.y_off = par * Cob;
       if (!last && cfg.training) g.stats = b.mk(A_WS, part.off + (int64_t)par * nblk1 * 2 * g.Npad * 4);
       b.push(F, OP_RUNGEMM, 400 + d).g = g;
       dec[d].f[par] = g; dec[d].coef[par] = coef;
@@ -651,9 +658,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   Mask mk;
   std::memset(&mk, 0, sizeof(mk));
   {
-    const int Fo = Fe[0], Co = 2;
+    const int Fo = Fe[0], Co = std::max(2, CP);
     mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.dest = mk.dmask = b.none();
-    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt; mk.mch = 2; mk.estm = b.none();
+    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt; mk.mch = Co; mk.estm = b.none();
     mk.mask_fstride = (int64_t)Fo * Co; mk.mask_bstride = (int64_t)(T + 1) * Fo * Co; mk.mask_base = (int64_t)Fo * Co; mk.T = T;
     b.push(F, OP_MASK_FWD, 500).mask = mk;
   }
@@ -706,7 +713,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     std::vector<Ptr> d_decy(n), d_decz(n), d_skip(n), d_encz(n), d_ency(n);
     for (int d = 0; d < n; ++d) {
       const int idx = n - d;
-      const int Co = ch[idx - 1], Fo = 2 * Fe[idx];
+      const int Co = idx == 1 ? std::max(ch[idx - 1], CP) : ch[idx - 1], Fo = 2 * Fe[idx];
       d_decy[d] = b.ws("dec" + std::to_string(d) + ".dy", (int64_t)B * (T + 1) * Fo * Co, adt);
       if (idx != 1) d_decz[d] = b.ws("dec" + std::to_string(d) + ".dz", (int64_t)B * T * Fo * Co, adt);
     }
@@ -745,9 +752,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // ---- decoder backward
     for (int d = n - 1; d >= 0; --d) {
       const int idx = n - d;
-      const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
+      const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0;
       const int Fi = Fe[idx], Fo = 2 * Fi;
       const bool last = (idx == 1);
+      const int Co = last ? std::max(ch[idx - 1], CP) : ch[idx - 1];     // buffer channels (pad rows of the mask layer carry zero weights)
       const std::string nm = "dec" + std::to_string(d);
       const std::string pp = "decoder." + std::to_string(d);
       if (!last)

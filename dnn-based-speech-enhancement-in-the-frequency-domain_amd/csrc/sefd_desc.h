@@ -225,7 +225,8 @@ enum OpKind : int32_t {
   OP_LSTM_FWD, OP_LSTM_BWD, OP_COMBINE_FWD, OP_COMBINE_BWD, OP_MASK_FWD, OP_MASK_BWD, OP_OLA_FWD, OP_OLA_BWD,
   OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE, OP_MAGS,
   OP_CELL_FWD, OP_CELL_BWD, OP_DROPOUT_FWD, OP_DROPOUT_BWD, OP_FSN_IN, OP_FSN_SCALE, OP_FSN_SBSUM, OP_FSN_SBBUILD, OP_FSN_OUT,
-  OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY, OP_REFLECTPAD
+  OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY, OP_REFLECTPAD,
+  OP_SPECPAD        // Mags struct reused: spec fp32 [frames][NF][2] -> mags [frames][NF][MS] (dtype dt), channels 2..MS-1 zero (NF = slots here)
 };
 
 struct Op {

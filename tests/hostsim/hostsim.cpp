@@ -552,7 +552,7 @@ void run_op(const Op& op, const AB& ab) {
           if (slot >= 2) {
             const int64_t b = f / d.T, t = f % d.T;
             const int64_t mo = b * d.mask_bstride + t * d.mask_fstride + d.mask_base + (slot - 2) * d.mch;
-            const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch == 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
+            const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch >= 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
             const double sr = spec[i * 2], si = spec[i * 2 + 1];
             if (d.mode == 3) {
               emag = std::tanh(mr) * std::sqrt(sr * sr + si * si);
@@ -587,7 +587,7 @@ void run_op(const Op& op, const AB& ab) {
               const int64_t f = b * d.T + (u - lead);
               const int64_t s_ = (f * NS + k + 2) * 2;
               const double sr = spec[s_], si = spec[s_ + 1], der = dest[s_], dei = dest[s_ + 1];
-              const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch == 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
+              const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch >= 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
               if (d.mode == 3) {
                 const double tm = std::tanh(mr), ph = std::atan2(si, sr);
                 gr = (der * std::cos(ph) + dei * std::sin(ph)) * std::sqrt(sr * sr + si * si) * (1 - tm * tm);
@@ -607,7 +607,7 @@ void run_op(const Op& op, const AB& ab) {
               else { gr = der * sr; gi = dei * si; }
             }
             st(rp(ab, d.dmask), d.mdt, mo, (float)gr);
-            if (d.mch == 2) st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
+            if (d.mch >= 2) st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
           }
       break;
     }
@@ -660,6 +660,12 @@ void run_op(const Op& op, const AB& ab) {
             else if (d.accumulate) { est[e] += orr[o]; est[e + 1] += oi[o]; }
             else { est[e] = orr[o]; est[e + 1] = oi[o]; }
           }
+      break;
+    }
+    case OP_SPECPAD: {
+      const Mags& d = op.mags;
+      const float* spec = (const float*)rp(ab, d.spec);
+      for (int64_t i = 0; i < d.frames * d.NF * d.MS; ++i) { const int ch = (int)(i % d.MS); st(rp(ab, d.mags), d.dt, i, ch < 2 ? spec[(i / d.MS) * 2 + ch] : 0.f); }
       break;
     }
     case OP_MAGS: {

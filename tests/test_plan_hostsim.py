@@ -69,8 +69,10 @@ def test_hostsim_forward_backward_vs_oracle(mode, loss):
         assert rel_err(got, taps[f"enc{i}.out"]) < 2e-5, f"enc{i}.out"
     for d in range(6):
         idx = 6 - d
-        got = act_to_nchw(plan.view(ar, f"dec{d}.y"), B, T + 1, 2 * F[idx], ch[idx - 1])
-        assert rel_err(got, taps[f"dec{d}.conv"]) < 5e-5, f"dec{d}.conv"
+        cbuf = max(ch[idx - 1], 8) if d == 5 else ch[idx - 1]          # the mask layer's buffer is channel-padded to 8 (pad == 0)
+        got = act_to_nchw(plan.view(ar, f"dec{d}.y"), B, T + 1, 2 * F[idx], cbuf)
+        assert float(got[:, ch[idx - 1]:].abs().max()) == 0.0 if cbuf > ch[idx - 1] else True
+        assert rel_err(got[:, :ch[idx - 1]], taps[f"dec{d}.conv"]) < 5e-5, f"dec{d}.conv"
     assert rel_err(plan.io(ar, "out_wav", (B, L)), wav) < 5e-5
     assert rel_err(plan.io(ar, "out_real", (B, NF, T)), o_r) < 5e-5
     assert rel_err(plan.io(ar, "out_imag", (B, NF, T)), o_i) < 5e-5
