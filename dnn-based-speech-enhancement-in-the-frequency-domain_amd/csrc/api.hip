@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* est, cons
   const int b = blockIdx.y, blk = blockIdx.x;
   const float4* e4 = reinterpret_cast<const float4*>(est + (int64_t)b * L);
   const float4* t4 = reinterpret_cast<const float4*>(tgt + (int64_t)b * L);
-  const int n4 = L / 4;
+  const int n4 = (L % 4 == 0) ? L / 4 : 0;          // rows are 16-byte aligned only when L is a multiple of 4 (spectra: L = T = 483)
   float see = 0.f, set = 0.f, stt = 0.f;
   for (int i = blk * 256 + threadIdx.x; i < n4; i += kLossBlk * 256) {
     const float4 e = e4[i], t = t4[i];
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* est, cons
     set += e.x * t.x + e.y * t.y + e.z * t.z + e.w * t.w;
     stt += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
   }
-  if (blk == 0)
-    for (int i = n4 * 4 + threadIdx.x; i < L; i += 256) {
+  if (blk == 0 || n4 == 0)
+    for (int i = n4 * 4 + (n4 == 0 ? blk * 256 : 0) + threadIdx.x; i < L; i += (n4 == 0 ? kLossBlk * 256 : 256)) {
       const float e = est[(int64_t)b * L + i], t = tgt[(int64_t)b * L + i];
       see += e * e; set += e * t; stt += t * t;
     }

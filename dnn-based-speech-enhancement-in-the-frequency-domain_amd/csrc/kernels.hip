@@ -513,6 +513,8 @@ __global__ void mask_fwd_kernel(const Mask d, const ArenaBases ab) {
         er = em * cs; ei = em * sn;
       } else if (d.mode == 1) {
         er = sr * mr - si * mi; ei = sr * mi + si * mr;
+      } else if (d.mode == 4) {                  // 'Direct(None make)': spectral mapping, the decoder output IS the spectrum (models.py:232-250)
+        er = mr; ei = mi;
       } else {
         er = sr * mr; ei = si * mi;
       }
@@ -574,6 +576,8 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
         if (mm > 0.f) { gr += d_mm * mr / mm; gi += d_mm * mi / mm; }
       } else if (d.mode == 1) {
         gr = der * sr + dei * si; gi = -der * si + dei * sr;
+      } else if (d.mode == 4) {
+        gr = der; gi = dei;
       } else {
         gr = der * sr; gi = dei * si;
       }

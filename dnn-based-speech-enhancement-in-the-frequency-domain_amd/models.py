@@ -317,8 +317,6 @@ class DCCRN(_SefdModule):
 
     # ---- reference surface ----------------------------------------------------------------------------------
     def forward(self, inputs, targets=0):
-        if self.masking_mode == 'Direct(None make)':
-            raise NotImplementedError("Direct (spectral mapping) mode is not on the HIP path yet")
         if not inputs.is_cuda:
             raise RuntimeError("sefd DCCRN runs on the MI355X only (inputs must be a cuda tensor); there is no CPU fallback")
         inputs = inputs.float().contiguous()
@@ -328,6 +326,9 @@ class DCCRN(_SefdModule):
             self._flat_nbt += 1
         params = [p for _, p in self._trainable()]
         out_real, out_imag, out_wav = _DCCRNFunction.apply(self, rt, inputs, None, *params)
+        if self.masking_mode == 'Direct(None make)':            # spectral mapping (models.py:232-250): spectra of the target too
+            target_real, target_imag = self._stft_ref(targets)
+            return out_real, target_real, out_imag, target_imag, out_wav
         return out_real, out_imag, out_wav
 
     def loss(self, estimated, target, real_spec=0, img_spec=0, perceptual=False):

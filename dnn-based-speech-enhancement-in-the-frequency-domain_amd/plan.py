@@ -9,7 +9,7 @@ from . import _lib
 
 ARENA_WS, ARENA_PARAM, ARENA_GRAD, ARENA_STATE, ARENA_CONST, ARENA_IO, ARENA_COUNT = 0, 1, 2, 3, 4, 5, 6
 PHASE_FWD, PHASE_BWD = 0, 1
-MASK_MODES = {"E": 0, "C": 1, "R": 2}
+MASK_MODES = {"E": 0, "C": 1, "R": 2, "Direct(None make)": 4}
 DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 

@@ -78,3 +78,23 @@ def fullsubnet_train(model, optimizer, train_loader, DEVICE):
             optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
+
+
+def dccrn_direct_train(model, optimizer, train_loader, DEVICE):
+    """trainer.py:121-150 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra."""
+    train_loss = torch.zeros((), device=DEVICE)
+    batch_num = 0
+    model.train()
+    for inputs, targets in train_loader:
+        batch_num += 1
+        inputs = inputs.float().to(DEVICE)
+        targets = targets.float().to(DEVICE)
+        output_real, target_real, output_imag, target_imag, _ = model(inputs, targets)
+        real_loss = model.loss(output_real, target_real)
+        imag_loss = model.loss(output_imag, target_imag)
+        loss = (real_loss + imag_loss) / 2
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        train_loss += loss.detach()
+    return train_loss / max(batch_num, 1)

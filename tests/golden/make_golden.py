@@ -132,6 +132,30 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
     print(f"dccrn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
 
 
+def dccrn_direct_case(cfg, models, name, kernel_num, rnn_units, loss, B, L):
+    """dccrn_direct_train (trainer.py:121-150): spectral mapping, loss = (loss(real) + loss(imag)) / 2."""
+    cfg.dccrn_kernel_num = list(kernel_num)
+    cfg.masking_mode = "Direct(None make)"
+    cfg.loss = loss
+    cfg.perceptual = False
+    cfg.lstm = "complex"
+    cfg.skip_type = True
+    m = models.DCCRN(rnn_units=rnn_units, masking_mode="Direct(None make)")
+    fill_state_dict_(m)
+    m.train()
+    x, y = test_signals(B, L)
+    o_r, t_r, o_i, t_i, wav = m(x, y)
+    lossv = (m.loss(o_r, t_r) + m.loss(o_i, t_i)) / 2
+    lossv.backward()
+    g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    rec = dict(meta=dict(B=B, L=L), out_real=o_r.detach().numpy(), target_real=t_r.detach().numpy(), out_imag=o_i.detach().numpy(),
+               target_imag=t_i.detach().numpy(), out_wav=wav.detach().numpy(), loss=float(lossv),
+               grad_norm={k: float(v.double().norm()) for k, v in g.items()},
+               grad={k: v.numpy() for k, v in g.items() if SMALL_PARAMS(k)})
+    np.savez_compressed(os.path.join(HERE, f"dccrn_{name}.npz"), **flat(rec, "g"))
+    print(f"dccrn_{name}: loss {float(lossv):.6f}")
+
+
 def crn_case(cfg, models, name, kernel_num, rnn_units, rnn_input, mask, loss, B, L):
     cfg.dccrn_kernel_num = list(kernel_num)
     cfg.masking_mode = mask
@@ -273,6 +297,7 @@ def main():
     dccrn_case(cfg, models, "small_E_sisnr_lms", small, 128, "E", "SI-SNR", "LMS", 2, 4000, store_taps=False)
     dccrn_case(cfg, models, "default_E_sisnr", dflt, 256, "E", "SI-SNR", False, 2, 4000)
     dccrn_case(cfg, models, "default_C_sisnr_full", dflt, 256, "C", "SI-SNR", False, 1, 48000, store_taps=False)
+    dccrn_direct_case(cfg, models, "small_direct_mse", small, 128, "MSE", 2, 4000)
     crn_case(cfg, models, "default_E_mse", dflt, 256, 512, "E", "MSE", 2, 4000)
     crn_case(cfg, models, "small_E_sisnr", small, 128, 128, "E", "SI-SNR", 2, 4000)
     fsn_case(cfg, models, tfm, "default_mse", 2, 6000)

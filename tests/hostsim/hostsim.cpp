@@ -564,6 +564,7 @@ void run_op(const Op& op, const AB& ab) {
               const double em = std::tanh(mm) * mag;
               er = em * std::cos(ph + mph); ei = em * std::sin(ph + mph);
             } else if (d.mode == 1) { er = sr * mr - si * mi; ei = sr * mi + si * mr; }
+            else if (d.mode == 4) { er = mr; ei = mi; }
             else { er = sr * mr; ei = si * mi; }
           }
           est[i * 2] = (float)er; est[i * 2 + 1] = (float)ei;
@@ -604,6 +605,7 @@ void run_op(const Op& op, const AB& ab) {
                 d_mm += -(d_rp * mr + d_ip * mi) / (den * den);
                 if (mm > 0) { gr += d_mm * mr / mm; gi += d_mm * mi / mm; }
               } else if (d.mode == 1) { gr = der * sr + dei * si; gi = -der * si + dei * sr; }
+              else if (d.mode == 4) { gr = der; gi = dei; }
               else { gr = der * sr; gi = dei * si; }
             }
             st(rp(ab, d.dmask), d.mdt, mo, (float)gr);

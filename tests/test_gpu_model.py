@@ -313,3 +313,24 @@ def test_fullsubnet_fused_train_step_and_dropout():
     opt = Adam(m.parameters(), lr=1e-3)
     losses = [float(m.train_step(x.cuda(), y.cuda(), opt)) for _ in range(6)]      # dropout keep 0.2 active
     assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0]
+
+
+def test_dccrn_direct_mode_against_reference_golden():
+    """masking_mode 'Direct(None make)' + dccrn_direct_train's loss (trainer.py:135-138) on spectra [B, 257, T] (T = 43: unaligned rows)."""
+    g = load_golden("dccrn_small_direct_mse")
+    m = make_model((16, 32, 32, 64, 64, 64), 128, "Direct(None make)", "MSE")
+    m.train()
+    x, y = make_signals(2, 4000)
+    o_r, t_r, o_i, t_i, wav = m(x.cuda(), y.cuda())
+    lossv = (m.loss(o_r, t_r) + m.loss(o_i, t_i)) / 2
+    lossv.backward()
+    assert rel_err(o_r, g["g/out_real"]) < TOL and rel_err(o_i, g["g/out_imag"]) < TOL
+    assert rel_err(t_r, g["g/target_real"]) < TOL and rel_err(t_i, g["g/target_imag"]) < TOL and rel_err(wav, g["g/out_wav"]) < TOL
+    assert abs(float(lossv) - float(g["g/loss"])) < TOL * float(g["g/loss"])
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    for k, v in sub(g, "g/grad_norm").items():
+        if not noise_bias(k):
+            assert abs(float(grads[k].double().norm()) - float(v)) <= TOL * float(v) + 1e-7, k
+    for k, v in sub(g, "g/grad").items():
+        if not noise_bias(k):
+            assert rel_l2(grads[k], v) < (5e-3 if k.endswith(".2.weight") else TOL), k

@@ -159,3 +159,21 @@ def test_dccrn_full_length_forward():
     assert rel_err(o_r, g["g/out_real"]) < 5e-5
     assert rel_err(wav, g["g/out_wav"]) < 5e-5
     assert abs(float(-ol.si_snr(wav, y)) - float(g["g/loss"])) < 1e-4
+
+
+def test_dccrn_direct_mode_against_reference():
+    """Spectral mapping ('Direct(None make)', models.py:232-250) + dccrn_direct_train loss (trainer.py:135-138)."""
+    g = load_golden("dccrn_small_direct_mse")
+    cfg = DCCRNConfig(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128, masking_mode="Direct(None make)")
+    P = oracle_params(cfg)
+    x, y = make_signals(2, 4000)
+    Pg = {k: (v.clone().requires_grad_(True) if is_trainable(k) else v) for k, v in P.items()}
+    (o_r, t_r, o_i, t_i, wav), _ = dccrn_forward(Pg, x, cfg, targets=y, train=True)
+    lossv = (ol.main_loss("MSE", o_r, t_r) + ol.main_loss("MSE", o_i, t_i)) / 2
+    assert rel_err(o_r, g["g/out_real"]) < 2e-5 and rel_err(t_i, g["g/target_imag"]) < 2e-5 and rel_err(wav, g["g/out_wav"]) < 2e-5
+    assert abs(float(lossv) - float(g["g/loss"])) < 2e-5 * float(g["g/loss"])
+    names = [k for k in Pg if is_trainable(k)]
+    grads = dict(zip(names, torch.autograd.grad(lossv, [Pg[k] for k in names])))
+    for k, v in sub(g, "g/grad_norm").items():
+        if not (k.endswith("conv.bias") and not k.startswith("decoder.5.")):
+            assert abs(float(grads[k].double().norm()) - float(v)) <= 3e-4 * float(v) + 1e-7, k

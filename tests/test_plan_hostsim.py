@@ -42,7 +42,7 @@ def test_default_plan_matches_reference_param_count():
     assert plan.n_param == 3671053 - 0      # DCCRN default; buffers are not counted there
 
 
-@pytest.mark.parametrize("mode,loss", [("E", "SI-SNR"), ("C", "SDR"), ("R", "MSE")])
+@pytest.mark.parametrize("mode,loss", [("E", "SI-SNR"), ("C", "SDR"), ("R", "MSE"), ("Direct(None make)", "MSE")])
 def test_hostsim_forward_backward_vs_oracle(mode, loss):
     B, L = 2, 4000
     cfg = DCCRNConfig(masking_mode=mode, **SMALL)
@@ -58,7 +58,8 @@ def test_hostsim_forward_backward_vs_oracle(mode, loss):
     # ---- oracle forward with taps
     Pg = {k: (v.clone().requires_grad_(True) if is_trainable(k) else v.clone()) for k, v in P.items()}
     taps = {}
-    (o_r, o_i, wav), new_stats = dccrn_forward(Pg, x, cfg, targets=y, train=True, taps=taps)
+    outs, new_stats = dccrn_forward(Pg, x, cfg, targets=y, train=True, taps=taps)
+    o_r, o_i, wav = (outs[0], outs[2], outs[4]) if mode.startswith("Direct") else outs
     assert rel_err(spec_to_ref(plan.view(ar, "spec"), B, T, NF), taps["spec"]) < 1e-5
     ch = (2,) + SMALL["kernel_num"]
     F = [256 >> i for i in range(7)]
