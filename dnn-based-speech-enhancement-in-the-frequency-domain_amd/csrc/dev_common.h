@@ -60,6 +60,30 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// LDS-DMA issued as inline assembly.  With the builtin the compiler knows the instruction writes LDS and, unable to tell
+// the ring-buffer stages apart, puts s_waitcnt vmcnt(0) in front of every later ds_read - which serialises "issue the
+// next tile" with "read this tile" and removes all overlap.  As opaque asm the DMA is ordered by explicit counters only:
+// each thread issues a fixed number of DMAs per stage and waits with wait_vm<N>() for all but the newest N.
+// `lds_wave_base` (wave-uniform byte address) + lane * 16 is the destination.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "v"(gsrc)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// Wait until the oldest in-flight stage has landed: `rem` newer stages (at most S-2) of NL DMAs each may stay in flight.
+template <int NL, int S>
+__device__ __forceinline__ void wait_stage(int rem) {
+  if constexpr (S >= 4) { if (rem >= 2) { wait_vm<2 * NL>(); return; } }
+  if constexpr (S >= 3) { if (rem >= 1) { wait_vm<NL>(); return; } }
+  wait_vm<0>();
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -74,6 +98,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
+void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);
 void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);

@@ -8,6 +8,7 @@
 // The A operand is never materialised (no im2col): every A row is a handful of contiguous runs of the
 // channels-last activation tensor (see sefd_desc.h), gathered straight from HBM/L2 with 16-byte loads.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -88,7 +89,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // GLDS = true: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass,
 // which otherwise costs more LDS cycles than the fragment reads); padding chunks are fetched from a zero page, and the
 // XOR swizzle is applied on the SOURCE chunk index because the DMA destination is lane-linear (wave base + lane*16).
-template <typename TA, int BN, bool GLDS>
+template <typename TA, int BN, bool GLDS, int S = 2>
 __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int VEC = 16 / sizeof(TA);
   constexpr int BK = 8 * VEC;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   constexpr int BPASS = BN / 32;
   constexpr int TILE_BYTES = (BM + BN) * 128;
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[S * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -154,6 +155,10 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   const TA* rptr[4];
   int jlo[4], jhi[4];
   int seglen = 0, wseg = 0;
+  // per-source geometry in registers: indexing the by-value kernel argument with a run-time source id would turn into
+  // global loads from the kernarg segment inside the K loop
+  const int Tin0 = d.Tin[0], Tin1 = d.Tin[1], fs0 = d.fstride[0], fs1 = d.fstride[1], rl0 = d.rowlen[0], rl1 = d.rowlen[1];
+  const int64_t ts0 = d.tstride[0], ts1 = d.tstride[1];
   auto enter_run = [&](int sgi) {
     const Seg sg = d.seg[sgi];
     seglen = sg.len;
@@ -165,11 +170,11 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
       if (sg.src >= 0 && rv[p]) {
         const int s = sg.src;
         const int tt = ru[p] + sg.dt;
-        if (tt >= 0 && tt < d.Tin[s]) {
-          const int rr = sg.off + rfo[p] * d.fstride[s];
+        if (tt >= 0 && tt < (s ? Tin1 : Tin0)) {
+          const int rr = sg.off + rfo[p] * (s ? fs1 : fs0);
           lo = rr < 0 ? -rr : 0;
-          hi = min(sg.len, d.rowlen[s] - rr);
-          ptr = (s ? x1 : x0) + (s ? rb1[p] : rb0[p]) + (int64_t)tt * d.tstride[s] + rr;
+          hi = min(sg.len, (s ? rl1 : rl0) - rr);
+          ptr = (s ? x1 : x0) + (s ? rb1[p] : rb0[p]) + (int64_t)tt * (s ? ts1 : ts0) + rr;
           if ((reinterpret_cast<uintptr_t>(ptr) & 15) != 0) { lo |= 0x40000000; }   // unaligned run: element-wise path
         }
       }
@@ -234,32 +239,38 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   enter_run(0);
   if constexpr (GLDS) {
     const TA* zp = reinterpret_cast<const TA*>(rp(ab, d.zero));
-    const int wbase = __builtin_amdgcn_readfirstlane(wid) * 1024;        // this wave's 8 rows x 128 B inside each 32-row pass
-    auto dma = [&](char* As, char* Bs, int kk) {
+    const uint32_t lbase = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wid) * 1024;   // this wave's 8 rows x 128 B of each 32-row pass
+    constexpr int NL = 4 + BPASS;                      // DMAs per thread per stage
+    auto dma = [&](int stage, int kk) {
+      const uint32_t A = lbase + stage * TILE_BYTES, B = A + BM * 128;
       const int j0 = kk + csrc * VEC;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const TA* src = (j0 >= jlo[p] && j0 + VEC <= jhi[p]) ? rptr[p] + j0 : zp;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(As + wbase + p * 4096), 16, 0, 0);
+        dma16(src, A + p * 4096);
       }
 #pragma unroll
-      for (int p = 0; p < BPASS; ++p)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[p] + wseg + kk),
-                                         (__attribute__((address_space(3))) void*)(Bs + wbase + p * 4096), 16, 0, 0);
+      for (int p = 0; p < BPASS; ++p) dma16(wrow[p] + wseg + kk, B + p * 4096);
     };
-    dma(smem, smem + BM * 128, 0);
-    __syncthreads();                                   // waits for the DMA (vmcnt(0)) and publishes the tile
-    for (int kt = 0; kt < ntiles; ++kt) {
-      char* As = smem + (kt & 1) * TILE_BYTES;
-      char* An = smem + ((kt + 1) & 1) * TILE_BYTES;
+    // S-stage ring: the issue pointer runs S-1 K-tiles ahead of the MFMA loop; one LDS-only barrier per tile
+    int issued = 0, istage = 0;
+    auto issue_next = [&]() {
+      dma(istage, k0);
+      istage = istage + 1 == S ? 0 : istage + 1;
+      ++issued;
       k0 += BK;
-      if (kt + 1 < ntiles) {
-        if (k0 >= seglen) { k0 = 0; ++seg; enter_run(seg); }
-        dma(An, An + BM * 128, k0);                    // lands while this tile is multiplied; its buffer was last read in kt-1
-      }
+      if (k0 >= seglen && issued < ntiles) { k0 = 0; ++seg; enter_run(seg); }
+    };
+    for (int i = 0; i < S - 1; ++i)
+      if (issued < ntiles) issue_next();
+    int cstage = 0;
+    for (int kt = 0; kt < ntiles; ++kt) {
+      wait_stage<NL, S>(ntiles - 1 - kt);              // tile kt has landed (this thread's part)
+      lds_barrier();                                   // ... everyone's part; and stage kt-1 is no longer being read
+      if (issued < ntiles) issue_next();               // refills the stage read in kt-1
+      const char* As = smem + cstage * TILE_BYTES;
       compute(As, As + BM * 128);
-      __syncthreads();
+      cstage = cstage + 1 == S ? 0 : cstage + 1;
     }
   } else {
     issue_loads(0);
@@ -650,13 +661,13 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const uint16_t* tile, int col0, in
   return __builtin_bit_cast(bf16x8, f);
 }
 
-template <int TN>
+template <int TN, int S>
 __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int TK = kWgTK, RS = kWgRows;
   constexpr int NT = TN / 32;
   constexpr int DMASK = TN == 64 ? 3 : 7;
-  __shared__ __attribute__((aligned(16))) uint16_t dys[2][RS * TN];
-  __shared__ __attribute__((aligned(16))) uint16_t as[2][RS * TK];
+  __shared__ __attribute__((aligned(16))) uint16_t dys[S][RS * TN];
+  __shared__ __attribute__((aligned(16))) uint16_t as[S][RS * TK];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int ntile, ktile, split;
@@ -668,12 +679,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
   const uint16_t* onep = zp + 128;                 // second 256-byte page: bf16 (1, 0, 0, ...)
   float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)split * d.Npad * d.ldw;
 
-  const int nsteps_total = (d.M + RS - 1) / RS;
+  // Reduction rows are walked per batch item in steps of RS rows: step (b, s) covers rows q = RS*s .. RS*s+RS-1 of item b
+  // (q >= Tout*Fo reads the zero page).  With Fo a power of two the (frame, bin) of a row is then a per-thread constant plus
+  // a wave-uniform term, so one DMA address costs a handful of VALU instructions next to the 4 MFMAs it feeds.
+  const int Fo = d.Fo, Tout = d.Tout;
+  const int TF = Tout * Fo;
+  const int nb = d.M / TF;
+  const int spb = (TF + RS - 1) / RS;
+  const int nsteps_total = nb * spb;
   const int per = (nsteps_total + d.nsplit - 1) / d.nsplit;
   const int step0 = split * per;
   const int step1 = min(nsteps_total, step0 + per);
-  const int TF = d.Tout * d.Fo;
-  const int fsh = (d.Fo & (d.Fo - 1)) == 0 ? __ffs(d.Fo) - 1 : -1;
+  const int fsh = (Fo & (Fo - 1)) == 0 ? __ffs(Fo) - 1 : -1;
 
   // A tile: 16 chunks per row, thread -> (row ra + 16p, LDS position pa); it fetches source chunk qa = pa ^ ((row & 7) << 1)
   const int pa = tid & 15, ra = tid >> 4;
@@ -689,60 +706,103 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
   const bool a_real = sgi >= 0 && sg.src >= 0 && j0 + 8 <= sg.len;
   const bool a_ones = sgi >= 0 && sg.src < 0 && j0 == 0;
   const int asrc = sg.src > 0 ? 1 : 0;
-  const uint16_t* xs = asrc ? x1 : x0;
+  // geometry of this thread's source in registers (a run-time index into the by-value argument becomes kernarg loads in the loop)
+  const int a_Tin = asrc ? d.Tin[1] : d.Tin[0];
+  const int a_fstride = asrc ? d.fstride[1] : d.fstride[0];
+  const int a_rowlen = asrc ? d.rowlen[1] : d.rowlen[0];
+  const int64_t a_tstride = asrc ? d.tstride[1] : d.tstride[0];
+  const int64_t bs0 = d.bstride[0], bs1 = d.bstride[1], ts0 = d.tstride[0], ts1 = d.tstride[1];
+  const int fs0 = d.fstride[0], fs1 = d.fstride[1];
+  const uint16_t* xs_base = (asrc ? x1 + d.base[1] : x0 + d.base[0]) + sg.off + j0;
+  const int a_r0 = sg.off + j0;
+  const int a_dt = sg.dt;
+  // valid bins of this thread's chunk: 0 <= a_r0 + fo*fstride, a_r0 + fo*fstride + 8 <= rowlen
+  int flo = 0, fhi = Fo - 1;
+  if (a_fstride > 0) {
+    if (a_r0 < 0) flo = (-a_r0 + a_fstride - 1) / a_fstride;
+    const int room = a_rowlen - 8 - a_r0;
+    fhi = room < 0 ? -1 : min(Fo - 1, room / a_fstride);
+  } else if (a_r0 < 0 || a_r0 + 8 > a_rowlen) {
+    fhi = -1;
+  }
+  const unsigned fspan = fhi >= flo ? (unsigned)(fhi - flo) : 0u;
+  const bool a_any = a_real && fhi >= flo;
   // dy tile: TN/8 chunks per row
   constexpr int DCH = TN / 8;
   constexpr int DROWS = 256 / DCH;                 // rows per pass (16 or 32)
   constexpr int DPASS = RS / DROWS;
+  constexpr int NL = 2 + DPASS;                    // DMAs per thread per stage
   const int pd = tid % DCH, rd = tid / DCH;
   const int qd = pd ^ ((rd & DMASK) << 1);
   const int ncol = ntile * TN + qd * 8;
   const bool d_ok = ncol + 8 <= d.N;
+  const int64_t y_bstride = d.y_bstride, y_tstride = d.y_tstride, y_fstride = d.y_fstride;
+  const uint16_t* dy_base = dy + d.y_off + ncol;
 
-  struct RowPos { int b, q; };
-  auto init_pos = [&](int m) { RowPos r; r.b = m / TF; r.q = m - r.b * TF; return r; };
-  auto advance = [&](RowPos& r) { r.q += RS; while (r.q >= TF) { r.q -= TF; ++r.b; } };
-  RowPos apos[2], dpos[DPASS];
+  // per-thread constant part of each row (pow-2 Fo): row r of a step sits at frame u0 + ur, bin f0 + fr
+  int a_r[2], a_ur[2], a_fr[2], y_r[DPASS];
+  const uint16_t* a_tc[2];
+  const uint16_t* y_tc[DPASS];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) apos[p] = init_pos(step0 * RS + ra + 16 * p);
+  for (int p = 0; p < 2; ++p) {
+    const int r = ra + 16 * p;
+    a_r[p] = r;
+    a_ur[p] = (fsh >= 0 && Fo < RS) ? (r >> fsh) : 0;
+    a_fr[p] = (fsh >= 0 && Fo < RS) ? (r & (Fo - 1)) : r;
+    a_tc[p] = xs_base + (int64_t)(a_ur[p] + a_dt) * a_tstride + (int64_t)a_fr[p] * a_fstride;
+  }
 #pragma unroll
-  for (int p = 0; p < DPASS; ++p) dpos[p] = init_pos(step0 * RS + rd + DROWS * p);
-  const int wbase = __builtin_amdgcn_readfirstlane(wid) * 512;          // elements: this wave's 1 KiB inside each 4 KiB pass
+  for (int p = 0; p < DPASS; ++p) {
+    const int r = rd + DROWS * p;
+    y_r[p] = r;
+    const int ur = (fsh >= 0 && Fo < RS) ? (r >> fsh) : 0, fr = (fsh >= 0 && Fo < RS) ? (r & (Fo - 1)) : r;
+    y_tc[p] = dy_base + (int64_t)ur * y_tstride + (int64_t)fr * y_fstride;
+  }
+  const uint32_t wbase = __builtin_amdgcn_readfirstlane(wid) * 1024;   // bytes: this wave's 1 KiB inside each 4 KiB pass
+  const uint32_t as_l = lds_addr(&as[0][0]) + wbase, dys_l = lds_addr(&dys[0][0]) + wbase;
 
-  auto dma = [&](int buf, int step) {
+  int ib = step0 / spb, is = step0 - ib * spb;     // issue pointer (wave-uniform)
+  auto dma = [&](int stage) {
+    const int q0 = is * RS;
+    if (fsh >= 0) {
+      const int u0 = q0 >> fsh, f0 = q0 & (Fo - 1);
+      const int64_t o0 = (int64_t)ib * bs0 + (int64_t)u0 * ts0 + (int64_t)f0 * fs0;
+      const int64_t o1 = (int64_t)ib * bs1 + (int64_t)u0 * ts1 + (int64_t)f0 * fs1;
+      const int64_t oy = (int64_t)ib * y_bstride + (int64_t)u0 * y_tstride + (int64_t)f0 * y_fstride;
+      const int64_t oa = asrc ? o1 : o0;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int m = step * RS + ra + 16 * p;
-      const uint16_t* src = zp;
-      if (m < d.M) {
-        if (a_real) {
-          const int u = fsh >= 0 ? (apos[p].q >> fsh) : (apos[p].q / d.Fo);
-          const int fo = apos[p].q - u * d.Fo;
-          const int tt = u + sg.dt;
-          const int rr = sg.off + fo * d.fstride[asrc] + j0;
-          if (tt >= 0 && tt < d.Tin[asrc] && rr >= 0 && rr + 8 <= d.rowlen[asrc])
-            src = xs + (int64_t)apos[p].b * d.bstride[asrc] + d.base[asrc] + (int64_t)tt * d.tstride[asrc] + rr;
-        } else if (a_ones) {
-          src = onep;
-        }
+      for (int p = 0; p < 2; ++p) {
+        const bool rowv = q0 + a_r[p] < TF;
+        const bool v = a_any && rowv && (unsigned)(u0 + a_ur[p] + a_dt) < (unsigned)a_Tin &&
+                       (unsigned)(f0 + a_fr[p] - flo) <= fspan;
+        const uint16_t* src = v ? a_tc[p] + oa : ((a_ones && rowv) ? onep : zp);
+        dma16(src, as_l + stage * (RS * TK * 2) + p * 4096);
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(&as[buf][p * 2048 + wbase]), 16, 0, 0);
-      advance(apos[p]);
-    }
 #pragma unroll
-    for (int p = 0; p < DPASS; ++p) {
-      const int m = step * RS + rd + DROWS * p;
-      const uint16_t* src = zp;
-      if (m < d.M && d_ok) {
-        const int u = fsh >= 0 ? (dpos[p].q >> fsh) : (dpos[p].q / d.Fo);
-        const int fo = dpos[p].q - u * d.Fo;
-        src = dy + (int64_t)dpos[p].b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off + ncol;
+      for (int p = 0; p < DPASS; ++p) {
+        const uint16_t* src = (d_ok && q0 + y_r[p] < TF) ? y_tc[p] + oy : zp;
+        dma16(src, dys_l + stage * (RS * TN * 2) + p * 4096);
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(&dys[buf][p * 2048 + wbase]), 16, 0, 0);
-      advance(dpos[p]);
+    } else {                                         // general Fo: one division per row
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int q = q0 + a_r[p];
+        const int u = q / Fo, fo = q - u * Fo;
+        const bool rowv = q < TF;
+        const bool v = a_any && rowv && (unsigned)(u + a_dt) < (unsigned)a_Tin && (unsigned)(fo - flo) <= fspan;
+        const uint16_t* src = v ? xs_base + (int64_t)ib * (asrc ? bs1 : bs0) + (int64_t)(u + a_dt) * a_tstride + (int64_t)fo * a_fstride
+                                : ((a_ones && rowv) ? onep : zp);
+        dma16(src, as_l + stage * (RS * TK * 2) + p * 4096);
+      }
+#pragma unroll
+      for (int p = 0; p < DPASS; ++p) {
+        const int q = q0 + y_r[p];
+        const int u = q / Fo, fo = q - u * Fo;
+        const uint16_t* src = (d_ok && q < TF) ? dy_base + (int64_t)ib * y_bstride + (int64_t)u * y_tstride + (int64_t)fo * y_fstride : zp;
+        dma16(src, dys_l + stage * (RS * TN * 2) + p * 4096);
+      }
     }
+    if (++is == spb) { is = 0; ++ib; }
   };
 
   f32x4 acc[NT][4];
@@ -752,21 +812,26 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wn = (wid >> 1) * (TN / 2), wk = (wid & 1) * 64;
 
-  if (step0 < step1) dma(0, step0);
-  __syncthreads();
-  for (int st = step0; st < step1; ++st) {
-    const int buf = (st - step0) & 1;
-    if (st + 1 < step1) dma(buf ^ 1, st + 1);
+  // S-stage ring: DMA runs S-1 row steps ahead of the MFMAs; per step one vmcnt wait for the oldest stage + one LDS barrier
+  const int nst = step1 - step0;
+  int issued = 0, istage = 0;
+  for (int i = 0; i < S - 1; ++i)
+    if (issued < nst) { dma(istage); istage = istage + 1 == S ? 0 : istage + 1; ++issued; }
+  int cstage = 0;
+  for (int i = 0; i < nst; ++i) {
+    wait_stage<NL, S>(nst - 1 - i);
+    lds_barrier();
+    if (issued < nst) { dma(istage); istage = istage + 1 == S ? 0 : istage + 1; ++issued; }
     bf16x8 af[NT], bfr[4];
 #pragma unroll
-    for (int a = 0; a < NT; ++a) af[a] = tr_frag_swz<TN>(&dys[buf][0], wn + a * 16, lane);
+    for (int a = 0; a < NT; ++a) af[a] = tr_frag_swz<TN>(&dys[cstage][0], wn + a * 16, lane);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bfr[b] = tr_frag_swz<TK>(&as[buf][0], wk + b * 16, lane);
+    for (int b = 0; b < 4; ++b) bfr[b] = tr_frag_swz<TK>(&as[cstage][0], wk + b * 16, lane);
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-    __syncthreads();
+    cstage = cstage + 1 == S ? 0 : cstage + 1;
   }
 #pragma unroll
   for (int a = 0; a < NT; ++a)
@@ -781,15 +846,31 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Ring depth of the LDS-DMA pipelines.  SEFD_RG_STAGES / SEFD_WG_STAGES (2..4) override the defaults for tuning runs.
+static int env_stages(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return v >= 2 && v <= 4 ? v : dflt;
+}
+
+template <typename TA, int BN>
+static void launch_rungemm_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st, int grid) {
+  static const int stages = env_stages("SEFD_RG_STAGES", 2);
+  if (stages == 2) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2>), dim3(grid), dim3(256), 0, st, d, ab);
+  else if (stages == 3) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3>), dim3(grid), dim3(256), 0, st, d, ab);
+  else hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 4>), dim3(grid), dim3(256), 0, st, d, ab);
+}
+
 template <typename TA>
 static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   const int bn = bn_of(d.N);
   const int nm = (d.M + kBM - 1) / kBM;
   const int grid = nm * (d.Npad / bn);
   if (d.flags & kRunAligned) {
-    if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128, true>), dim3(grid), dim3(256), 0, st, d, ab);
-    else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64, true>), dim3(grid), dim3(256), 0, st, d, ab);
-    else hipLaunchKernelGGL((rungemm_kernel<TA, 32, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    if (bn == 128) launch_rungemm_dma<TA, 128>(d, ab, st, grid);
+    else if (bn == 64) launch_rungemm_dma<TA, 64>(d, ab, st, grid);
+    else launch_rungemm_dma<TA, 32>(d, ab, st, grid);
     return;
   }
   if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128, false>), dim3(grid), dim3(256), 0, st, d, ab);
@@ -802,15 +883,19 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   else launch_rungemm_t<float>(d, ab, st);
 }
 
+template <int TN>
+static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  static const int stages = env_stages("SEFD_WG_STAGES", 4);
+  dim3 grid(((d.Npad + TN - 1) / TN) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
+  if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 2>), grid, dim3(256), 0, st, d, ab);
+  else if (stages == 3) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 3>), grid, dim3(256), 0, st, d, ab);
+  else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 4>), grid, dim3(256), 0, st, d, ab);
+}
+
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (d.xdt == DT_BF16 && (d.flags & kRunAligned)) {
-    if (d.Npad >= 128) {
-      dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128>), grid, dim3(256), 0, st, d, ab);
-    } else {
-      dim3 grid(((d.Npad + 63) / 64) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
-      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<64>), grid, dim3(256), 0, st, d, ab);
-    }
+    if (d.Npad >= 128) launch_wgrad_dma<128>(d, ab, st);
+    else launch_wgrad_dma<64>(d, ab, st);
     return;
   }
   if (d.xdt == DT_BF16) {

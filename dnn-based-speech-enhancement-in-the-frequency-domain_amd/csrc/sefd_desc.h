@@ -183,6 +183,13 @@ struct Memset {
   Ptr dst;
   int64_t bytes;
 };
+// Fused STFT: framing + window + 512-point FFT in LDS, one wavefront per frame (radix 8x8x8, two LDS transposes).
+// frame (b, t) reads src[b][t*hop - off + n], n < 512 (0 outside [0, L)), times win[n]; writes bins 0..256 to the slot layout
+// spec [B][T][258][2] (slot 0 = 0).  tw: fp32 (cos, sin)(2 pi k / 512), k < 512 ; win: fp32 [512]  (both A_CONST).
+struct StftFft {
+  Ptr src, spec, tw, win;
+  int32_t B, L, T, hop, off, pad_;
+};
 // torch.stft(center=True, pad_mode='reflect'): dst[b][i] = src[b][reflect(i - pad)], i < L + 2*pad
 struct ReflectPad {
   Ptr src, dst;
@@ -226,7 +233,8 @@ enum OpKind : int32_t {
   OP_SPECOUT_FWD, OP_SPECOUT_BWD, OP_MEMSET, OP_SPLITSUM, OP_BN_BWD_FINALIZE, OP_MAGS,
   OP_CELL_FWD, OP_CELL_BWD, OP_DROPOUT_FWD, OP_DROPOUT_BWD, OP_FSN_IN, OP_FSN_SCALE, OP_FSN_SBSUM, OP_FSN_SBBUILD, OP_FSN_OUT,
   OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY, OP_REFLECTPAD,
-  OP_SPECPAD        // Mags struct reused: spec fp32 [frames][NF][2] -> mags [frames][NF][MS] (dtype dt), channels 2..MS-1 zero (NF = slots here)
+  OP_SPECPAD,       // Mags struct reused: spec fp32 [frames][NF][2] -> mags [frames][NF][MS] (dtype dt), channels 2..MS-1 zero (NF = slots here)
+  OP_STFT_FFT
 };
 
 struct Op {
@@ -251,6 +259,7 @@ struct Op {
     Dropout drop;
     Fsn fsn;
     ReflectPad rpad;
+    StftFft fft;
   };
 };
 

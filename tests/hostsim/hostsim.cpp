@@ -78,14 +78,29 @@ void wgrad(const RunGemm& d, const AB& ab) {
   float* part = (float*)rp(ab, d.w);
   const int TF = d.Tout * d.Fo;
   const int64_t sz = (int64_t)d.Npad * d.ldw;
-  const int nsteps = (d.M + kWgRows - 1) / kWgRows;
+  // The LDS-DMA bf16 kernel walks the rows per batch item (steps of kWgRows rows, the last step of an item padded); the
+  // other kernels walk the flat row index.  The per-split partials are compared, so the partition is mirrored here.
+  const bool per_item = d.xdt == DT_BF16 && (d.flags & kRunAligned);
+  const int nb = d.M / TF;
+  const int spb = (TF + kWgRows - 1) / kWgRows;
+  const int nsteps = per_item ? nb * spb : (d.M + kWgRows - 1) / kWgRows;
   const int per = (nsteps + d.nsplit - 1) / d.nsplit;
   std::vector<double> acc(sz);
   std::vector<double> arow(d.ldw);
   for (int sp = 0; sp < d.nsplit; ++sp) {
     std::fill(acc.begin(), acc.end(), 0.0);
-    const int m0 = sp * per * kWgRows, m1 = std::min<int64_t>(d.M, (int64_t)(sp + 1) * per * kWgRows);
-    for (int m = m0; m < m1; ++m) {
+    const int st0 = sp * per, st1 = std::min(nsteps, (sp + 1) * per);
+    for (int stp = st0; stp < st1; ++stp)
+    for (int r = 0; r < kWgRows; ++r) {
+      int m;
+      if (per_item) {
+        const int b = stp / spb, q = (stp - b * spb) * kWgRows + r;
+        if (q >= TF) continue;
+        m = b * TF + q;
+      } else {
+        m = stp * kWgRows + r;
+        if (m >= d.M) continue;
+      }
       const int b = m / TF, rem = m % TF, u = rem / d.Fo, fo = rem % d.Fo;
       std::fill(arow.begin(), arow.end(), 0.0);
       for (int s = 0; s < d.nseg; ++s)
@@ -259,6 +274,25 @@ bool run_fsn(const Op& op, const AB& ab) {
       for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.F * 2; ++i) {
         const int cch = (int)(i & 1); const int64_t q = i >> 1; const int64_t bf = q % ((int64_t)d.B * d.F); const int t = (int)(q / ((int64_t)d.B * d.F));
         st(rp(ab, d.out), d.dt, i, t >= d.LA ? g[(bf * d.T + (t - d.LA)) * 2 + cch] : 0.f);
+      }
+      return true;
+    }
+    case OP_STFT_FFT: {
+      const StftFft& d = op.fft;
+      const float* src = (const float*)rp(ab, d.src);
+      const float* win = (const float*)rp(ab, d.win);
+      float* spec = (float*)rp(ab, d.spec);
+      std::vector<double> v(512);
+      for (int64_t fr = 0; fr < (int64_t)d.B * d.T; ++fr) {
+        const int64_t b = fr / d.T; const int t = (int)(fr % d.T);
+        for (int n = 0; n < 512; ++n) { const int p = t * d.hop - d.off + n; v[n] = (p >= 0 && p < d.L) ? (double)src[b * d.L + p] * win[n] : 0.0; }
+        float* o = spec + fr * 516;
+        o[0] = o[1] = 0.f;
+        for (int k = 0; k <= 256; ++k) {
+          double re = 0, im = 0;
+          for (int n = 0; n < 512; ++n) { const double a = 2.0 * 3.14159265358979323846 * (double)((k * n) % 512) / 512.0; re += v[n] * std::cos(a); im -= v[n] * std::sin(a); }
+          o[2 * (k + 1)] = (float)re; o[2 * (k + 1) + 1] = (float)im;
+        }
       }
       return true;
     }
