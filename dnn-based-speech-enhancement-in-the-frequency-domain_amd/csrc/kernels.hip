@@ -4,6 +4,7 @@
 //   lstm_fwd / lstm_bwd        persistent recurrence, W_hh resident in VGPRs as MFMA B-fragments, h exchanged through LDS
 //   combine, mask, ola, specout  complex-LSTM glue, cRM application (E/C/R), overlap-add + clamp, layout conversion
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -31,12 +32,55 @@ __global__ void pack_kernel(const Pack d, const ArenaBases ab) {
   }
 }
 
-__global__ void splitsum_kernel(const Unpack d, const ArenaBases ab) {
-  float* part = reinterpret_cast<float*>(rp(ab, d.part));
+__global__ void packmulti_kernel(const PackMulti m, const ArenaBases ab) {
+  const Pack d = reinterpret_cast<const Pack*>(rp(ab, m.entries))[blockIdx.y];
+  const int32_t* tab = reinterpret_cast<const int32_t*>(rp(ab, d.tab));
+  const float* src = reinterpret_cast<const float*>(rp(ab, d.src));
+  char* dst = rp(ab, d.dst);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = part[i];
-    for (int k = 1; k < d.nsplit; ++k) s += part[k * d.sstride + i];
-    part[i] = s;
+    float v = 0.f;
+    for (int e = 0; e < d.width; ++e) {
+      const int32_t t = tab[i * d.width + e];
+      if (t > 0) v += src[t - 1];
+      else if (t < 0) v -= src[-t - 1];
+    }
+    st_elem(dst, d.ddt, i, v);
+  }
+}
+
+// Sum of the nsplit row-split partials of a WGRAD (deterministic order).  A workgroup owns 64 consecutive elements:
+// 16 lanes x float4 along the elements, 16 lanes along the splits (thin layers have 768 splits of only 8 K elements, so
+// parallelism has to come from the split axis), then a fixed-order 16-way combine through LDS.
+__global__ __launch_bounds__(256) void splitsum_kernel(const Unpack d, const ArenaBases ab) {
+  __shared__ float4 red[16][16];
+  float* part = reinterpret_cast<float*>(rp(ab, d.part));
+  const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
+  const bool vec = (d.n & 3) == 0 && (d.sstride & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < d.n; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + ex * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {
+      if (i < d.n)
+        for (int k = sy; k < d.nsplit; k += 16) {
+          const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)k * d.sstride + i);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    } else {
+      float* sp = &s.x;
+      for (int e = 0; e < 4; ++e)
+        if (i + e < d.n)
+          for (int k = sy; k < d.nsplit; k += 16) sp[e] += part[(int64_t)k * d.sstride + i + e];
+    }
+    red[sy][ex] = s;
+    __syncthreads();
+    if (sy == 0) {
+      float4 t = red[0][ex];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) { const float4 v = red[j][ex]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      if (vec) { if (i < d.n) *reinterpret_cast<float4*>(part + i) = t; }
+      else { const float* tp = &t.x; for (int e = 0; e < 4; ++e) if (i + e < d.n) part[i + e] = tp[e]; }
+    }
+    __syncthreads();
   }
 }
 
@@ -739,8 +783,10 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
   switch (op.kind) {
     case OP_PACK:
       hipLaunchKernelGGL(pack_kernel, dim3(grid_for(op.pack.n)), dim3(256), 0, st, op.pack, ab); break;
+    case OP_PACKMULTI:
+      hipLaunchKernelGGL(packmulti_kernel, dim3(128, op.packm.count), dim3(256), 0, st, op.packm, ab); break;
     case OP_SPLITSUM:
-      hipLaunchKernelGGL(splitsum_kernel, dim3(grid_for(op.unpack.n)), dim3(256), 0, st, op.unpack, ab); break;
+      hipLaunchKernelGGL(splitsum_kernel, dim3((unsigned)std::min<int64_t>((op.unpack.n + 63) / 64, 8192)), dim3(256), 0, st, op.unpack, ab); break;
     case OP_UNPACK:
       hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(op.unpack.n)), dim3(256), 0, st, op.unpack, ab); break;
     case OP_BN_FINALIZE:

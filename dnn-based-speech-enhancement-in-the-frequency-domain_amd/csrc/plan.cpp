@@ -134,6 +134,25 @@ struct Builder {
     }
   }
 
+  // Fused FFT STFT (stft_fft.hip) for fft_len == 512: frame t reads src[t*hop - off + j] * win[j], j < W.  Returns false
+  // (caller plans the framing GEMM instead) for other transform sizes.
+  bool stft_fft(std::vector<Op>& ops, int tag, Ptr src, Ptr spec, int B, int L, int T, int hop, int off, int NFFT,
+                const std::vector<double>& win) {
+    if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM")) return false;
+    if (fft_tw.arena < 0) {
+      std::vector<float> tw(1024);
+      for (int k = 0; k < 512; ++k) { tw[2 * k] = (float)std::cos(2.0 * kPi * k / 512.0); tw[2 * k + 1] = (float)std::sin(2.0 * kPi * k / 512.0); }
+      fft_tw = cst(tw.data(), 4096);
+    }
+    std::vector<float> wf(512, 0.f);
+    for (size_t j = 0; j < win.size(); ++j) wf[j] = (float)win[j];
+    Op& op = push(ops, OP_STFT_FFT, tag);
+    op.fft.src = src; op.fft.spec = spec; op.fft.tw = fft_tw; op.fft.win = cst(wf.data(), 2048);
+    op.fft.B = B; op.fft.L = L; op.fft.T = T; op.fft.hop = hop; op.fft.off = off; op.fft.pad_ = 0;
+    return true;
+  }
+  Ptr fft_tw = Ptr{-1, 0, 0};
+
   // WGRAD for the layer whose forward descriptor is `f` (same A runs + a ones run) against upstream gradient `dy`.
   void wgrad(std::vector<Op>& ops, const RunGemm& f, Ptr dy, const Coef& coef, int tag,
              const std::function<void(int n, int32_t out[2])>* bias) {
@@ -146,9 +165,14 @@ struct Builder {
     g.y = dy;
     g.bias = none();
     g.stats = none();
-    const int tiles = (int)(rup(g.Npad, kWgTN) / kWgTN * rup(g.ldw, kWgTK) / kWgTK);
+    // Row splits: every workgroup of a WGRAD launch does the same amount of work, so the grid is sized to fill the
+    // co-resident slots of the 256 CUs in ONE wave of workgroups and never spill a few stragglers into a second one
+    // (the 4-stage bf16 kernel keeps 64 KiB (128-wide n tile) or 48 KiB (64-wide) of LDS: 2 or 3 workgroups per CU).
+    const int tn = (g.xdt == DT_BF16 && g.Npad >= 128) ? 128 : kWgTN;
+    const int slots = g.xdt == DT_BF16 ? (tn == 128 ? 512 : 768) : 768;
+    const int tiles = (int)(rup(g.Npad, tn) / tn * rup(g.ldw, kWgTK) / kWgTK);
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
-    int ns = (768 + tiles - 1) / tiles;
+    int ns = std::max(1, slots / tiles);
     ns = std::max(1, std::min(ns, std::max(1, steps / 4)));
     g.nsplit = ns;
     const int64_t sz = (int64_t)g.Npad * g.ldw;
@@ -240,6 +264,23 @@ void finalize_rungemms(Builder& b, Plan* P) {
              g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
       g.flags = (g.flags & ~kRunAligned) | (ok ? kRunAligned : 0);
     }
+  // weight repacking: one launch per phase instead of one per matrix (71 launches of ~5 us in a DCCRN step)
+  for (auto* ops : {&P->fwd, &P->bwd}) {
+    std::vector<Pack> packs;
+    std::vector<Op> rest;
+    for (Op& op : *ops) {
+      if (op.kind == OP_PACK) packs.push_back(op.pack); else rest.push_back(op);
+    }
+    if (packs.size() < 2) continue;
+    Op m;
+    std::memset(&m, 0, sizeof(m));
+    m.kind = OP_PACKMULTI;
+    m.tag = 1;
+    m.packm.entries = b.cst(packs.data(), (int64_t)packs.size() * sizeof(Pack));
+    m.packm.count = (int32_t)packs.size();
+    rest.insert(rest.begin(), m);
+    ops->swap(rest);
+  }
 }
 
 }  // namespace
@@ -380,7 +421,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // ------------------------------------------------------------------ STFT (ConvSTFT.forward, tools_for_model.py:54-61)
   Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
   Ptr spec_lp = spec;
-  {
+  if (!b.stft_fft(F, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win)) {
     RunGemm g = Builder::gemm0();
     g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
     g.bstride[0] = L; g.tstride[0] = 0; g.base[0] = 0; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
@@ -1045,7 +1086,9 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   // ---- STFT of the noisy input and of the target (CRN.forward always does both, models.py:468, 505)
   Ptr spec = b.ws("spec", BT * SW, DT_F32);
   Ptr spec_t = b.ws("spec_t", BT * SW, DT_F32);
-  {
+  if (b.stft_fft(F, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win)) {
+    b.stft_fft(F, 2, io_tgt, spec_t, B, L, T, hop, trim, NFFT, win);
+  } else {
     RunGemm g = Builder::gemm0();
     g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
     g.bstride[0] = L; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
@@ -1478,6 +1521,7 @@ Plan* build_frontend_plan(const ModelConfig& cfg) {
   std::vector<double> win(W);
   for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
   Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
+  if (!b.stft_fft(P->fwd, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win)) {
   RunGemm g = Builder::gemm0();
   g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
   g.bstride[0] = L; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
@@ -1496,6 +1540,7 @@ Plan* build_frontend_plan(const ModelConfig& cfg) {
   }
   g.y = spec; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
   b.push(P->fwd, OP_RUNGEMM, 1).g = g;
+  }
   SpecOut so;
   std::memset(&so, 0, sizeof(so));
   so.est = spec; so.out_real = io_or; so.out_imag = io_oi; so.B = B; so.T = T; so.NF = NF;

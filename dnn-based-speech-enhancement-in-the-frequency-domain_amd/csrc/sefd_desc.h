@@ -75,6 +75,13 @@ struct Pack {
   int32_t ddt, width;
 };
 
+// All PACK ops of one phase merged into one launch (they read only A_PARAM, so they can all run first): `entries` is an
+// array of `count` Pack descriptors in A_CONST; workgroup row y serves entry y.
+struct PackMulti {
+  Ptr entries;
+  int32_t count, pad_;
+};
+
 // SPLITSUM: part[0][i] = sum_s part[s*sstride + i]   (in place, fixed order -> deterministic)
 // UNPACK:   grad[j] = sum_{e in [start[j], start[j+1])} sign(ent[e]) * src[|ent[e]|-1]    (CSR table in A_CONST)
 struct Unpack {
@@ -234,7 +241,8 @@ enum OpKind : int32_t {
   OP_CELL_FWD, OP_CELL_BWD, OP_DROPOUT_FWD, OP_DROPOUT_BWD, OP_FSN_IN, OP_FSN_SCALE, OP_FSN_SBSUM, OP_FSN_SBBUILD, OP_FSN_OUT,
   OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY, OP_REFLECTPAD,
   OP_SPECPAD,       // Mags struct reused: spec fp32 [frames][NF][2] -> mags [frames][NF][MS] (dtype dt), channels 2..MS-1 zero (NF = slots here)
-  OP_STFT_FFT
+  OP_STFT_FFT,
+  OP_PACKMULTI
 };
 
 struct Op {
@@ -260,6 +268,7 @@ struct Op {
     Fsn fsn;
     ReflectPad rpad;
     StftFft fft;
+    PackMulti packm;
   };
 };
 

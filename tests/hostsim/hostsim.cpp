@@ -73,6 +73,19 @@ void rungemm(const RunGemm& d, const AB& ab) {
   }
 }
 
+void pack(const Pack& d, const AB& ab) {
+  const int32_t* tab = (const int32_t*)rp(ab, d.tab);
+  const float* src = (const float*)rp(ab, d.src);
+  for (int64_t i = 0; i < d.n; ++i) {
+    float v = 0.f;
+    for (int e = 0; e < d.width; ++e) {
+      const int32_t t = tab[i * d.width + e];
+      if (t > 0) v += src[t - 1]; else if (t < 0) v -= src[-t - 1];
+    }
+    st(rp(ab, d.dst), d.ddt, i, v);
+  }
+}
+
 void wgrad(const RunGemm& d, const AB& ab) {
   const char* dy = rp(ab, d.y);
   float* part = (float*)rp(ab, d.w);
@@ -334,18 +347,10 @@ void run_op(const Op& op, const AB& ab) {
   switch (op.kind) {
     case OP_RUNGEMM: rungemm(op.g, ab); break;
     case OP_WGRAD: wgrad(op.g, ab); break;
-    case OP_PACK: {
-      const Pack& d = op.pack;
-      const int32_t* tab = (const int32_t*)rp(ab, d.tab);
-      const float* src = (const float*)rp(ab, d.src);
-      for (int64_t i = 0; i < d.n; ++i) {
-        float v = 0.f;
-        for (int e = 0; e < d.width; ++e) {
-          const int32_t t = tab[i * d.width + e];
-          if (t > 0) v += src[t - 1]; else if (t < 0) v -= src[-t - 1];
-        }
-        st(rp(ab, d.dst), d.ddt, i, v);
-      }
+    case OP_PACK: pack(op.pack, ab); break;
+    case OP_PACKMULTI: {
+      const Pack* e = (const Pack*)rp(ab, op.packm.entries);
+      for (int i = 0; i < op.packm.count; ++i) pack(e[i], ab);
       break;
     }
     case OP_SPLITSUM: {
