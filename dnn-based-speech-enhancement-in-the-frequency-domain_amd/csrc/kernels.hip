@@ -357,7 +357,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_kernel(const LstmRec d, con
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        gxv[q][r] = gx[(rowbt[r] + t) * d.gx_ld + q * H + unit];     // rows >= B alias row 0, never stored
+        gxv[q][r] = gx[(rowbt[r] + t) * d.gx_ld + gate_col(q, unit)];     // rows >= B alias row 0, never stored
   };
   load_gx(0);
   const int64_t GBT = (int64_t)d.B * T;
@@ -389,10 +389,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_kernel(const LstmRec d, con
       if (rvalid[r]) {
         const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
         st_elem(hout, d.hdt, row * H + unit, h);
-        gates[row * 4 * H + 0 * H + unit] = ig;
-        gates[row * 4 * H + 1 * H + unit] = fg;
-        gates[row * 4 * H + 2 * H + unit] = gg;
-        gates[row * 4 * H + 3 * H + unit] = og;
+        *reinterpret_cast<float4*>(gates + (row * H + unit) * 4) = make_float4(ig, fg, gg, og);
         cs[row * H + unit] = c[r];
       }
     }
@@ -441,7 +438,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
     for (int r = 0; r < 4; ++r) {
       const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) g4[r][q] = gates[row * 4 * H + q * H + unit];      // rows >= B alias row 0, results unused
+      for (int q = 0; q < 4; ++q) g4[r][q] = gates[(row * H + unit) * 4 + q];      // rows >= B alias row 0, results unused
       cp[r] = cs[(row - (t > 0 ? 1 : 0)) * H + unit];
       dhv[r] = dh[row * H + unit];
     }
@@ -467,10 +464,10 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
         dg = dc * ig * (1.f - gg * gg);
         dcarry[r] = dc * fg;
         const int64_t o = d.gx_goff[g] + (rowbt[r] + t) * d.gx_ld;
-        st_elem(dgo, d.gdt, o + unit, di);
-        st_elem(dgo, d.gdt, o + H + unit, df);
-        st_elem(dgo, d.gdt, o + 2 * H + unit, dg);
-        st_elem(dgo, d.gdt, o + 3 * H + unit, dog);
+        st_elem(dgo, d.gdt, o + gate_col(0, unit), di);
+        st_elem(dgo, d.gdt, o + gate_col(1, unit), df);
+        st_elem(dgo, d.gdt, o + gate_col(2, unit), dg);
+        st_elem(dgo, d.gdt, o + gate_col(3, unit), dog);
       }
       float* lrow = lds + (4 * kq + r) * gs;
       lrow[unit] = di; lrow[H + unit] = df; lrow[2 * H + unit] = dg; lrow[3 * H + unit] = dog;

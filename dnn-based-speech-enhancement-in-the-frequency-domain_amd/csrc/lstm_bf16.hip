@@ -54,30 +54,29 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
   }
   float c[4] = {0.f, 0.f, 0.f, 0.f};
-  // gate pre-activations are prefetched TWO steps ahead: one step (~1 us) does not cover an HBM round trip under load
-  float gxv[4][4], gx1[4][4], gx2[4][4];
-  auto load_gx = [&](int t, float (&dst)[4][4]) {
-    const int tc = t < T ? t : T - 1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[q][r] = gx[(rowbt[r] + tc) * d.gx_ld + q * H + unit];   // rows >= B alias row 0, never stored
-  };
-  load_gx(0, gxv);
-  load_gx(1, gx1);
+  // The step loop is issue-bound (two waves per SIMD, ~300 instructions per step before this layout): the four gates of a
+  // (row, unit) cell are adjacent in gx and in the saved gates (sefd_desc.h gate_col), so a lane moves a cell with ONE 16-byte
+  // load and ONE 16-byte store, addresses advance by constants, and the two-step prefetch ring is unrolled (no copies).
   const int64_t GBT = (int64_t)d.B * T;
-  for (int t = 0; t < T; ++t) {
+  const float* gxp[4];                          // gx of (row r, this unit), current prefetch position
+  int64_t so[4];                                // (g*GBT + row*T + t) * H + unit : element offset of the cell in h / c, x4 in gates
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    gxp[r] = gx + rowbt[r] * d.gx_ld + gate_col(0, unit);            // rows >= B alias row 0, never stored
+    so[r] = ((int64_t)g * GBT + rowbt[r]) * H + unit;
+  }
+  const int64_t gx_ld = d.gx_ld;
+  auto load_gx = [&](int t, float4 (&dst)[4]) {                        // t is clamped: the last two prefetches re-read step T-1
+    const int64_t inc = t < T - 1 ? gx_ld : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dst[r] = *reinterpret_cast<const float4*>(gxp[r]); gxp[r] += inc; }
+  };
+  auto step = [&](int t, const float4 (&cur)[4], float4 (&pre)[4]) {
     f32x4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][r] = gxv[q][r];
-    load_gx(t + 2, gx2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { gxv[q][r] = gx1[q][r]; gx1[q][r] = gx2[q][r]; }
-    const int hp = (t & 1) * 16 * hs;            // LDS offsets, not pointers: keeps the accesses in the LDS address space (ds_*, not flat_*)
+    for (int r = 0; r < 4; ++r) { acc[0][r] = cur[r].x; acc[1][r] = cur[r].y; acc[2][r] = cur[r].z; acc[3][r] = cur[r].w; }
+    load_gx(t + 2, pre);                        // gate pre-activations two steps ahead: one step does not cover an HBM round trip
+    const int hp = (t & 1) * 16 * hs;           // LDS offsets, not pointers: keeps the accesses in the LDS address space (ds_*, not flat_*)
     if (t > 0) {
 #pragma unroll
       for (int ks = 0; ks < HMAX / 32; ++ks) {
@@ -97,17 +96,25 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
       const uint16_t hb = f2bf(og * tanhf_(c[r]));
       ldsh[hn + (4 * kq + r) * hs + unit] = hb;
       if (rvalid[r]) {
-        const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
-        hout[row * H + unit] = hb;
-        gates[row * 4 * H + unit] = ig;
-        gates[row * 4 * H + H + unit] = fg;
-        gates[row * 4 * H + 2 * H + unit] = gg;
-        gates[row * 4 * H + 3 * H + unit] = og;
-        cs[row * H + unit] = c[r];
+        hout[so[r]] = hb;
+        *reinterpret_cast<float4*>(gates + so[r] * 4) = make_float4(ig, fg, gg, og);
+        cs[so[r]] = c[r];
       }
+      so[r] += H;
     }
     lds_barrier();
+  };
+  float4 b0v[4], b1v[4], b2v[4];
+  load_gx(0, b0v);
+  load_gx(1, b1v);
+  int t = 0;
+  for (; t + 3 <= T; t += 3) {
+    step(t, b0v, b2v);
+    step(t + 1, b1v, b0v);
+    step(t + 2, b2v, b1v);
   }
+  if (t < T) { step(t, b0v, b2v); ++t; }
+  if (t < T) { step(t, b1v, b0v); ++t; }
 }
 
 template <int HMAX>
@@ -121,64 +128,75 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
   const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates));
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
   const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
-  char* dgo = rp(ab, d.dgates);
+  uint16_t* dgo = reinterpret_cast<uint16_t*>(rp(ab, d.dgates));
   constexpr int gs = 4 * H + 8;
   const int unit = 16 * w + (lane & 15);
   const int kq = lane >> 4;
   constexpr int KS = 4 * H / 32;
 
-  uint4 wreg[HMAX / 8];                       // B[k = n][j = unit] = W_hh[n][unit], n = 32*ks + 8*kq + e
+  // B[k = gate column][j = unit] = W_hh[torch row of that column][unit]; the LDS tile (and dgates in memory) use the
+  // unit-major gate-column order of sefd_desc.h, the parameter keeps PyTorch's gate-major rows
+  uint4 wreg[HMAX / 8];
 #pragma unroll
   for (int ks = 0; ks < HMAX / 8; ++ks) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (ks < KS) {
       float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = whh[(int64_t)(32 * ks + 8 * kq + e) * H + unit];
+      for (int e = 0; e < 8; ++e) f[e] = whh[(int64_t)gate_torch_row(32 * ks + 8 * kq + e, H) * H + unit];
       v = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
     }
     wreg[ks] = v;
   }
   bool rvalid[4];
-  int64_t rowbt[4];
+  int64_t fo[4];                                // fetch position: (g*GBT + row*T + t) * H + unit
+  const int64_t GBT = (int64_t)d.B * T;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + 4 * kq + r;
     rvalid[r] = b < d.B;
-    rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
+    fo[r] = ((int64_t)g * GBT + (int64_t)(rvalid[r] ? b : 0) * T + (T - 1)) * H + unit;   // rows >= B alias row 0, results unused
   }
-  const int64_t GBT = (int64_t)d.B * T;
+  // dgates_t leave through the LDS tile with 16-byte stores: 16 rows x H/2 chunks = 2 chunks per thread (rows w', w'+8)
+  constexpr int CPR = H / 2;
+  const int crow = threadIdx.x / CPR, cc8 = threadIdx.x % CPR;
+  uint16_t* dptr[2];
+  bool dvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int b = b0 + crow + 8 * i;
+    dvalid[i] = b < d.B;
+    dptr[i] = dgo + d.gx_goff[g] + ((int64_t)(dvalid[i] ? b : 0) * T + (T - 1)) * d.gx_ld + cc8 * 8;
+  }
+  const int64_t gx_ld = d.gx_ld;
+
   float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
-  // software prefetch: the saved activations of step t-1 are fetched while step t computes (all addresses are known)
-  float pg[4][4], pct[4], pcp[4], pdh[4];       // gates i,f,g,o ; c_t ; c_{t-1} ; upstream dh   for the current step
-  float ng[4][4], ncp[4], ndh[4];               // the same for step t-1
-  float mg[4][4], mcp[4], mdh[4];               // ... and for step t-2 (two steps of look-ahead cover the HBM latency)
-  auto fetch = [&](int t_, float (&g4)[4][4], float (&cp)[4], float (&dhv)[4]) {
-    const int t = t_ > 0 ? t_ : 0;
+  // software prefetch ring, two steps of look-ahead (one step does not cover an HBM round trip); unrolled, no copies
+  struct Sav { float4 g[4]; float cp[4], dh[4]; };
+  auto fetch = [&](int t_, Sav& s) {            // reads the current position, then steps back one frame (stays at frame 0)
+    const int64_t back = t_ > 0 ? H : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t row = (int64_t)g * GBT + rowbt[r] + t;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) g4[r][q] = gates[row * 4 * H + q * H + unit];      // rows >= B alias row 0, results unused
-      cp[r] = cs[(row - (t > 0 ? 1 : 0)) * H + unit];
-      dhv[r] = dh[row * H + unit];
+      s.g[r] = *reinterpret_cast<const float4*>(gates + fo[r] * 4);
+      s.cp[r] = cs[fo[r] - back];
+      s.dh[r] = dh[fo[r]];
+      fo[r] -= back;
     }
   };
-  fetch(T - 1, pg, pcp, pdh);
-  fetch(T - 2, ng, ncp, ndh);
+  float pct[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pct[r] = cs[((int64_t)g * GBT + rowbt[r] + T - 1) * H + unit];
-  for (int t = T - 1; t >= 0; --t) {
-    fetch(t - 2, mg, mcp, mdh);
+  for (int r = 0; r < 4; ++r) pct[r] = cs[fo[r]];
+  auto step = [&](int t, const Sav& cur, Sav& pre) {
+    fetch(t - 2, pre);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float di = 0.f, df = 0.f, dg = 0.f, dog = 0.f;
       if (rvalid[r]) {
-        const float ig = pg[r][0], fg = pg[r][1], gg = pg[r][2], og = pg[r][3];
+        const float ig = cur.g[r].x, fg = cur.g[r].y, gg = cur.g[r].z, og = cur.g[r].w;
         const float ct = pct[r];
-        const float cp = t > 0 ? pcp[r] : 0.f;
-        const float dht = pdh[r] + dhrec[r];
+        const float cp = t > 0 ? cur.cp[r] : 0.f;
+        const float dht = cur.dh[r] + dhrec[r];
         const float tc = tanhf_(ct);
         dog = dht * tc * og * (1.f - og);
         const float dc = dht * og * (1.f - tc * tc) + dcarry[r];
@@ -187,22 +205,14 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
         dg = dc * ig * (1.f - gg * gg);
         dcarry[r] = dc * fg;
       }
-      uint16_t* lrow = ldsh + (4 * kq + r) * gs;
-      lrow[unit] = f2bf(di); lrow[H + unit] = f2bf(df); lrow[2 * H + unit] = f2bf(dg); lrow[3 * H + unit] = f2bf(dog);
+      pct[r] = cur.cp[r];                       // c_{t-1} is the cell state of the next (earlier) step
+      *reinterpret_cast<uint2*>(ldsh + (4 * kq + r) * gs + gate_col(0, unit)) = make_uint2(pack2(di, df), pack2(dg, dog));
     }
     lds_barrier();
-    // dgates_t leave through the LDS tile with 16-byte stores (2 per thread) instead of sixteen 2-byte stores per lane
-    {
-      constexpr int CPR = 4 * H / 8;                       // 16-byte chunks per row
-      for (int ch = threadIdx.x; ch < 16 * CPR; ch += HMAX * 4) {
-        const int row = ch / CPR, c8 = ch - row * CPR;
-        const int b = b0 + row;
-        if (b < d.B) {
-          const uint4 v = *reinterpret_cast<const uint4*>(ldsh + row * gs + c8 * 8);
-          uint16_t* dst = reinterpret_cast<uint16_t*>(dgo) + d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld + c8 * 8;
-          *reinterpret_cast<uint4*>(dst) = v;
-        }
-      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (dvalid[i]) *reinterpret_cast<uint4*>(dptr[i]) = *reinterpret_cast<const uint4*>(ldsh + (crow + 8 * i) * gs + cc8 * 8);
+      dptr[i] -= gx_ld;
     }
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
@@ -217,15 +227,19 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
       }
     }
     dhrec = a0 + a1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pct[r] = pcp[r]; pcp[r] = ncp[r]; pdh[r] = ndh[r];
-      ncp[r] = mcp[r]; ndh[r] = mdh[r];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { pg[r][q] = ng[r][q]; ng[r][q] = mg[r][q]; }
-    }
     lds_barrier();
+  };
+  Sav s0, s1, s2;
+  fetch(T - 1, s0);
+  fetch(T - 2, s1);
+  int t = T - 1;
+  for (; t >= 2; t -= 3) {
+    step(t, s0, s2);
+    step(t - 1, s1, s0);
+    step(t - 2, s2, s1);
   }
+  if (t >= 0) { step(t, s0, s2); --t; }
+  if (t >= 0) { step(t, s1, s0); --t; }
 }
 
 template <int HMAX>

@@ -526,7 +526,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     ls[l].cst = b.ws(nm + ".c", 4 * BT * H, DT_F32);
     ls[l].hc = b.ws(nm + ".hc", BT * 2 * H, adt);
     std::function<void(int, int32_t*)> bias = [=](int nn, int32_t* o) {
-      const int set = nn / (4 * H), gq = nn % (4 * H);
+      const int set = nn / (4 * H), gq = gate_torch_row(nn % (4 * H), H);
       o[0] = pe(*bih[set], gq, 1); o[1] = pe(*bhh[set], gq, 1);
     };
     ls[l].bgx = bias;
@@ -545,7 +545,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       g.N = 8 * H;
       Builder::layout_segs(g);
       Builder::Coef coef = [=](int nn, int s, int j) -> int32_t {
-        const int set = nn / (4 * H), gq = nn % (4 * H);
+        const int set = nn / (4 * H), gq = gate_torch_row(nn % (4 * H), H);
         const int feat = (l == 0) ? j * D + s : j;      // reference feature order c*D + d (models.py:203-206)
         return pe(*Wih[set], (int64_t)gq * I + feat, 1);
       };
@@ -890,7 +890,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         Builder::layout_segs(f);
         f.y_bstride = (int64_t)T * 8 * H; f.y_tstride = 8 * H; f.y_off = set * 4 * H;
         const ParamInfo* Wp = Whh[set];
-        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)nn * H + j, 1); };
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
         Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);
         b.wgrad(R, f, dyp, coef, 200 + l, nullptr);
       }
@@ -1168,7 +1168,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   Ptr cbuf = b.ws("lstm.c", BT * H, DT_F32);
   RunGemm ggx = Builder::gemm0();
   Builder::Coef cgx;
-  std::function<void(int, int32_t*)> bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, nn, 1); o[1] = pe(bhh, nn, 1); };
+  std::function<void(int, int32_t*)> bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, gate_torch_row(nn, H), 1); o[1] = pe(bhh, gate_torch_row(nn, H), 1); };
   {
     RunGemm& g = ggx;
     g.x[0] = encz[n - 1]; g.xdt = adt; g.ydt = DT_F32;
@@ -1178,7 +1178,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
     for (int dd = 0; dd < D; ++dd) g.seg[dd] = Seg{0, 0, dd * Cl, Cl, 0};
     g.N = 4 * H;
     Builder::layout_segs(g);
-    cgx = [=](int nn, int s, int j) -> int32_t { return pe(Wih, (int64_t)nn * hid + (j * D + s), 1); };
+    cgx = [=](int nn, int s, int j) -> int32_t { return pe(Wih, (int64_t)gate_torch_row(nn, H) * hid + (j * D + s), 1); };
     b.pack_weights(F, g, cgx, "lstm.ih", 200, &bgx);
     g.y = gxb; g.y_bstride = (int64_t)T * 4 * H; g.y_tstride = 4 * H;
     b.push(F, OP_RUNGEMM, 200).g = g;
@@ -1443,7 +1443,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
       f.N = 4 * H;
       Builder::layout_segs(f);
       f.y_bstride = (int64_t)T * 4 * H; f.y_tstride = 4 * H;
-      Builder::Coef chh = [=](int nn, int sg, int j) -> int32_t { return pe(Whh, (int64_t)nn * H + j, 1); };
+      Builder::Coef chh = [=](int nn, int sg, int j) -> int32_t { return pe(Whh, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
       b.wgrad(R, f, dgates, chh, 200, nullptr);
       for (int q = 0; q < D; ++q) {            // dX into the encoder-output gradient, one slice per frequency row d
         RunGemm g = Builder::gemm0();

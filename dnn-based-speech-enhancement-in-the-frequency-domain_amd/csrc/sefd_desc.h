@@ -130,6 +130,12 @@ struct BnBwdApply {            // FINALIZE: partials -> totals [3][C] + paramete
 // h    [G][B][T][H]   (dtype hdt) ; gates [G][B][T][4H] fp32 post-activation ; c [G][B][T][H] fp32
 // Row (b,t) of group g:  gx  at gx  + gx_goff[g]  + (b*T+t)*gx_ld   (fp32, 4H wide)
 //                        dgates at dgates + gx_goff[g] + (b*T+t)*gx_ld (dtype gdt, 4H wide)
+// Gate-column order of gx / dgates (inside a group's 4H block) and of the saved gates [rows][H][4]: the four gates
+// (q = 0 i, 1 f, 2 g, 3 o) of one hidden unit are adjacent, column = unit*4 + q, so an LSTM lane moves a (row, unit) cell
+// with one 16-byte access.  PyTorch keeps gate-major rows: weight_ih / weight_hh / bias row of that column = q*H + unit.
+static inline constexpr int gate_col(int q, int unit) { return unit * 4 + q; }
+static inline constexpr int gate_torch_row(int col, int H) { return (col & 3) * H + (col >> 2); }
+
 struct LstmRec {
   Ptr gx, whh[2], h, gates, c;
   Ptr dh, dgates;              // backward: dh [G][B][T][H] upstream (fp32) ; dgates out (same addressing as gx)

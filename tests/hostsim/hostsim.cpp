@@ -497,7 +497,7 @@ void run_op(const Op& op, const AB& ab) {
             for (int j = 0; j < H; ++j) {
               double pre[4];
               for (int q = 0; q < 4; ++q) {
-                double s = gx[q * H + j];
+                double s = gx[gate_col(q, j)];
                 const float* wr = whh.data() + (int64_t)(q * H + j) * H;
                 for (int k = 0; k < H; ++k) s += h[k] * wr[k];
                 pre[q] = s;
@@ -505,8 +505,8 @@ void run_op(const Op& op, const AB& ab) {
               const double ig = 1 / (1 + std::exp(-pre[0])), fg = 1 / (1 + std::exp(-pre[1])), gg = std::tanh(pre[2]), og = 1 / (1 + std::exp(-pre[3]));
               c[j] = fg * c[j] + ig * gg;
               hn[j] = og * std::tanh(c[j]);
-              gates[row * 4 * H + j] = (float)ig; gates[row * 4 * H + H + j] = (float)fg;
-              gates[row * 4 * H + 2 * H + j] = (float)gg; gates[row * 4 * H + 3 * H + j] = (float)og;
+              float* gq = gates + (row * H + j) * 4;
+              gq[0] = (float)ig; gq[1] = (float)fg; gq[2] = (float)gg; gq[3] = (float)og;
               cs[row * H + j] = (float)c[j];
             }
             for (int j = 0; j < H; ++j) {
@@ -533,7 +533,8 @@ void run_op(const Op& op, const AB& ab) {
           for (int t = T - 1; t >= 0; --t) {
             const int64_t row = ((int64_t)g * d.B + b) * T + t;
             for (int j = 0; j < H; ++j) {
-              const double ig = gates[row * 4 * H + j], fg = gates[row * 4 * H + H + j], gg = gates[row * 4 * H + 2 * H + j], og = gates[row * 4 * H + 3 * H + j];
+              const float* gq = gates + (row * H + j) * 4;
+              const double ig = gq[0], fg = gq[1], gg = gq[2], og = gq[3];
               const double ct = cs[row * H + j], cp = t > 0 ? cs[(row - 1) * H + j] : 0.0;
               const double dht = dh[row * H + j] + dhrec[j];
               const double tc = std::tanh(ct);
@@ -545,7 +546,7 @@ void run_op(const Op& op, const AB& ab) {
               dc[j] = dcv * fg;
             }
             const int64_t o = d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld;
-            for (int k = 0; k < 4 * H; ++k) st(rp(ab, d.dgates), d.gdt, o + k, (float)dg[k]);
+            for (int k = 0; k < 4 * H; ++k) st(rp(ab, d.dgates), d.gdt, o + gate_col(k / H, k % H), (float)dg[k]);
             for (int j = 0; j < H; ++j) {
               double s = 0;
               if (t > 0) for (int k = 0; k < 4 * H; ++k) s += (d.hdt == DT_BF16 ? (double)bf2f(f2bf((float)dg[k])) : dg[k]) * whh[(int64_t)k * H + j];
