@@ -263,6 +263,11 @@ void finalize_rungemms(Builder& b, Plan* P) {
         ok = ok && g.xdt == DT_BF16 && g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&
              g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
       g.flags = (g.flags & ~kRunAligned) | (ok ? kRunAligned : 0);
+      if (op.kind == OP_RUNGEMM) {
+        const bool ya = g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&
+                        g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
+        g.flags = (g.flags & ~kRunYAligned) | (ya ? kRunYAligned : 0);
+      }
     }
   // weight repacking: one launch per phase instead of one per matrix (71 launches of ~5 us in a DCCRN step)
   for (auto* ops : {&P->fwd, &P->bwd}) {

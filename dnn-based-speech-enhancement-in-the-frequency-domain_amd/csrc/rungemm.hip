@@ -89,16 +89,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // GLDS = true: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass,
 // which otherwise costs more LDS cycles than the fragment reads); padding chunks are fetched from a zero page, and the
 // XOR swizzle is applied on the SOURCE chunk index because the DMA destination is lane-linear (wave base + lane*16).
-template <typename TA, int BN, bool GLDS, int S = 2>
-__global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
+template <typename TA, int BN, bool GLDS, int S = 2, int BM = kBM, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int VEC = 16 / sizeof(TA);
   constexpr int BK = 8 * VEC;
-  constexpr int BM = kBM;
+  constexpr int PR = NW * 8;                   // rows per load pass (8 threads per 128-byte row)
+  constexpr int RP = BM / PR;                  // A-row passes per thread (rows r0 + PR*p)
   constexpr int WN_ = BN == 128 ? 2 : 1;      // waves along N
-  constexpr int WM_ = 4 / WN_;                 // waves along M
+  constexpr int WM_ = NW / WN_;                // waves along M
   constexpr int MI = BM / (32 * WM_);
   constexpr int NI = BN / (32 * WN_);
-  constexpr int BPASS = BN / 32;
+  constexpr int BPASS = BN / PR;
   constexpr int TILE_BYTES = (BM + BN) * 128;
 
   __shared__ __attribute__((aligned(16))) char smem[S * TILE_BYTES];
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
 
   // ---- per-thread load assignment: chunk column c, rows r0 + 32p
   const int c = tid & 7, r0 = tid >> 3;
-  int64_t rb0[4], rb1[4];
-  int ru[4], rfo[4];
-  bool rv[4];
+  int64_t rb0[RP], rb1[RP];
+  int ru[RP], rfo[RP];
+  bool rv[RP];
   const int TF = d.Tout * d.Fo;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int m = mtile * BM + r0 + 32 * p;
+  for (int p = 0; p < RP; ++p) {
+    const int m = mtile * BM + r0 + PR * p;
     rv[p] = m < d.M;
     const int mm = rv[p] ? m : 0;
     const int b = mm / TF, rem = mm - b * TF;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   const int csrc = GLDS ? (c ^ ((r0 >> 1) & 7)) : c;       // chunk of the K-tile this thread fetches
   const TA* wrow[BPASS];
 #pragma unroll
-  for (int p = 0; p < BPASS; ++p) wrow[p] = w + (int64_t)(ntile * BN + r0 + 32 * p) * d.ldw + csrc * VEC;
+  for (int p = 0; p < BPASS; ++p) wrow[p] = w + (int64_t)(ntile * BN + r0 + PR * p) * d.ldw + csrc * VEC;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   int ntiles = 0;
   for (int s = 0; s < d.nseg; ++s) ntiles += (d.seg[s].len + BK - 1) / BK;
 
-  const TA* rptr[4];
-  int jlo[4], jhi[4];
+  const TA* rptr[RP];
+  int jlo[RP], jhi[RP];
   int seglen = 0, wseg = 0;
   // per-source geometry in registers: indexing the by-value kernel argument with a run-time source id would turn into
   // global loads from the kernarg segment inside the K loop
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
     seglen = sg.len;
     wseg = sg.koff;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < RP; ++p) {
       int lo = 0, hi = 0;
       const TA* ptr = x0;
       if (sg.src >= 0 && rv[p]) {
@@ -181,11 +182,11 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
       rptr[p] = ptr; jlo[p] = lo; jhi[p] = hi;
     }
   };
-  uint4 aReg[4], bReg[BPASS];
+  uint4 aReg[RP], bReg[BPASS];
   auto issue_loads = [&](int kk) {
     const int j0 = kk + c * VEC;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < RP; ++p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (j0 >= jlo[p] && j0 + VEC <= jhi[p]) {
         v = *reinterpret_cast<const uint4*>(rptr[p] + j0);
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
     for (int p = 0; p < BPASS; ++p) bReg[p] = *reinterpret_cast<const uint4*>(wrow[p] + wseg + kk);
   };
   // LDS offsets: the swizzle term ((row >> 1) & 7) is the same for all of a thread's rows (row strides are multiples of 16)
-  int woff[4];
+  int woff[RP > BPASS ? RP : BPASS];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) woff[p] = swz_off(r0 + 32 * p, c);
+  for (int p = 0; p < (RP > BPASS ? RP : BPASS); ++p) woff[p] = swz_off(r0 + PR * p, c);
   const int rsw = ((lane & 31) >> 1) & 7;
   int chs[4];
 #pragma unroll
@@ -239,18 +240,18 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   enter_run(0);
   if constexpr (GLDS) {
     const TA* zp = reinterpret_cast<const TA*>(rp(ab, d.zero));
-    const uint32_t lbase = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wid) * 1024;   // this wave's 8 rows x 128 B of each 32-row pass
-    constexpr int NL = 4 + BPASS;                      // DMAs per thread per stage
+    const uint32_t lbase = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wid) * 1024;   // this wave's 8 rows x 128 B of each pass
+    constexpr int NL = RP + BPASS;                      // DMAs per thread per stage
     auto dma = [&](int stage, int kk) {
       const uint32_t A = lbase + stage * TILE_BYTES, B = A + BM * 128;
       const int j0 = kk + csrc * VEC;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < RP; ++p) {
         const TA* src = (j0 >= jlo[p] && j0 + VEC <= jhi[p]) ? rptr[p] + j0 : zp;
-        dma16(src, A + p * 4096);
+        dma16(src, A + p * (PR * 128));
       }
 #pragma unroll
-      for (int p = 0; p < BPASS; ++p) dma16(wrow[p] + wseg + kk, B + p * 4096);
+      for (int p = 0; p < BPASS; ++p) dma16(wrow[p] + wseg + kk, B + p * (PR * 128));
     };
     // S-stage ring: the issue pointer runs S-1 K-tiles ahead of the MFMA loop; one LDS-only barrier per tile
     int issued = 0, istage = 0;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
       char* As = smem + (kt & 1) * TILE_BYTES;
       char* Bs = As + BM * 128;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(As + woff[p]) = aReg[p];
+      for (int p = 0; p < RP; ++p) *reinterpret_cast<uint4*>(As + woff[p]) = aReg[p];
 #pragma unroll
       for (int p = 0; p < BPASS; ++p) *reinterpret_cast<uint4*>(Bs + woff[p]) = bReg[p];
       __syncthreads();
@@ -296,6 +297,10 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
   // ---- epilogue: row address table in LDS, bias, store, BatchNorm partial statistics
   int64_t* rowoff = reinterpret_cast<int64_t*>(smem);              // [BM]
   float* stat = reinterpret_cast<float*>(smem + BM * 8);           // [WM_][BN][2]
+  uint16_t* otile = reinterpret_cast<uint16_t*>(smem + BM * 8 + WM_ * BN * 8);   // [BM][OS] bf16 staging tile (kRunYAligned)
+  constexpr int OS = BN + 8;                                       // row stride in elements: 16-byte aligned rows, rotating banks
+  constexpr bool kCanStage = BM * 8 + WM_ * BN * 8 + BM * OS * 2 <= S * TILE_BYTES;
+  const bool staged = kCanStage && (d.flags & kRunYAligned) && !(d.flags & kRunAccum);
   if (tid < BM) {
     const int m = mtile * BM + tid;
     int64_t o = -1;
@@ -315,20 +320,36 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
     const int n = ntile * BN + nl;
     const float bv = (bias && n < d.N) ? bias[n] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    if (staged) {
+      // bf16 output through LDS: the 32x32 accumulator layout gives every lane ONE column, i.e. 2-byte global stores in
+      // 64-byte pieces; staged, the tile leaves as whole 16-byte chunks of contiguous rows (8x fewer store instructions)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int64_t o = rowoff[row];
-        float v = acc[i][j][e] + bv;
-        if (o >= 0 && n < d.N) {
-          if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yb)[o + n];
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          float v = acc[i][j][e] + bv;
           if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
-          if (d.ydt == DT_BF16) reinterpret_cast<uint16_t*>(yb)[o + n] = f2bf(v);
-          else reinterpret_cast<float*>(yb)[o + n] = v;
-          s1 += v;
-          s2 += v * v;
+          otile[row * OS + nl] = f2bf(v);
+          if (mtile * BM + row < d.M && n < d.N) { s1 += v; s2 += v * v; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int64_t o = rowoff[row];
+          float v = acc[i][j][e] + bv;
+          if (o >= 0 && n < d.N) {
+            if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yb)[o + n];
+            if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
+            if (d.ydt == DT_BF16) reinterpret_cast<uint16_t*>(yb)[o + n] = f2bf(v);
+            else reinterpret_cast<float*>(yb)[o + n] = v;
+            s1 += v;
+            s2 += v * v;
+          }
         }
       }
     }
@@ -341,18 +362,38 @@ __global__ __launch_bounds__(256) void rungemm_kernel(const RunGemm d, const Are
       }
     }
   }
+  if (staged) {
+    __syncthreads();
+    constexpr int CPR = BN / 8;                                    // 16-byte chunks per tile row
+    for (int q = tid; q < BM * CPR; q += NW * 64) {
+      const int row = q / CPR, cc = q - row * CPR;
+      const int64_t o = rowoff[row];
+      const int n0 = ntile * BN + cc * 8;
+      if (o >= 0 && n0 < d.N)                                      // N % 8 == 0 here: a chunk is all valid or all padding
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
+    }
+  }
   if (want_stats) {
     __syncthreads();
     if (tid < BN) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int wmi = 0; wmi < WM_; ++wmi) {
-        s1 += stat[(wmi * BN + tid) * 2 + 0];
-        s2 += stat[(wmi * BN + tid) * 2 + 1];
-      }
+      // one row of partials per kBM (= 128) output rows, whatever the tile height: the planner sizes `stats` that way
+      constexpr int HALVES = BM / kBM, WMH = WM_ / HALVES;
       float* part = reinterpret_cast<float*>(rp(ab, d.stats));
-      part[((int64_t)mtile * 2 + 0) * d.Npad + ntile * BN + tid] = s1;
-      part[((int64_t)mtile * 2 + 1) * d.Npad + ntile * BN + tid] = s2;
+      const int nrows = (d.M + kBM - 1) / kBM;
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int wmi = h * WMH; wmi < (h + 1) * WMH; ++wmi) {
+          s1 += stat[(wmi * BN + tid) * 2 + 0];
+          s2 += stat[(wmi * BN + tid) * 2 + 1];
+        }
+        const int srow = mtile * HALVES + h;
+        if (srow < nrows) {
+          part[((int64_t)srow * 2 + 0) * d.Npad + ntile * BN + tid] = s1;
+          part[((int64_t)srow * 2 + 1) * d.Npad + ntile * BN + tid] = s2;
+        }
+      }
     }
   }
 }
@@ -857,6 +898,21 @@ static int env_stages(const char* name, int dflt) {
 template <typename TA, int BN>
 static void launch_rungemm_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st, int grid) {
   static const int stages = env_stages("SEFD_RG_STAGES", 2);
+  static const int tall = getenv("SEFD_RG_BM") ? atoi(getenv("SEFD_RG_BM")) : 128;
+  if constexpr (sizeof(TA) == 2 && BN == 128) {
+    // 256 x 128 tile, 8 waves, 3-stage ring (144 KiB LDS, one workgroup per CU): the weight tile is shared by twice the
+    // rows, 25 % fewer operand bytes per MAC than two 128 x 128 workgroups, same waves per CU
+    if (tall == 256 && d.M >= 256 * 512) {
+      const int nm2 = (d.M + 255) / 256;
+      hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3, 256, 8>), dim3(nm2 * (d.Npad / BN)), dim3(512), 0, st, d, ab);
+      return;
+    }
+    if (tall == 257 && d.M >= 256 * 512) {           // same tile, 2-stage ring
+      const int nm2 = (d.M + 255) / 256;
+      hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2, 256, 8>), dim3(nm2 * (d.Npad / BN)), dim3(512), 0, st, d, ab);
+      return;
+    }
+  }
   if (stages == 2) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2>), dim3(grid), dim3(256), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3>), dim3(grid), dim3(256), 0, st, d, ab);
   else hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 4>), dim3(grid), dim3(256), 0, st, d, ab);

@@ -66,6 +66,7 @@ struct RunGemm {
 constexpr int kRunAligned = 1;   // LDS-DMA loader usable
 constexpr int kRunAccum = 2;     // y += result (fp32 y): recurrent term added onto the hoisted input GEMM / gradient accumulation
 constexpr int kRunRelu = 4;      // y = max(result, 0)
+constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chunks: the tile is staged through LDS and stored wide
 
 // PACK: dst[i] = sum_{e < width} sign(tab[i*width+e]) * src[|tab[i*width+e]|-1]   (entry 0 -> nothing).  Table int32 in A_CONST.
 // width 1: packed conv / LSTM weights ; width 2: combined biases (b_r - b_i | b_r + b_i), (b_ih + b_hh).
