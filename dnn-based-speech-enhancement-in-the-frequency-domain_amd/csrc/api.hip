@@ -1,5 +1,6 @@
 // extern "C" surface (include/sefd.h): plan life cycle, op execution, fused losses, Adam.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include "../../include/sefd.h"
@@ -8,7 +9,13 @@
 
 using namespace sefd;
 
-struct sefd_plan { Plan* p; std::vector<std::string> names; };
+struct sefd_plan {
+  Plan* p;
+  std::vector<std::string> names;
+  // second stream + events for the off-critical-path lane (created on first use, owned by the plan)
+  mutable hipStream_t side = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
 
 static_assert(sizeof(sefd_model_config) == sizeof(ModelConfig), "config mirror out of sync");
 
@@ -22,7 +29,14 @@ sefd_plan* sefd_plan_create(const sefd_model_config* cfg) {
   for (auto& kv : h->p->bufs) h->names.push_back(kv.first);
   return h;
 }
-void sefd_plan_destroy(sefd_plan* h) { if (h) { delete h->p; delete h; } }
+void sefd_plan_destroy(sefd_plan* h) {
+  if (!h) return;
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  delete h->p;
+  delete h;
+}
 const char* sefd_plan_error(const sefd_plan* h) { return h->p->error.c_str(); }
 int64_t sefd_plan_arena_bytes(const sefd_plan* h, int a) { return (a >= 0 && a < A_COUNT) ? h->p->arena_bytes[a] : -1; }
 int32_t sefd_plan_frames(const sefd_plan* h) { return h->p->T; }
@@ -75,11 +89,60 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
   ArenaBases ab;
   for (int a = 0; a < A_COUNT; ++a) ab.p[a] = reinterpret_cast<char*>(arenas[a]);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto launch = [&](const Op& op, hipStream_t s) {
+    if (op.kind == OP_RUNGEMM) launch_rungemm(op.g, ab, s);
+    else if (op.kind == OP_WGRAD) launch_wgrad(op.g, ab, s);
+    else launch_misc(op, ab, s);
+  };
+  // Two-lane execution of a whole phase: lane-1 ops (decoder weight gradients + their split sums) are held back until the
+  // first LSTM backward, then issued on the side stream right after that kernel, so they fill the ~248 CUs the recurrence
+  // leaves idle; the main stream waits for them before the first op that follows the last lane-1 op's consumers (UNPACK).
+  // Partial runs (tests, per-op timing) and SEFD_NO_OVERLAP=1 execute everything in program order on `stream`.
+  static const bool no_overlap = getenv("SEFD_NO_OVERLAP") != nullptr;
+  bool two_lane = !no_overlap && first == 0 && last == (int)ops.size();
+  if (two_lane) {
+    bool any = false, lstm = false;
+    for (const Op& op : ops) { any |= op.lane == 1; lstm |= op.kind == OP_LSTM_BWD; }
+    two_lane = any && lstm;
+  }
+  if (!two_lane) {
+    for (int i = first; i < last; ++i) launch(ops[i], st);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  if (!h->side) {
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return -3;
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
+    if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return -3;
+  }
+  std::vector<int> held;
+  bool forked = false, joined = false;
   for (int i = first; i < last; ++i) {
     const Op& op = ops[i];
-    if (op.kind == OP_RUNGEMM) launch_rungemm(op.g, ab, st);
-    else if (op.kind == OP_WGRAD) launch_wgrad(op.g, ab, st);
-    else launch_misc(op, ab, st);
+    if (op.lane == 1 && !forked) { held.push_back(i); continue; }
+    if (op.lane == 1) {                                  // after the fork point: program order is already satisfied up to here
+      (void)hipEventRecord(h->ev_fork, st);
+      (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+      launch(op, h->side);
+      continue;
+    }
+    if (op.kind == OP_LSTM_BWD && !forked) {
+      (void)hipEventRecord(h->ev_fork, st);              // everything the held ops read has been produced before this point
+      launch(op, st);                                    // the recurrence takes its CUs first
+      (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+      for (int j : held) launch(ops[j], h->side);
+      forked = true;
+      continue;
+    }
+    if (op.kind == OP_UNPACK && forked && !joined) {     // gathers every gradient partial: needs the side lane's results
+      (void)hipEventRecord(h->ev_join, h->side);
+      (void)hipStreamWaitEvent(st, h->ev_join, 0);
+      joined = true;
+    }
+    launch(op, st);
+  }
+  if (forked && !joined) {
+    (void)hipEventRecord(h->ev_join, h->side);
+    (void)hipStreamWaitEvent(st, h->ev_join, 0);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

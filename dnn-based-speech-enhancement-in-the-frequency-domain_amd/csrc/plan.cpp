@@ -77,11 +77,13 @@ struct Builder {
   Ptr pptr(const std::string& n, int arena = A_PARAM) { return mk(arena, par(n).off * 4); }
   Ptr sptr(const std::string& n) { return mk(A_STATE, P->state[sidx.at(n)].off * 4); }
 
+  int cur_lane = 0;
   Op& push(std::vector<Op>& v, int kind, int tag) {
     Op op;
     std::memset(&op, 0, sizeof(op));
     op.kind = kind;
     op.tag = tag;
+    op.lane = cur_lane;
     v.push_back(op);
     return v.back();
   }
@@ -807,7 +809,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       if (!last)
         bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm);
       // weight gradients of both sub-pixel phases; each phase also contributes its rows to the bias gradient (ones run)
+      b.cur_lane = 1;                           // weight gradients of the decoder: nothing downstream needs them before UNPACK
       for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
+      b.cur_lane = 0;
       // input gradients: conv-form over dy [B][T+1][Fo][Co]; dx[ci,f,t] = sum W[ci,co,kh,kw] dy[co, 2f+kh-2, t+kw]
       const int nsrc = cfg.skip ? 2 : 1;
       for (int s = 0; s < nsrc; ++s) {
@@ -844,7 +848,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // ---- projection backward
     Ptr dhc_next = b.ws("dhc" + std::to_string(NL - 1), BT * 2 * H, DT_F32);
     {
+      b.cur_lane = 1;
       b.wgrad(R, proj, d_decin, cproj, 300, &bproj);
+      b.cur_lane = 0;
       RunGemm g = Builder::gemm0();
       g.x[0] = d_decin; g.xdt = adt; g.ydt = DT_F32;
       g.bstride[0] = (int64_t)T * D * Cl; g.tstride[0] = D * Cl; g.rowlen[0] = D * Cl; g.Tin[0] = T;
@@ -1388,7 +1394,9 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
       const std::string pp = "decoder." + std::to_string(d);
       if (!last)
         bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm);
+      b.cur_lane = 1;                           // weight gradients of the decoder: nothing downstream needs them before UNPACK
       for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
+      b.cur_lane = 0;
       const int nsrc = cfg.skip ? 2 : 1;
       for (int s = 0; s < nsrc; ++s) {
         const int Cs = s == 0 ? C0 : C1;
@@ -1417,7 +1425,9 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
     // projection + LSTM backward
     Ptr dh = b.ws("lstm.dh", BT * H, DT_F32);
     {
+      b.cur_lane = 1;
       b.wgrad(R, proj, d_decin, cproj, 300, &bproj);
+      b.cur_lane = 0;
       RunGemm g = Builder::gemm0();
       g.x[0] = d_decin; g.xdt = adt; g.ydt = DT_F32;
       g.bstride[0] = (int64_t)T * D * Cl; g.tstride[0] = D * Cl; g.rowlen[0] = D * Cl; g.Tin[0] = T;

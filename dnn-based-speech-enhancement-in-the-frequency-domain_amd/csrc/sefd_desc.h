@@ -255,6 +255,10 @@ enum OpKind : int32_t {
 struct Op {
   int32_t kind;
   int32_t tag;                 // layer id for profiling / debugging
+  int32_t lane;                // 0: critical path.  1: off the critical path (decoder weight gradients): a full-phase run
+                               // holds these back and runs them on a second HIP stream next to the LSTM backward, whose
+                               // recurrence occupies only 8 of the 256 CUs for ~1.5 ms (api.hip sefd_plan_run)
+  int32_t pad_;
   union {
     RunGemm g;
     Pack pack;
