@@ -55,7 +55,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel_v(const BnApply d, const 
   const float a = *reinterpret_cast<const float*>(rp(ab, d.slope));
   const int cmask = (C & (C - 1)) == 0 ? C - 1 : -1;
   const int64_t nq = d.R * C / V;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (cmask >= 0 && ((stride * V) & cmask) == 0) {
+    // the grid stride is a whole number of rows: a thread always meets the same V channels, so their parameters live in
+    // registers (the LDS look-ups, 4 per element, were costing more issue slots than the 16-byte HBM accesses they serve)
+    const int c = (int)(((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * V) & cmask);
+    float pm[V], pis[V], pg[V], pb[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { pm[e] = sp[c + e]; pis[e] = sp[C + c + e]; pg[e] = sp[2 * C + c + e]; pb[e] = sp[3 * C + c + e]; }
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += stride) {
+      float v[V];
+      VecIO<T>::load(y, q * V, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float bn = pg[e] * ((v[e] - pm[e]) * pis[e]) + pb[e];
+        v[e] = bn > 0.f ? bn : a * bn;
+      }
+      VecIO<T>::store(z, q * V, v);
+    }
+    return;
+  }
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += stride) {
     const int64_t i = q * V;
     const int c = cmask >= 0 ? (int)(i & cmask) : (int)(i % C);
     float v[V];
@@ -106,24 +126,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce 
   const int64_t row1 = min(d.R, row0 + d.rows_per_blk);
   if (rl < nrl && cc < CV) {
     const int c = cc * V;
+    float pm[V], pis[V], pg[V], pb[V];              // this thread's channels never change: parameters in registers
+#pragma unroll
+    for (int e = 0; e < V; ++e) { pm[e] = sp[c + e]; pis[e] = sp[C + c + e]; pg[e] = sp[2 * C + c + e]; pb[e] = sp[3 * C + c + e]; }
     int64_t r = row0 + rl;
     int64_t b = r / d.rpb;
     int ql = (int)(r - b * d.rpb);
-    for (; r < row1; r += nrl) {
-      float yv[V], gz[V];
-      VecIO<T>::load(y, r * C + c, yv);
-      load_dz_v<T>(d, dz0, dz1, b, ql, c, gz);
+    auto accumulate = [&](const float* yv, const float* gz) {
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        const float xh = (yv[e] - sp[c + e]) * sp[C + c + e];
-        const float bn = sp[2 * C + c + e] * xh + sp[3 * C + c + e];
+        const float xh = (yv[e] - pm[e]) * pis[e];
+        const float bn = pg[e] * xh + pb[e];
         const float dbn = bn > 0.f ? gz[e] : a * gz[e];
         sa += bn > 0.f ? 0.f : bn * gz[e];
         s0[e] += dbn;
         s1[e] += dbn * xh;
       }
-      ql += nrl;
-      while (ql >= d.rpb) { ql -= (int)d.rpb; ++b; }
+    };
+    auto next_row = [&]() { r += nrl; ql += nrl; while (ql >= d.rpb) { ql -= (int)d.rpb; ++b; } };
+    // two rows per trip: four independent 16-byte loads in flight per lane (one row per trip left the pass latency-bound)
+    while (r + nrl < row1) {
+      float yv0[V], gz0[V], yv1[V], gz1[V];
+      VecIO<T>::load(y, r * C + c, yv0);
+      load_dz_v<T>(d, dz0, dz1, b, ql, c, gz0);
+      next_row();
+      VecIO<T>::load(y, r * C + c, yv1);
+      load_dz_v<T>(d, dz0, dz1, b, ql, c, gz1);
+      next_row();
+      accumulate(yv0, gz0);
+      accumulate(yv1, gz1);
+    }
+    if (r < row1) {
+      float yv[V], gz[V];
+      VecIO<T>::load(y, r * C + c, yv);
+      load_dz_v<T>(d, dz0, dz1, b, ql, c, gz);
+      accumulate(yv, gz);
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
@@ -169,7 +206,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel_v(const BnBwdApply d,
   const int nq = (int)(r.rpb * C / V);
   const int cmask = (C & (C - 1)) == 0 ? C - 1 : -1;
   const int csh = cmask >= 0 ? __ffs(C) - 1 : 0;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+  const int qstride = gridDim.x * blockDim.x;
+  if (cmask >= 0 && ((qstride * V) & cmask) == 0) {       // same channels on every iteration: parameters in registers
+    const int c = ((blockIdx.x * blockDim.x + threadIdx.x) * V) & cmask;
+    float pm[V], pis[V], pg[V], pb[V], t0[V], t1[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      pm[e] = sp[c + e]; pis[e] = sp[C + c + e]; pg[e] = sp[2 * C + c + e]; pb[e] = sp[3 * C + c + e];
+      t0[e] = st[c + e]; t1[e] = st[C + c + e];
+    }
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += qstride) {
+      const int il = q * V;
+      const int ql = il >> csh;
+      float yv[V], gz[V], o[V];
+      const int64_t gi = b * r.rpb * C + il;
+      VecIO<T>::load(y, gi, yv);
+      load_dz_v<T>(r, dz0, dz1, b, ql, c, gz);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (yv[e] - pm[e]) * pis[e];
+        const float bn = pg[e] * xh + pb[e];
+        const float dbn = bn > 0.f ? gz[e] : a * gz[e];
+        o[e] = pg[e] * pis[e] * (dbn - t0[e] - xh * t1[e]);
+      }
+      VecIO<T>::store(dy, gi, o);
+    }
+    return;
+  }
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += qstride) {
     const int il = q * V;
     const int ql = cmask >= 0 ? (il >> csh) : il / C;
     const int c = il - ql * C;
