@@ -10,6 +10,14 @@ namespace sefd {
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
+// Gate math on pairs of cells: the non-transcendental half of a sigmoid / tanh / cell update compiles to packed fp32
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two lanes-worth per issue slot); v_exp_f32 / v_rcp_f32 stay scalar.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ f32x2 rcp_2(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) { return rcp_2(exp2_2(x * -1.4426950408889634f) + 1.f); }
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) { return rcp_2(exp2_2(x * 2.8853900817779268f) + 1.f) * -2.f + 1.f; }
+
 // H is a compile-time constant (32 / 64 / 96 / 128): with run-time trip counts hipcc guards every MFMA with a branch and
 // drains the software-prefetched loads before the matrix section, which serialises the 483-step loop.
 template <int HMAX>
@@ -90,17 +98,24 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     }
     const int hn = ((t + 1) & 1) * 16 * hs;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf_(acc[2][r]), og = sigmoidf_(acc[3][r]);
-      c[r] = fg * c[r] + ig * gg;
-      const uint16_t hb = f2bf(og * tanhf_(c[r]));
-      ldsh[hn + (4 * kq + r) * hs + unit] = hb;
-      if (rvalid[r]) {
-        hout[so[r]] = hb;
-        *reinterpret_cast<float4*>(gates + so[r] * 4) = make_float4(ig, fg, gg, og);
-        cs[so[r]] = c[r];
+    for (int rp2 = 0; rp2 < 4; rp2 += 2) {
+      const f32x2 ig = sigmoid2(f32x2{acc[0][rp2], acc[0][rp2 + 1]}), fg = sigmoid2(f32x2{acc[1][rp2], acc[1][rp2 + 1]});
+      const f32x2 gg = tanh2(f32x2{acc[2][rp2], acc[2][rp2 + 1]}), og = sigmoid2(f32x2{acc[3][rp2], acc[3][rp2 + 1]});
+      const f32x2 cn = fg * f32x2{c[rp2], c[rp2 + 1]} + ig * gg;
+      const f32x2 hv = og * tanh2(cn);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = rp2 + k;
+        c[r] = cn[k];
+        const uint16_t hb = f2bf(hv[k]);
+        ldsh[hn + (4 * kq + r) * hs + unit] = hb;
+        if (rvalid[r]) {
+          hout[so[r]] = hb;
+          *reinterpret_cast<float4*>(gates + so[r] * 4) = make_float4(ig[k], fg[k], gg[k], og[k]);
+          cs[so[r]] = cn[k];
+        }
+        so[r] += H;
       }
-      so[r] += H;
     }
     lds_barrier();
   };
@@ -190,23 +205,28 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
   auto step = [&](int t, const Sav& cur, Sav& pre) {
     fetch(t - 2, pre);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float di = 0.f, df = 0.f, dg = 0.f, dog = 0.f;
-      if (rvalid[r]) {
-        const float ig = cur.g[r].x, fg = cur.g[r].y, gg = cur.g[r].z, og = cur.g[r].w;
-        const float ct = pct[r];
-        const float cp = t > 0 ? cur.cp[r] : 0.f;
-        const float dht = cur.dh[r] + dhrec[r];
-        const float tc = tanhf_(ct);
-        dog = dht * tc * og * (1.f - og);
-        const float dc = dht * og * (1.f - tc * tc) + dcarry[r];
-        di = dc * gg * ig * (1.f - ig);
-        df = dc * cp * fg * (1.f - fg);
-        dg = dc * ig * (1.f - gg * gg);
-        dcarry[r] = dc * fg;
+    for (int rp2 = 0; rp2 < 4; rp2 += 2) {
+      const f32x2 ig = {cur.g[rp2].x, cur.g[rp2 + 1].x}, fg = {cur.g[rp2].y, cur.g[rp2 + 1].y};
+      const f32x2 gg = {cur.g[rp2].z, cur.g[rp2 + 1].z}, og = {cur.g[rp2].w, cur.g[rp2 + 1].w};
+      const f32x2 ct = {pct[rp2], pct[rp2 + 1]};
+      const f32x2 cp = t > 0 ? f32x2{cur.cp[rp2], cur.cp[rp2 + 1]} : f32x2{0.f, 0.f};
+      const f32x2 dht = f32x2{cur.dh[rp2], cur.dh[rp2 + 1]} + f32x2{dhrec[rp2], dhrec[rp2 + 1]};
+      const f32x2 tc = tanh2(ct);
+      f32x2 dog = dht * tc * og * (1.f - og);
+      const f32x2 dc = dht * og * (1.f - tc * tc) + f32x2{dcarry[rp2], dcarry[rp2 + 1]};
+      f32x2 di = dc * gg * ig * (1.f - ig);
+      f32x2 df = dc * cp * fg * (1.f - fg);
+      f32x2 dg = dc * ig * (1.f - gg * gg);
+      const f32x2 dcn = dc * fg;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = rp2 + k;
+        const bool v = rvalid[r];                 // rows beyond the batch alias row 0: their gradients are forced to zero
+        dcarry[r] = v ? dcn[k] : 0.f;
+        pct[r] = cur.cp[r];                       // c_{t-1} is the cell state of the next (earlier) step
+        *reinterpret_cast<uint2*>(ldsh + (4 * kq + r) * gs + gate_col(0, unit)) =
+            v ? make_uint2(pack2(di[k], df[k]), pack2(dg[k], dog[k])) : make_uint2(0u, 0u);
       }
-      pct[r] = cur.cp[r];                       // c_{t-1} is the cell state of the next (earlier) step
-      *reinterpret_cast<uint2*>(ldsh + (4 * kq + r) * gs + gate_col(0, unit)) = make_uint2(pack2(di, df), pack2(dg, dog));
     }
     lds_barrier();
 #pragma unroll
