@@ -42,6 +42,27 @@ def make_batch(B, L, rank, device):
     return noisy.to(device), clean.to(device)
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel class from the committed PMC summary (tools/pmc_traffic.py over separate
+    `rocprofv3 --pmc TCC_EA0_RDREQ_sum ...` / `... WRREQ_sum` passes of this same command; reads x 64 B x 2 per the gfx950
+    note in MI355X_MICROARCH.md, writes x 64 B).  None when no summary matches this build."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        summ = json.load(open(path))
+    except Exception:
+        return None
+    want = ("rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float") if key[0] == "rungemm" else ("wgrad_bf16" if key[1] else "wgrad_kernel<float")
+    tot, n = 0.0, 0
+    for k, e in summ.items():
+        if k.startswith(want) and "hbm_bytes_per_launch" in e:
+            ln = e.get("launches_TCC_EA0_RDREQ_sum", 1)
+            tot += e["hbm_bytes_per_launch"] * ln
+            n += ln
+    return round(tot / n) if n else None
+
+
 def roofline(model, rt):
     """Time every MFMA GEMM launch of one step individually (HIP events on the launch stream) and aggregate the
     dominant kernel class: algorithmic FLOPs (2*M*N*K with the true, unpadded N and K) / measured duration."""
@@ -75,7 +96,7 @@ def roofline(model, rt):
     detail = {f"{k[0]}_{'bf16' if k[1] else 'f32'}": dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms=round(v["ms"], 3),
                                                            launches=v["launches"]) for k, v in agg.items()}
     return dict(bound="mfma", kernel=f"{key[0]}_kernel<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak,
-                unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None, launches_per_step=a["launches"],
+                unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=pmc_traffic(key), launches_per_step=a["launches"],
                 avg_launch_ms=round(a["ms"] / a["launches"], 4), kernels=detail)
 
 

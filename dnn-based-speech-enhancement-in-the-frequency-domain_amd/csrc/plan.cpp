@@ -252,6 +252,8 @@ void finalize_rungemms(Builder& b, Plan* P) {
       if (op.kind != OP_RUNGEMM && op.kind != OP_WGRAD) continue;
       RunGemm& g = op.g;
       g.zero = z;
+      fastdiv_make((uint32_t)(g.Tout * g.Fo), &g.div_tf_m, &g.div_tf_s);
+      fastdiv_make((uint32_t)g.Fo, &g.div_fo_m, &g.div_fo_s);
       const int vec = 16 / esize(g.xdt);
       bool ok = true;
       for (int s = 0; s < g.nseg && ok; ++s) {

@@ -60,6 +60,9 @@ __device__ __forceinline__ uint4 load_a_chunk(const RunGemm& d, const TA* x0, co
   }
 }
 
+// x / d for 0 <= x < 2^31 with the planner's (m, s) of sefd_desc.h fastdiv_make
+__device__ __forceinline__ int fdiv(int x, uint32_t m, uint32_t s) { return m ? (int)(__umulhi((uint32_t)x, m) >> s) : x; }
+
 __device__ __forceinline__ int swz_off(int row, int chunk) {   // byte offset of a 16-byte chunk inside a [rows][128 B] tile
   return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 16;
 }
@@ -89,7 +92,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // GLDS = true: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass,
 // which otherwise costs more LDS cycles than the fragment reads); padding chunks are fetched from a zero page, and the
 // XOR swizzle is applied on the SOURCE chunk index because the DMA destination is lane-linear (wave base + lane*16).
-template <typename TA, int BN, bool GLDS, int S = 2, int BM = kBM, int NW = 4>
+template <typename TA, int BN, bool GLDS, int S = 2, int BM = kBM, int NW = 4, bool ILV = false>
 __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int VEC = 16 / sizeof(TA);
   constexpr int BK = 8 * VEC;
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
     const int m = mtile * BM + r0 + PR * p;
     rv[p] = m < d.M;
     const int mm = rv[p] ? m : 0;
-    const int b = mm / TF, rem = mm - b * TF;
-    ru[p] = rem / d.Fo;
+    const int b = fdiv(mm, d.div_tf_m, d.div_tf_s), rem = mm - b * TF;
+    ru[p] = fdiv(rem, d.div_fo_m, d.div_fo_s);
     rfo[p] = rem - ru[p] * d.Fo;
     rb0[p] = (int64_t)b * d.bstride[0] + d.base[0];
     rb1[p] = (int64_t)b * d.bstride[1] + d.base[1];
@@ -242,16 +245,26 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
     const TA* zp = reinterpret_cast<const TA*>(rp(ab, d.zero));
     const uint32_t lbase = lds_addr(smem) + __builtin_amdgcn_readfirstlane(wid) * 1024;   // this wave's 8 rows x 128 B of each pass
     constexpr int NL = RP + BPASS;                      // DMAs per thread per stage
-    auto dma = [&](int stage, int kk) {
+    // part q of 4 of a stage's DMAs (A passes q, q+4, ..; B passes likewise): the interleaved loop issues one part
+    // after each of the four MFMA groups of the tile being multiplied
+    auto dma_part = [&](int stage, int kk, int q) {
       const uint32_t A = lbase + stage * TILE_BYTES, B = A + BM * 128;
       const int j0 = kk + csrc * VEC;
 #pragma unroll
       for (int p = 0; p < RP; ++p) {
+        if ((p & 3) != q) continue;
         const TA* src = (j0 >= jlo[p] && j0 + VEC <= jhi[p]) ? rptr[p] + j0 : zp;
         dma16(src, A + p * (PR * 128));
       }
 #pragma unroll
-      for (int p = 0; p < BPASS; ++p) dma16(wrow[p] + wseg + kk, B + p * (PR * 128));
+      for (int p = 0; p < BPASS; ++p) {
+        if ((p & 3) != q) continue;
+        dma16(wrow[p] + wseg + kk, B + p * (PR * 128));
+      }
+    };
+    auto dma = [&](int stage, int kk) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_part(stage, kk, q);
     };
     // S-stage ring: the issue pointer runs S-1 K-tiles ahead of the MFMA loop; one LDS-only barrier per tile
     int issued = 0, istage = 0;
@@ -268,9 +281,42 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
     for (int kt = 0; kt < ntiles; ++kt) {
       wait_stage<NL, S>(ntiles - 1 - kt);              // tile kt has landed (this thread's part)
       lds_barrier();                                   // ... everyone's part; and stage kt-1 is no longer being read
-      if (issued < ntiles) issue_next();               // refills the stage read in kt-1
       const char* As = smem + cstage * TILE_BYTES;
-      compute(As, As + BM * 128);
+      if constexpr (ILV) {
+        // software pipeline inside the wave: fragments of group kc+1 are read while group kc multiplies, and the next
+        // stage's DMAs (address math included) are spread over the four MFMA groups instead of preceding them
+        const char* Bs = As + BM * 128;
+        const bool more = issued < ntiles;
+        uint4 af[2][MI], bf[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const uint4*>(As + arow + i * 4096 + chs[0]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[0][j] = *reinterpret_cast<const uint4*>(Bs + brow + j * 4096 + chs[0]);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          if (kc < 3) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[(kc + 1) & 1][i] = *reinterpret_cast<const uint4*>(As + arow + i * 4096 + chs[kc + 1]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[(kc + 1) & 1][j] = *reinterpret_cast<const uint4*>(Bs + brow + j * 4096 + chs[kc + 1]);
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) mfma_step<TA>(acc[i][j], af[kc & 1][i], bf[kc & 1][j]);
+          if (more) dma_part(istage, k0, kc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+          istage = istage + 1 == S ? 0 : istage + 1;
+          ++issued;
+          k0 += BK;
+          if (k0 >= seglen && issued < ntiles) { k0 = 0; ++seg; enter_run(seg); }
+        }
+      } else {
+        if (issued < ntiles) issue_next();             // refills the stage read in kt-1
+        compute(As, As + BM * 128);
+      }
       cstage = cstage + 1 == S ? 0 : cstage + 1;
     }
   } else {
@@ -305,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
     const int m = mtile * BM + tid;
     int64_t o = -1;
     if (m < d.M) {
-      const int b = m / TF, rem = m - b * TF, u = rem / d.Fo, fo = rem - u * d.Fo;
+      const int b = fdiv(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
       o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
     }
     rowoff[tid] = o;
@@ -895,24 +941,13 @@ static int env_stages(const char* name, int dflt) {
   return v >= 2 && v <= 4 ? v : dflt;
 }
 
+// Tile-shape note (measured on MI355X, DCCRN B=32, profiles/r01_tuning_notes.md): the kernel template also builds as a
+// 256 x 128 tile (4 or 8 waves, 2- or 3-stage ring), as a 3/4-stage 128 x 128 ring (one workgroup per CU) and with the
+// fragment reads / next-stage DMAs interleaved between the MFMA groups; none of them beat two co-resident 128 x 128
+// workgroups with a 2-stage ring, so that is the only configuration launched.  SEFD_RG_STAGES keeps the ring depth tunable.
 template <typename TA, int BN>
 static void launch_rungemm_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st, int grid) {
   static const int stages = env_stages("SEFD_RG_STAGES", 2);
-  static const int tall = getenv("SEFD_RG_BM") ? atoi(getenv("SEFD_RG_BM")) : 128;
-  if constexpr (sizeof(TA) == 2 && BN == 128) {
-    // 256 x 128 tile, 8 waves, 3-stage ring (144 KiB LDS, one workgroup per CU): the weight tile is shared by twice the
-    // rows, 25 % fewer operand bytes per MAC than two 128 x 128 workgroups, same waves per CU
-    if (tall == 256 && d.M >= 256 * 512) {
-      const int nm2 = (d.M + 255) / 256;
-      hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3, 256, 8>), dim3(nm2 * (d.Npad / BN)), dim3(512), 0, st, d, ab);
-      return;
-    }
-    if (tall == 257 && d.M >= 256 * 512) {           // same tile, 2-stage ring
-      const int nm2 = (d.M + 255) / 256;
-      hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2, 256, 8>), dim3(nm2 * (d.Npad / BN)), dim3(512), 0, st, d, ab);
-      return;
-    }
-  }
   if (stages == 2) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2>), dim3(grid), dim3(256), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3>), dim3(grid), dim3(256), 0, st, d, ab);
   else hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 4>), dim3(grid), dim3(256), 0, st, d, ab);

@@ -62,7 +62,18 @@ struct RunGemm {
   int32_t nsplit;          // WGRAD only: number of row splits
   int32_t flags;           // bit 0: every run is 16-byte aligned and a whole number of 16-byte chunks -> LDS-DMA loader
   Ptr zero;                // >= 16 zero bytes (A_CONST): source of padding chunks for the LDS-DMA loader
+  // Division by the two run-time row-decode divisors (Tout*Fo and Fo) as multiply-high + shift, filled by the planner
+  // (fastdiv_make): for 0 <= x < 2^31, x / d == umulhi(x, m) >> s ; m == 0 encodes d == 1.  The kernels decode 4-8 row
+  // indices per thread in their prologue; with 15 000-workgroup launches on the thin layers that was a visible cost.
+  uint32_t div_tf_m, div_tf_s, div_fo_m, div_fo_s;
 };
+static inline void fastdiv_make(uint32_t d, uint32_t* m, uint32_t* s) {
+  if (d <= 1) { *m = 0; *s = 0; return; }
+  uint32_t L = 0;
+  while ((1ull << L) < d) ++L;                                   // L = ceil(log2 d) >= 1
+  *m = (uint32_t)((((uint64_t)1 << (31 + L)) + d - 1) / d);     // ceil(2^(31+L) / d) < 2^32
+  *s = L - 1;                                                    // (31 + L) - 32
+}
 constexpr int kRunAligned = 1;   // LDS-DMA loader usable
 constexpr int kRunAccum = 2;     // y += result (fp32 y): recurrent term added onto the hoisted input GEMM / gradient accumulation
 constexpr int kRunRelu = 4;      // y = max(result, 0)
