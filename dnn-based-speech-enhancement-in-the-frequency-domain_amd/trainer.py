@@ -98,3 +98,49 @@ def dccrn_direct_train(model, optimizer, train_loader, DEVICE):
         optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
+
+
+# ------------------------------------------------------------------------------------------------ validation
+def model_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers=None):
+    """Validation pass of the T-F masking models (reference trainer.py:188-241): eval-mode plans (BatchNorm running
+    statistics), no gradients, mean of the per-batch losses.
+
+    The reference scores every enhanced utterance with PESQ (a closed x86 binary) and pystoi on the CPU; neither ships
+    here, so they are injected: `scorers = (cal_pesq, cal_stoi)`, each `f(estimated[B, L] ndarray, clean[B, L] ndarray)
+    -> per-utterance scores`.  Without scorers the two averages are NaN and no score file is written; with them the
+    per-utterance lines go to `<dir_to_save>/Epoch_<epoch>_SCORES` in the reference's format and `writer.log_wav` is
+    called every 10th epoch exactly as there.  Returns (validation_loss, avg_pesq, avg_stoi)."""
+    import numpy as np
+    validation_loss = torch.zeros((), device=DEVICE)
+    avg_pesq = avg_stoi = 0.0
+    batch_num = 0
+    f_score = open(f"{dir_to_save}/Epoch_{epoch:d}_SCORES", "a") if scorers is not None else None
+    was_training = model.training
+    model.eval()
+    last = None
+    try:
+        with torch.no_grad():
+            for inputs, targets in validation_loader:
+                batch_num += 1
+                inputs = inputs.float().to(DEVICE, non_blocking=True)
+                targets = targets.float().to(DEVICE, non_blocking=True)
+                _, _, outputs = model(inputs, targets)
+                validation_loss += model.loss(outputs, targets)
+                last = (inputs, targets, outputs)
+                if scorers is not None:
+                    est, clean = outputs.cpu().numpy(), targets.cpu().numpy()
+                    pesq, stoi = np.asarray(scorers[0](est, clean)).reshape(-1), np.asarray(scorers[1](est, clean)).reshape(-1)
+                    for p, s in zip(pesq, stoi):
+                        f_score.write("PESQ {:.6f} | STOI {:.6f}\n".format(p, s))
+                    avg_pesq += float(pesq.sum()) / len(inputs)
+                    avg_stoi += float(stoi.sum()) / len(inputs)
+        if writer is not None and epoch % 10 == 0 and last is not None:
+            writer.log_wav(last[0][0], last[1][0], last[2][0], epoch)
+    finally:
+        if f_score is not None:
+            f_score.close()
+        model.train(was_training)
+    n = max(batch_num, 1)
+    if scorers is None:
+        return validation_loss / n, float("nan"), float("nan")
+    return validation_loss / n, avg_pesq / n, avg_stoi / n

@@ -285,8 +285,44 @@ def frontend_and_losses(cfg, models, tfm, tfl):
     print("frontend_losses: q4", out["q4"], "lms", out["lms_loss"])
 
 
+def dccrn_eval_case(cfg, models, name, kernel_num, rnn_units, mask, loss, B, L, Bv, Lv):
+    """Validation path (trainer.py:188-241 `model_validate` minus the PESQ/STOI scorers): one training-mode forward, then
+    `model.eval()` + `torch.no_grad()` forward and loss on a different batch - BatchNorm uses the UPDATED running
+    statistics, so this pins the eval plans and the running-stat update together."""
+    cfg.dccrn_kernel_num = list(kernel_num)
+    cfg.masking_mode = mask
+    cfg.loss = loss
+    cfg.perceptual = False
+    cfg.lstm = "complex"
+    cfg.skip_type = True
+    torch.manual_seed(0)
+    m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask)
+    fill_state_dict_(m)
+    m.train()
+    x, y = test_signals(B, L)
+    # a training-mode forward updates the running statistics; no optimizer step here: Adam turns the rounding-noise
+    # gradients of the conv biases in front of BatchNorm into +-lr steps of random sign, which eval mode (running mean
+    # taken with the OLD bias) does not cancel - the reference itself is only reproducible to ~1e-3 after such a step
+    with torch.no_grad():
+        _, _, wav = m(x, y)
+        lossv = m.loss(wav, y)
+    m.eval()
+    xv, yv = test_signals(Bv, Lv)
+    xv, yv = xv.flip(0) * 0.8, yv.flip(0) * 0.8             # not the training batch
+    with torch.no_grad():
+        o_r, o_i, wv = m(xv, yv)
+        vloss = m.loss(wv, yv)
+    rec = dict(meta=dict(B=B, L=L, Bv=Bv, Lv=Lv, kernel_num=np.array(kernel_num), rnn_units=rnn_units, mask=np.array(mask), loss=np.array(loss)),
+               train_loss=float(lossv), val_loss=float(vloss), val_wav=wv.numpy(), val_real=sample(o_r), val_imag=sample(o_i))
+    np.savez_compressed(os.path.join(HERE, f"dccrn_{name}.npz"), **flat(rec, "g"))
+    print(f"dccrn_{name}: train loss {float(lossv):.6f} val loss {float(vloss):.6f}")
+
+
 def main():
     cfg, models, tfm, tfl = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":          # regenerate only the validation-path case
+        dccrn_eval_case(cfg, models, "small_eval", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", 2, 4000, 3, 5000)
+        return
     frontend_and_losses(cfg, models, tfm, tfl)
     small = (16, 32, 32, 64, 64, 64)
     dflt = (32, 64, 128, 256, 256, 256)
@@ -302,6 +338,7 @@ def main():
     crn_case(cfg, models, "small_E_sisnr", small, 128, 128, "E", "SI-SNR", 2, 4000)
     fsn_case(cfg, models, tfm, "default_mse", 2, 6000)
     fsn_case(cfg, models, tfm, "small_mse", 2, 6000, hidden=(128, 64))
+    dccrn_eval_case(cfg, models, "small_eval", small, 128, "C", "SI-SNR", 2, 4000, 3, 5000)
 
 
 if __name__ == "__main__":

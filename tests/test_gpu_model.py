@@ -156,6 +156,44 @@ def test_full_length_clip_and_properties():
     assert rel_err(full[1:2], one) < 1e-5
 
 
+def test_validation_path_against_reference_golden(tmp_path):
+    """`trainer.model_validate` (reference trainer.py:188-241): eval-mode plans with the running statistics a
+    training-mode forward just updated, no gradients; enhanced waveform and loss vs the reference golden."""
+    from sefd_amd import trainer
+    g = load_golden("dccrn_small_eval")
+    kn = tuple(int(k) for k in g["g/meta/kernel_num"])
+    m = make_model(kn, int(g["g/meta/rnn_units"]), "C", "SI-SNR")
+    m.train()
+    x, y = make_signals(int(g["g/meta/B"]), int(g["g/meta/L"]))
+    with torch.no_grad():
+        _, _, wav0 = m(x.cuda(), y.cuda())
+        assert abs(float(m.loss(wav0, y.cuda())) - float(g["g/train_loss"])) < TOL * abs(float(g["g/train_loss"]))
+    xv, yv = make_signals(int(g["g/meta/Bv"]), int(g["g/meta/Lv"]))
+    xv, yv = xv.flip(0) * 0.8, yv.flip(0) * 0.8
+    m.eval()
+    with torch.no_grad():
+        _, _, wv = m(xv.cuda(), yv.cuda())
+    assert rel_err(wv, g["g/val_wav"]) < TOL
+    calls = []
+
+    def fake_pesq(est, clean):
+        calls.append(est.shape)
+        return np.full(len(est), 2.5)
+
+    def fake_stoi(est, clean):
+        return np.full(len(est), 0.9)
+
+    m.train()
+    vloss, pesq, stoi = trainer.model_validate(m, [(xv, yv)], None, str(tmp_path), 3, "cuda", scorers=(fake_pesq, fake_stoi))
+    assert m.training                                             # mode restored
+    assert abs(float(vloss) - float(g["g/val_loss"])) < TOL * abs(float(g["g/val_loss"]))
+    assert calls == [tuple(xv.shape)] and abs(pesq - 2.5) < 1e-9 and abs(stoi - 0.9) < 1e-9
+    lines = open(tmp_path / "Epoch_3_SCORES").read().strip().splitlines()
+    assert lines == ["PESQ 2.500000 | STOI 0.900000"] * len(xv)
+    vloss2, p2, s2 = trainer.model_validate(m, [(xv, yv)], None, str(tmp_path), 4, "cuda")
+    assert abs(float(vloss2) - float(vloss)) < 1e-6 and p2 != p2 and s2 != s2      # NaN without scorers
+
+
 def test_cpu_tensor_is_rejected_not_silently_computed():
     m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")
     with pytest.raises(RuntimeError):

@@ -177,3 +177,27 @@ def test_dccrn_direct_mode_against_reference():
     for k, v in sub(g, "g/grad_norm").items():
         if not (k.endswith("conv.bias") and not k.startswith("decoder.5.")):
             assert abs(float(grads[k].double().norm()) - float(v)) <= 3e-4 * float(v) + 1e-7, k
+
+
+def test_oracle_validation_path_after_one_step():
+    """Eval-mode forward (BatchNorm running statistics updated by one training-mode forward) vs the reference (trainer.py:188-241)."""
+    from oracle.dccrn import DCCRNConfig, dccrn_forward, dccrn_state_shapes
+    from oracle.losses import main_loss
+    from oracle.step import dccrn_train_step
+    from oracle.weights import formula_state_dict, test_signals
+    g = load_golden("dccrn_small_eval")
+    cfg = DCCRNConfig(kernel_num=tuple(int(k) for k in g["g/meta/kernel_num"]), rnn_units=int(g["g/meta/rnn_units"]), masking_mode="C")
+    P = formula_state_dict(dccrn_state_shapes(cfg))
+    x, y = test_signals(int(g["g/meta/B"]), int(g["g/meta/L"]))
+    with torch.no_grad():
+        (_, _, wav0), new_stats = dccrn_forward(P, x, cfg, targets=y, train=True)      # updates the running statistics only
+    assert abs(float(main_loss("SI-SNR", wav0, y)) - float(g["g/train_loss"])) < 1e-4 * abs(float(g["g/train_loss"]))
+    P2 = dict(P)
+    P2.update(new_stats)
+    xv, yv = test_signals(int(g["g/meta/Bv"]), int(g["g/meta/Lv"]))
+    xv, yv = xv.flip(0) * 0.8, yv.flip(0) * 0.8
+    with torch.no_grad():
+        (o_r, o_i, wav), _ = dccrn_forward(P2, xv, cfg, targets=yv, train=False)
+        vloss = main_loss("SI-SNR", wav, yv)
+    assert rel_err(wav, g["g/val_wav"]) < 1e-4
+    assert abs(float(vloss) - float(g["g/val_loss"])) < 1e-4 * abs(float(g["g/val_loss"]))
