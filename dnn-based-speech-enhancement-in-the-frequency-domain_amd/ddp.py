@@ -2,10 +2,12 @@
 step - a sum all-reduce of the flat fp32 gradient buffer over RCCL/xGMI (torch.distributed backend "nccl" IS RCCL on ROCm).
 
 The reference has no distributed code at all; this is a new capability, so it is designed for MI355X:
-  * the gradient already lives in ONE contiguous fp32 arena (14.7 MB for default DCCRN), so the exchange is a handful of
-    large bucket all-reduces instead of hundreds of per-tensor ones (xGMI is point-to-point, per-link bound);
-  * buckets follow the backward order (decoder -> LSTM -> encoder); each bucket's all-reduce is issued on a side stream
-    as soon as the backward op that completes it has been enqueued, overlapping with the remaining encoder backward;
+  * the gradient already lives in ONE contiguous fp32 arena (14.7 MB for default DCCRN), so the exchange is one large
+    all-reduce (or a few caller-chosen buckets) instead of hundreds of per-tensor ones (xGMI is point-to-point, per-link
+    bound: few, large messages);
+  * it runs on a side stream that waits for the backward phase and that Adam waits for.  Today the whole arena becomes
+    valid at the UNPACK op that ends the backward phase, so the exchange (about 0.1-0.4 ms for 14.7 MB on 8 GPUs) is NOT
+    yet overlapped with the encoder backward; splitting UNPACK per bucket (decoder + LSTM first) is the planned next step;
   * averaging (1/world) is folded into the fused Adam kernel (grad_scale), no extra pass.
 BatchNorm statistics stay per rank (standard DDP semantics), which is what the throughput numbers use.
 """
