@@ -10,6 +10,24 @@ static inline int gridn(int64_t n, int cap = 16384) { int64_t g = (n + 255) / 25
 #define GSL(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------------------------------------- LSTM cell (one time step)
+// element offset of (row r, buffer k) and the gate-column helper for both layouts of LstmCell
+struct CellAddr {
+  int64_t o[5];
+};
+__device__ __forceinline__ CellAddr cell_addr(const LstmCell& d, int64_t r) {
+  CellAddr a;
+  if (d.G > 0) {
+    const int g = (int)(r / d.Bg);
+    const int64_t b = r - (int64_t)g * d.Bg;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a.o[k] = d.go[k][g] + b * d.rs[k];
+  } else {
+    a.o[0] = r * 4 * d.H; a.o[1] = r * d.H; a.o[2] = r * d.H; a.o[3] = r * d.H; a.o[4] = r * 4 * d.H;
+  }
+  return a;
+}
+__device__ __forceinline__ int cell_col(const LstmCell& d, int q, int j) { return d.unit_major ? gate_col(q, j) : q * d.H + j; }
+
 __global__ __launch_bounds__(256) void cell_fwd_kernel(const LstmCell d, const ArenaBases ab) {
   float* g = reinterpret_cast<float*>(rp(ab, d.gates));
   const float* cp = d.first ? nullptr : reinterpret_cast<const float*>(rp(ab, d.c_prev));
@@ -19,12 +37,14 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const LstmCell d, const A
   GSL(i, d.rows * H) {
     const int64_t r = i / H;
     const int j = (int)(i - r * H);
-    float* gr = g + r * 4 * H;
-    const float ig = sigmoidf_(gr[j]), fg = sigmoidf_(gr[H + j]), gg = tanhf_(gr[2 * H + j]), og = sigmoidf_(gr[3 * H + j]);
-    const float cn = fg * (cp ? cp[i] : 0.f) + ig * gg;
-    gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = gg; gr[3 * H + j] = og;
-    c[i] = cn;
-    st_elem(h, d.hdt, i, og * tanhf_(cn));
+    const CellAddr a = cell_addr(d, r);
+    float* gr = g + a.o[0];
+    const int ci = cell_col(d, 0, j), cf = cell_col(d, 1, j), cg = cell_col(d, 2, j), co = cell_col(d, 3, j);
+    const float ig = sigmoidf_(gr[ci]), fg = sigmoidf_(gr[cf]), gg = tanhf_(gr[cg]), og = sigmoidf_(gr[co]);
+    const float cn = fg * (cp ? cp[a.o[1] + j] : 0.f) + ig * gg;
+    gr[ci] = ig; gr[cf] = fg; gr[cg] = gg; gr[co] = og;
+    c[a.o[1] + j] = cn;
+    st_elem(h, d.hdt, a.o[2] + j, og * tanhf_(cn));
   }
 }
 
@@ -39,16 +59,17 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const LstmCell d, const A
   GSL(i, d.rows * H) {
     const int64_t r = i / H;
     const int j = (int)(i - r * H);
-    const float* gr = g + r * 4 * H;
-    const float ig = gr[j], fg = gr[H + j], gg = gr[2 * H + j], og = gr[3 * H + j];
-    const float tc = tanhf_(c[i]);
-    const float dht = dh[i];
+    const CellAddr a = cell_addr(d, r);
+    const float* gr = g + a.o[0];
+    const int ci = cell_col(d, 0, j), cf = cell_col(d, 1, j), cg = cell_col(d, 2, j), co = cell_col(d, 3, j);
+    const float ig = gr[ci], fg = gr[cf], gg = gr[cg], og = gr[co];
+    const float tc = tanhf_(c[a.o[1] + j]);
+    const float dht = dh[a.o[3] + j];
     const float dcv = dht * og * (1.f - tc * tc) + (d.first ? 0.f : dc[i]);
-    const int64_t o = r * 4 * H + j;
-    st_elem(dg, d.gdt, o, dcv * gg * ig * (1.f - ig));
-    st_elem(dg, d.gdt, o + H, dcv * (cp ? cp[i] : 0.f) * fg * (1.f - fg));
-    st_elem(dg, d.gdt, o + 2 * H, dcv * ig * (1.f - gg * gg));
-    st_elem(dg, d.gdt, o + 3 * H, dht * tc * og * (1.f - og));
+    st_elem(dg, d.gdt, a.o[4] + ci, dcv * gg * ig * (1.f - ig));
+    st_elem(dg, d.gdt, a.o[4] + cf, dcv * (cp ? cp[a.o[1] + j] : 0.f) * fg * (1.f - fg));
+    st_elem(dg, d.gdt, a.o[4] + cg, dcv * ig * (1.f - gg * gg));
+    st_elem(dg, d.gdt, a.o[4] + co, dht * tc * og * (1.f - og));
     dc[i] = dcv * fg;
   }
 }

@@ -323,7 +323,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   const int Cl = ch[n];                      // channels entering the LSTM
   for (int i = 1; i <= n; ++i)
     if (ch[i] % 8 != 0 && !(i == 0)) { P->error = "channel counts must be multiples of 8"; return P; }
-  if (H % 16 != 0 || H > 128) { P->error = "rnn_units/2 must be a multiple of 16 and <= 128"; return P; }
+  // H <= 128: persistent recurrence kernels (W_hh resident in VGPRs).  Larger H (DCCRN-large: rnn_units 512) does not fit
+  // the register file of one CU: the recurrence becomes one GEMM + one cell launch per time step on the same buffers.
+  const bool stepped = H > 128 || getenv("SEFD_LSTM_STEPPED") != nullptr;
+  if (H % 16 != 0 || (adt == DT_BF16 && H % 32 != 0)) { P->error = "rnn_units/2 must be a multiple of 16 (32 for bf16)"; return P; }
   if (adt == DT_BF16 && H % 32 != 0) { P->error = "bf16: rnn_units/2 must be a multiple of 32"; return P; }
   if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
 
@@ -565,7 +568,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.push(F, OP_RUNGEMM, 200 + l).g = g;
       ls[l].gx[p] = g; ls[l].cgx[p] = coef;
     }
-    {
+    if (!stepped) {
       Op& op = b.push(F, OP_LSTM_FWD, 200 + l);
       LstmRec& r = op.lstm;
       r.gx = ls[l].gxb;
@@ -574,6 +577,46 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       r.dh = r.dgates = b.none();
       for (int g4 = 0; g4 < 4; ++g4) r.gx_goff[g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
       r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = DT_F32;
+    } else {
+      // per time step: gx[t] += h[t-1] . W_hh^T (one GEMM per parameter set over the 2B rows (part, b)), then one cell launch
+      // over the 4 groups; gx is overwritten in place by the gates i,f,g,o, which is what the backward cells read
+      const ParamInfo* Whh[2] = {&b.par(pp + ".real_lstm.weight_hh_l0"), &b.par(pp + ".imag_lstm.weight_hh_l0")};
+      for (int set = 0; set < 2; ++set) {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = ls[l].h; g.xdt = adt; g.ydt = DT_F32;
+        g.bstride[0] = 0; g.tstride[0] = 2 * BT * H; g.fstride[0] = T * H; g.rowlen[0] = (int)(BT * H); g.Tin[0] = 2;
+        g.M = 2 * B; g.Tout = 2; g.Fo = B;
+        g.nseg = 1; g.seg[0] = Seg{0, 0, 0, H, 0};
+        g.N = 4 * H;
+        Builder::layout_segs(g);
+        const ParamInfo* Wp = Whh[set];
+        Builder::Coef chh = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
+        b.pack_weights(F, g, chh, nm + ".hh" + std::to_string(set), 200 + l);
+        g.y = ls[l].gxb; g.y_bstride = 0; g.y_tstride = (int)(BT * 8 * H); g.y_fstride = T * 8 * H; g.flags = kRunAccum;
+        ls[l].hh[set] = g;
+      }
+      for (int t = 0; t < T; ++t) {
+        if (t > 0)
+          for (int set = 0; set < 2; ++set) {
+            RunGemm g = ls[l].hh[set];
+            g.base[0] = (int64_t)set * BT * H + (int64_t)(t - 1) * H;
+            g.y_off = t * 8 * H + set * 4 * H;
+            b.push(F, OP_RUNGEMM, 200 + l).g = g;
+          }
+        LstmCell& cl = b.push(F, OP_CELL_FWD, 200 + l).cell;
+        cl.gates = b.mk(A_WS, ls[l].gxb.off + (int64_t)t * 8 * H * 4);
+        cl.c = b.mk(A_WS, ls[l].cst.off + (int64_t)t * H * 4);
+        cl.c_prev = t > 0 ? b.mk(A_WS, ls[l].cst.off + (int64_t)(t - 1) * H * 4) : b.none();
+        cl.h = b.mk(A_WS, ls[l].h.off + (int64_t)t * H * esize(adt));
+        cl.dh = cl.dc = cl.dgates = b.none();
+        cl.rows = 4 * B; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == 0;
+        cl.G = 4; cl.Bg = B; cl.unit_major = 1;
+        cl.rs[0] = (int64_t)T * 8 * H; cl.rs[1] = cl.rs[2] = cl.rs[3] = (int64_t)T * H; cl.rs[4] = (int64_t)T * 8 * H;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          cl.go[0][g4] = cl.go[4][g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
+          cl.go[1][g4] = cl.go[2][g4] = cl.go[3][g4] = (int64_t)g4 * BT * H;
+        }
+      }
     }
     {
       Op& op = b.push(F, OP_COMBINE_FWD, 200 + l);
@@ -877,7 +920,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         Op& op = b.push(R, OP_COMBINE_BWD, 200 + l);
         op.comb.h = dh; op.comb.out = dhc_next; op.comb.rows = BT; op.comb.H = H; op.comb.dt = DT_F32;
       }
-      {
+      if (!stepped) {
         Op& op = b.push(R, OP_LSTM_BWD, 200 + l);
         LstmRec& r = op.lstm;
         r.gx = ls[l].gxb;
@@ -885,6 +928,48 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         r.h = ls[l].h; r.gates = ls[l].gates; r.c = ls[l].cst; r.dh = dh; r.dgates = dgates;
         for (int g4 = 0; g4 < 4; ++g4) r.gx_goff[g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
         r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = adt;
+      } else {
+        // per time step, last to first: cell backward (dgates[t], carry dc), then dh[t-1] += dgates[t] . W_hh per parameter set
+        Ptr dcb = b.ws(nm + ".dc", (int64_t)4 * B * H, DT_F32);
+        RunGemm rb[2];
+        for (int set = 0; set < 2; ++set) {
+          RunGemm g = Builder::gemm0();
+          g.x[0] = dgates; g.xdt = adt; g.ydt = DT_F32;
+          g.bstride[0] = 0; g.tstride[0] = (int)(BT * 8 * H); g.fstride[0] = T * 8 * H; g.rowlen[0] = (int)(BT * 8 * H); g.Tin[0] = 2;
+          g.M = 2 * B; g.Tout = 2; g.Fo = B;
+          g.nseg = 1; g.seg[0] = Seg{0, 0, 0, 4 * H, 0};
+          g.N = H;
+          Builder::layout_segs(g);
+          const ParamInfo* Wp = Whh[set];
+          Builder::Coef cT = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)gate_torch_row(j, H) * H + nn, 1); };
+          b.pack_weights(R, g, cT, nm + ".hhT" + std::to_string(set), 200 + l);
+          g.y = dh; g.y_bstride = 0; g.y_tstride = (int)(2 * BT * H); g.y_fstride = T * H; g.flags = kRunAccum;
+          rb[set] = g;
+        }
+        for (int t = T - 1; t >= 0; --t) {
+          LstmCell& cl = b.push(R, OP_CELL_BWD, 200 + l).cell;
+          cl.gates = b.mk(A_WS, ls[l].gxb.off + (int64_t)t * 8 * H * 4);
+          cl.c = b.mk(A_WS, ls[l].cst.off + (int64_t)t * H * 4);
+          cl.c_prev = t > 0 ? b.mk(A_WS, ls[l].cst.off + (int64_t)(t - 1) * H * 4) : b.none();
+          cl.h = b.none();
+          cl.dh = b.mk(A_WS, dh.off + (int64_t)t * H * 4);
+          cl.dc = dcb;
+          cl.dgates = b.mk(A_WS, dgates.off + (int64_t)t * 8 * H * esize(adt));
+          cl.rows = 4 * B; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == T - 1;
+          cl.G = 4; cl.Bg = B; cl.unit_major = 1;
+          cl.rs[0] = (int64_t)T * 8 * H; cl.rs[1] = cl.rs[2] = cl.rs[3] = (int64_t)T * H; cl.rs[4] = (int64_t)T * 8 * H;
+          for (int g4 = 0; g4 < 4; ++g4) {
+            cl.go[0][g4] = cl.go[4][g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
+            cl.go[1][g4] = cl.go[2][g4] = cl.go[3][g4] = (int64_t)g4 * BT * H;
+          }
+          if (t > 0)
+            for (int set = 0; set < 2; ++set) {
+              RunGemm g = rb[set];
+              g.base[0] = (int64_t)t * 8 * H + (int64_t)set * 4 * H;
+              g.y_off = (int)((int64_t)set * BT * H + (int64_t)(t - 1) * H);
+              b.push(R, OP_RUNGEMM, 200 + l).g = g;
+            }
+        }
       }
       for (int p = 0; p < 2; ++p) {
         Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);

@@ -231,6 +231,15 @@ struct LstmCell {            // forward : gates slab holds pre-activations (inpu
   Ptr dh, dc, dgates;        // backward: dh fp32 [rows][H] (total upstream), dc fp32 [rows][H] carry (in/out), dgates out dtype gdt
   int64_t rows;
   int32_t H, hdt, gdt, first;     // first: t == 0 (no previous cell state) / backward: t == T-1 (no carry yet)
+  // Strided form (G > 0), used by the per-time-step LSTM of DCCRN / CRN when rnn_units/2 > 128 (W_hh no longer fits the
+  // register file of one CU): rows = G groups x Bg sequences addressed inside the batch-major [.., B*T, ..] buffers of the
+  // persistent path; element (group g, sequence b) of buffer k sits at  base_k + go[k][g] + b * rs[k]  (elements of that
+  // buffer's dtype; the time step is folded into base_k).  k: 0 gates (pre-activations in, i/f/g/o out, in place),
+  // 1 c and c_prev, 2 h, 3 dh, 4 dgates.  unit_major: gate column order of sefd_desc.h gate_col instead of q*H + unit.
+  // `dc` stays a dense [rows][H] carry.  G == 0: FullSubNet slabs (dense rows, gate-major columns).
+  int32_t G, Bg, unit_major, pad_;
+  int64_t rs[5];
+  int64_t go[5][4];
 };
 // Inverted dropout between the LSTM layers (nn.LSTM(dropout=0.8), tools_for_model.py:746): counter-based hash RNG on
 // (seed, element index); backward re-derives the mask from the same seed.  keep == 1 -> identity copy.

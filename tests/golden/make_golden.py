@@ -320,6 +320,9 @@ def dccrn_eval_case(cfg, models, name, kernel_num, rnn_units, mask, loss, B, L, 
 
 def main():
     cfg, models, tfm, tfl = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":          # only the wide-LSTM case (rnn_units 512, DCCRN-large's LSTM width)
+        dccrn_case(cfg, models, "wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR", False, 1, 2000, store_taps=False)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "eval":          # regenerate only the validation-path case
         dccrn_eval_case(cfg, models, "small_eval", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", 2, 4000, 3, 5000)
         return
@@ -339,6 +342,7 @@ def main():
     fsn_case(cfg, models, tfm, "default_mse", 2, 6000)
     fsn_case(cfg, models, tfm, "small_mse", 2, 6000, hidden=(128, 64))
     dccrn_eval_case(cfg, models, "small_eval", small, 128, "C", "SI-SNR", 2, 4000, 3, 5000)
+    dccrn_case(cfg, models, "wide_C_sdr", small, 512, "C", "SDR", False, 1, 2000, store_taps=False)
 
 
 if __name__ == "__main__":

@@ -73,6 +73,17 @@ void rungemm(const RunGemm& d, const AB& ab) {
   }
 }
 
+inline void cell_off(const LstmCell& d, int64_t r, int64_t* o) {
+  if (d.G > 0) {
+    const int g = (int)(r / d.Bg);
+    const int64_t b = r - (int64_t)g * d.Bg;
+    for (int k = 0; k < 5; ++k) o[k] = d.go[k][g] + b * d.rs[k];
+  } else {
+    o[0] = r * 4 * d.H; o[1] = r * d.H; o[2] = r * d.H; o[3] = r * d.H; o[4] = r * 4 * d.H;
+  }
+}
+inline int cell_col(const LstmCell& d, int q, int j) { return d.unit_major ? gate_col(q, j) : q * d.H + j; }
+
 void pack(const Pack& d, const AB& ab) {
   const int32_t* tab = (const int32_t*)rp(ab, d.tab);
   const float* src = (const float*)rp(ab, d.src);
@@ -166,12 +177,15 @@ bool run_fsn(const Op& op, const AB& ab) {
       float* c = (float*)rp(ab, d.c);
       for (int64_t i = 0; i < d.rows * d.H; ++i) {
         const int64_t r = i / d.H; const int j = (int)(i % d.H);
-        float* gr = g + r * 4 * d.H;
-        const double ig = sgm(gr[j]), fg = sgm(gr[d.H + j]), gg = std::tanh((double)gr[2 * d.H + j]), og = sgm(gr[3 * d.H + j]);
-        const double cn = fg * (cp ? cp[i] : 0.0) + ig * gg;
-        gr[j] = (float)ig; gr[d.H + j] = (float)fg; gr[2 * d.H + j] = (float)gg; gr[3 * d.H + j] = (float)og;
-        c[i] = (float)cn;
-        st(rp(ab, d.h), d.hdt, i, (float)(og * std::tanh(cn)));
+        int64_t o[5];
+        cell_off(d, r, o);
+        float* gr = g + o[0];
+        const int ci = cell_col(d, 0, j), cf = cell_col(d, 1, j), cg = cell_col(d, 2, j), co = cell_col(d, 3, j);
+        const double ig = sgm(gr[ci]), fg = sgm(gr[cf]), gg = std::tanh((double)gr[cg]), og = sgm(gr[co]);
+        const double cn = fg * (cp ? cp[o[1] + j] : 0.0) + ig * gg;
+        gr[ci] = (float)ig; gr[cf] = (float)fg; gr[cg] = (float)gg; gr[co] = (float)og;
+        c[o[1] + j] = (float)cn;
+        st(rp(ab, d.h), d.hdt, o[2] + j, (float)(og * std::tanh(cn)));
       }
       return true;
     }
@@ -184,15 +198,17 @@ bool run_fsn(const Op& op, const AB& ab) {
       float* dc = (float*)rp(ab, d.dc);
       for (int64_t i = 0; i < d.rows * d.H; ++i) {
         const int64_t r = i / d.H; const int j = (int)(i % d.H);
-        const float* gr = g + r * 4 * d.H;
-        const double ig = gr[j], fg = gr[d.H + j], gg = gr[2 * d.H + j], og = gr[3 * d.H + j];
-        const double tc = std::tanh((double)c[i]), dht = dh[i];
+        int64_t o[5];
+        cell_off(d, r, o);
+        const float* gr = g + o[0];
+        const int ci = cell_col(d, 0, j), cf = cell_col(d, 1, j), cg = cell_col(d, 2, j), co = cell_col(d, 3, j);
+        const double ig = gr[ci], fg = gr[cf], gg = gr[cg], og = gr[co];
+        const double tc = std::tanh((double)c[o[1] + j]), dht = dh[o[3] + j];
         const double dcv = dht * og * (1 - tc * tc) + (d.first ? 0.0 : dc[i]);
-        const int64_t o = r * 4 * d.H + j;
-        st(rp(ab, d.dgates), d.gdt, o, (float)(dcv * gg * ig * (1 - ig)));
-        st(rp(ab, d.dgates), d.gdt, o + d.H, (float)(dcv * (cp ? cp[i] : 0.0) * fg * (1 - fg)));
-        st(rp(ab, d.dgates), d.gdt, o + 2 * d.H, (float)(dcv * ig * (1 - gg * gg)));
-        st(rp(ab, d.dgates), d.gdt, o + 3 * d.H, (float)(dht * tc * og * (1 - og)));
+        st(rp(ab, d.dgates), d.gdt, o[4] + ci, (float)(dcv * gg * ig * (1 - ig)));
+        st(rp(ab, d.dgates), d.gdt, o[4] + cf, (float)(dcv * (cp ? cp[o[1] + j] : 0.0) * fg * (1 - fg)));
+        st(rp(ab, d.dgates), d.gdt, o[4] + cg, (float)(dcv * ig * (1 - gg * gg)));
+        st(rp(ab, d.dgates), d.gdt, o[4] + co, (float)(dht * tc * og * (1 - og)));
         dc[i] = (float)(dcv * fg);
       }
       return true;

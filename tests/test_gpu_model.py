@@ -19,6 +19,7 @@ CASES = [
     ("small_R_mse", (16, 32, 32, 64, 64, 64), 128, "R", "MSE"),
     ("small_E_sisdr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SDR"),
     ("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR"),
+    ("wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR"),        # rnn_units 512: per-time-step LSTM path (plan.cpp `stepped`)
 ]
 
 

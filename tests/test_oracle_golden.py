@@ -90,6 +90,7 @@ CASES = [
     ("small_E_sisdr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SDR", False),
     ("small_E_sisnr_lms", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", "LMS"),
     ("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR", False),
+    ("wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR", False),
 ]
 
 

@@ -34,7 +34,7 @@ def test_exports_and_param_table():
     want_state = [(k, tuple(v)) for k, v in shapes.items() if "running_" in k]
     assert [(k, shp) for k, (off, shp) in plan.state.items()] == want_state
     with pytest.raises(ValueError):
-        Plan(2, 4000, kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=2048)
+        Plan(2, 4000, kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=2050)      # rnn_units/2 must be a multiple of 16
 
 
 def test_default_plan_matches_reference_param_count():
@@ -44,7 +44,25 @@ def test_default_plan_matches_reference_param_count():
 
 @pytest.mark.parametrize("mode,loss", [("E", "SI-SNR"), ("C", "SDR"), ("R", "MSE"), ("Direct(None make)", "MSE")])
 def test_hostsim_forward_backward_vs_oracle(mode, loss):
-    B, L = 2, 4000
+    _check_plan_vs_oracle(mode, loss, SMALL, 2, 4000)
+
+
+def test_hostsim_wide_lstm_takes_the_per_step_path():
+    """rnn_units = 512 (DCCRN-large, BASELINE configs[4]): W_hh no longer fits one CU's registers, the planner emits one
+    recurrent GEMM per parameter set + one cell launch per time step on the same buffers (plan.cpp `stepped`)."""
+    kw = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=512)
+    plan = Plan(1, 2000, masking_mode="C", **kw)
+    kinds = [plan.op_info(PHASE_FWD, i)["kind"] for i in range(plan.num_ops(PHASE_FWD))]
+    assert kinds.count(1) > 2 * (plan.T - 1)               # at least two recurrent GEMMs per step and layer
+    _check_plan_vs_oracle("C", "SDR", kw, 1, 2000)
+
+
+def test_hostsim_forced_per_step_lstm_matches_too(monkeypatch):
+    monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+    _check_plan_vs_oracle("E", "SI-SNR", SMALL, 2, 4000)
+
+
+def _check_plan_vs_oracle(mode, loss, SMALL, B, L):
     cfg = DCCRNConfig(masking_mode=mode, **SMALL)
     P = oracle_params(cfg)
     plan = Plan(B, L, masking_mode=mode, **SMALL)
