@@ -2,8 +2,8 @@
 
 Like the reference, it is a module of constants imported as `cfg`; constructor defaults of the models are bound at
 import time and `cfg.loss` / `cfg.perceptual` / `cfg.lstm` / `cfg.skip_type` / `cfg.dccrn_kernel_num` are read at
-construction / call time.  Differences: no banner print, DEVICE defaults to 'cuda' (the MI355X), and two build-side
-knobs (`act_dtype`, `ddp_sync_bn`) that the reference does not have.
+construction / call time.  Differences: no banner print, DEVICE defaults to 'cuda' (the MI355X), and one build-side
+knob (`act_dtype`) that the reference does not have.  (BatchNorm statistics are per rank under DDP; SyncBN is not built.)
 """
 job_dir = './models/'
 logs_dir = './logs/'
