@@ -13,7 +13,7 @@ class ModelConfig(C.Structure):
                 ("n_layers", C.c_int32), ("kernel_num", C.c_int32 * 8),
                 ("rnn_layers", C.c_int32), ("rnn_units", C.c_int32), ("mask_mode", C.c_int32),
                 ("lstm_complex", C.c_int32), ("skip", C.c_int32), ("act_dtype", C.c_int32),
-                ("kernel_size", C.c_int32), ("training", C.c_int32)]
+                ("kernel_size", C.c_int32), ("training", C.c_int32), ("bn_world", C.c_int32)]
 
 
 _lib = None
@@ -35,6 +35,8 @@ def lib():
         "sefd_plan_error": (cp, [vp]),
         "sefd_plan_arena_bytes": (i64, [vp, i32]),
         "sefd_plan_frames": (i32, [vp]),
+        "sefd_plan_num_syncs": (i32, [vp]),
+        "sefd_plan_sync": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
         "sefd_plan_num_params": (i32, [vp, i32]),
         "sefd_plan_param_name": (cp, [vp, i32, i32]),
         "sefd_plan_param_offset": (i64, [vp, i32, i32]),
@@ -66,6 +68,7 @@ def lib():
 
 
 EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_plan_arena_bytes", "sefd_plan_frames",
+            "sefd_plan_num_syncs", "sefd_plan_sync",
             "sefd_plan_num_params", "sefd_plan_param_name", "sefd_plan_param_offset", "sefd_plan_param_numel",
             "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",

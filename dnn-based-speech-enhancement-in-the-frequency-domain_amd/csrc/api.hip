@@ -60,6 +60,13 @@ int32_t sefd_plan_buffer(const sefd_plan* h, const char* name, int32_t* arena, i
 int32_t sefd_plan_num_buffers(const sefd_plan* h) { return (int32_t)h->names.size(); }
 const char* sefd_plan_buffer_name(const sefd_plan* h, int i) { return h->names[i].c_str(); }
 const void* sefd_plan_const_data(const sefd_plan* h) { return h->p->consts.data(); }
+int32_t sefd_plan_num_syncs(const sefd_plan* h) { return (int32_t)h->p->syncs.size(); }
+int32_t sefd_plan_sync(const sefd_plan* h, int i, int32_t* phase, int32_t* op, int32_t* arena, int64_t* off, int64_t* count, int32_t* dtype) {
+  if (i < 0 || i >= (int)h->p->syncs.size()) return -1;
+  const SyncPoint& sp = h->p->syncs[i];
+  *phase = sp.phase; *op = sp.op; *arena = sp.buf.arena; *off = sp.buf.off; *count = sp.count; *dtype = sp.dtype;
+  return 0;
+}
 int32_t sefd_plan_num_ops(const sefd_plan* h, int phase) { return (int32_t)(phase == 0 ? h->p->fwd.size() : h->p->bwd.size()); }
 const void* sefd_plan_ops(const sefd_plan* h, int phase) { return phase == 0 ? h->p->fwd.data() : h->p->bwd.data(); }
 int32_t sefd_op_size(void) { return (int32_t)sizeof(Op); }

@@ -112,18 +112,34 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalize d, co
     return;
   }
   const float* part = reinterpret_cast<const float*>(rp(ab, d.part));
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = threadIdx.x; b < d.nblk; b += 256) {
-    s1 += part[((int64_t)b * 2 + 0) * d.Cpad + c];
-    s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c];
-  }
   __shared__ double r1[256], r2[256];
-  r1[threadIdx.x] = s1;
-  r2[threadIdx.x] = s2;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+  if (d.mode == 2) {                      // SyncBN: the totals of all ranks are already in place
+    if (threadIdx.x == 0) {
+      const double* tot = reinterpret_cast<const double*>(rp(ab, d.totals));
+      r1[0] = tot[c];
+      r2[0] = tot[d.C + c];
+    }
+  } else {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < d.nblk; b += 256) {
+      s1 += part[((int64_t)b * 2 + 0) * d.Cpad + c];
+      s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c];
+    }
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
     __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+      __syncthreads();
+    }
+    if (d.mode == 1) {                    // SyncBN: publish this rank's sums, the caller all-reduces them
+      if (threadIdx.x == 0) {
+        double* tot = reinterpret_cast<double*>(rp(ab, d.totals));
+        tot[c] = r1[0];
+        tot[d.C + c] = r2[0];
+      }
+      return;
+    }
   }
   if (threadIdx.x == 0) {
     const double mean = r1[0] / d.count;

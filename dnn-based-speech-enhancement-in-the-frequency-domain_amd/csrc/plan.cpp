@@ -290,6 +290,37 @@ void finalize_rungemms(Builder& b, Plan* P) {
     rest.insert(rest.begin(), m);
     ops->swap(rest);
   }
+  // SyncBN (cfg.bn_world > 1): every training-mode BN_FINALIZE becomes "publish this rank's sums" + "statistics from the
+  // all-reduced sums" with a sync point in between; every BN_BWD_FINALIZE is followed by a sync point on its totals.
+  // Counts become global.  The caller (models.py / hostsim tests) runs the op ranges between sync points and all-reduces.
+  const int world = P->cfg.bn_world;
+  if (world > 1 && P->cfg.training) {
+    int k = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+      std::vector<Op>& ops = phase == 0 ? P->fwd : P->bwd;
+      std::vector<Op> out;
+      for (Op op : ops) {
+        if (op.kind == OP_BN_FINALIZE && op.bnf.nblk >= 0) {
+          op.bnf.totals = b.ws("syncbn.tot" + std::to_string(k++), (int64_t)2 * op.bnf.C * 2, DT_F32);   // 2*C doubles
+          op.bnf.mode = 1;
+          out.push_back(op);
+          P->syncs.push_back(SyncPoint{phase, (int32_t)out.size() - 1, op.bnf.totals, 2 * (int64_t)op.bnf.C, 1});
+          op.bnf.mode = 2;
+          op.bnf.count *= world;
+          out.push_back(op);
+        } else if (op.kind == OP_BN_BWD_FINALIZE) {
+          out.push_back(op);
+          P->syncs.push_back(SyncPoint{phase, (int32_t)out.size() - 1, op.bnb.totals, 2 * (int64_t)op.bnb.r.C, 0});
+        } else if (op.kind == OP_BN_BWD_APPLY) {
+          op.bnb.count *= world;
+          out.push_back(op);
+        } else {
+          out.push_back(op);
+        }
+      }
+      ops.swap(out);
+    }
+  }
 }
 
 }  // namespace

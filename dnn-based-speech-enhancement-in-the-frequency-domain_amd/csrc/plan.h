@@ -21,6 +21,7 @@ struct ModelConfig {
   int32_t act_dtype;        // DT_F32 / DT_BF16 storage + MFMA dtype of the conv stack
   int32_t kernel_size;      // 5
   int32_t training;         // 1: BatchNorm batch statistics + running update ; 0: eval (running stats)
+  int32_t bn_world;         // > 1: SyncBN over that many ranks (sync points, counts scaled)
 };
 
 struct ParamInfo {
@@ -35,6 +36,8 @@ struct BufInfo {
   int32_t dtype;
 };
 
+struct SyncPoint { int32_t phase, op; Ptr buf; int64_t count; int32_t dtype; };
+
 struct Plan {
   ModelConfig cfg;
   int32_t T, NF;
@@ -44,6 +47,7 @@ struct Plan {
   int64_t arena_bytes[A_COUNT];
   std::vector<char> consts;                    // host image of A_CONST
   std::vector<Op> fwd, bwd;
+  std::vector<SyncPoint> syncs;                // SyncBN all-reduce points, in execution order per phase
   std::string error;
 };
 

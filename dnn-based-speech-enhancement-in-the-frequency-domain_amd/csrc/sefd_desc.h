@@ -108,9 +108,11 @@ struct BnFinalize {            // partial sums -> mean, invstd ; running stats m
   Ptr part;                    // [nblk][2][Cpad]
   Ptr mean_invstd;             // fp32 [2][C]  (workspace)
   Ptr running_mean, running_var;   // A_STATE (or A_NONE in eval)
-  int32_t nblk, C, Cpad, pad_;
-  double count;                // rows contributing
+  int32_t nblk, C, Cpad, mode; // mode 0: partials -> statistics.  SyncBN: 1: partials -> totals (this rank's sum, sum of squares);
+                               //         2: totals (all-reduced by the caller in between) -> statistics
+  double count;                // rows contributing (all ranks in mode 2)
   float eps, momentum;
+  Ptr totals;                  // fp64 [2][C] (modes 1, 2)
 };
 struct BnApply {               // z = prelu(gamma*(y-mean)*invstd + beta)
   Ptr y, z, mean_invstd, gamma, beta, slope;

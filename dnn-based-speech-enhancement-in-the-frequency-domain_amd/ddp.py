@@ -9,15 +9,18 @@ The reference has no distributed code at all; this is a new capab
     valid at the UNPACK op that ends the backward phase, so the exchange (about 0.1-0.4 ms for 14.7 MB on 8 GPUs) is NOT
     yet overlapped with the encoder backward; splitting UNPACK per bucket (decoder + LSTM first) is the planned next step;
   * averaging (1/world) is folded into the fused Adam kernel (grad_scale), no extra pass.
-BatchNorm statistics stay per rank (standard DDP semantics), which is what the throughput numbers use.
+BatchNorm statistics stay per rank by default (standard DDP semantics), which is what the throughput numbers
+use; `GradientExchange(sync_bn=True)` switches `train_step` to SyncBN plans (statistics over all ranks: N ranks x B/N
+utterances == the reference's single process with batch B; tests/test_ddp_gloo.py pins that with world size 2).
 """
 import torch
 import torch.distributed as dist
 
 
 class GradientExchange:
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, sync_bn=False):
         self.pg = process_group
+        self.sync_bn = bool(sync_bn)     # True: BatchNorm statistics over all ranks (22 small all-reduces per step, parity mode)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.stream = None
 
@@ -40,6 +43,13 @@ class GradientExchange:
         else:
             for lo, hi in (bounds or [(0, flat_grad.numel())]):
                 dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+
+
+    def all_reduce_stats(self, t: torch.Tensor):
+        """SyncBN sync point: in-place sum of a per-channel statistics buffer (2*C values) over the ranks, ordered on the
+        current stream (torch's NCCL wrapper inserts the stream dependencies)."""
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
 
 def shard_batch(n_items: int, rank: int, world: int):

@@ -201,7 +201,7 @@ class _SefdModule(nn.Module):
     def _runtime(self, B, L, device):
         if not self._flat_ok(device):
             self._flatten(device)
-        key = (B, L, bool(self.training), self.masking_mode, self.act_dtype)
+        key = (B, L, bool(self.training), self.masking_mode, self.act_dtype, getattr(self, "_bn_world", 1))
         rt = self._runtimes.get(key)
         if rt is None:
             rt = _Runtime(self, B, L, bool(self.training), device)
@@ -240,6 +240,11 @@ class _SefdModule(nn.Module):
         inputs = inputs.float()
         targets = targets.float().contiguous()
         B, L = inputs.shape
+        # SyncBN (exchange.sync_bn): a plan whose BatchNorm counts are global and whose phases are run in the op ranges
+        # between its sync points, with the small statistics buffers all-reduced in between (parity with the reference's
+        # single-process big batch).  Default: per-rank statistics, whole phases (two-lane backward).
+        sync = exchange is not None and exchange.world > 1 and getattr(exchange, "sync_bn", False)
+        self._bn_world = exchange.world if sync else 1
         rt = self._runtime(B, L, inputs.device)
         optimizer.bind(self)
         self._flat_nbt += 1
@@ -247,12 +252,18 @@ class _SefdModule(nn.Module):
         rt.wav.copy_(inputs)
         if rt.tgt is not None:
             rt.tgt.copy_(targets)
-        rt.run(PHASE_FWD)
+        if sync:
+            rt.plan.run_synced(PHASE_FWD, rt.arenas, stream, exchange.all_reduce_stats)
+        else:
+            rt.run(PHASE_FWD)
         ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
         rt.g_real.zero_()
         rt.g_imag.zero_()
         tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)
-        rt.run(PHASE_BWD)
+        if sync:
+            rt.plan.run_synced(PHASE_BWD, rt.arenas, stream, exchange.all_reduce_stats)
+        else:
+            rt.run(PHASE_BWD)
         if exchange is not None and exchange.world > 1:      # DDP: sum gradients over ranks (RCCL), average inside Adam
             exchange.all_reduce(self._flat_grad)
             optimizer.grad_scale = exchange.grad_scale
@@ -313,7 +324,8 @@ class DCCRN(_SefdModule):
     def _make_plan(self, B, L, training):
         return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=self.hidden_layers, rnn_units=self.rnn_units,
                     win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, masking_mode=self.masking_mode,
-                    lstm=self._lstm_kind, skip_type=self._skip, act_dtype=self.act_dtype, training=training, model="DCCRN")
+                    lstm=self._lstm_kind, skip_type=self._skip, act_dtype=self.act_dtype, training=training, model="DCCRN",
+                    bn_world=getattr(self, "_bn_world", 1))
 
     # ---- reference surface ----------------------------------------------------------------------------------
     def forward(self, inputs, targets=0):
@@ -424,7 +436,7 @@ class CRN(_SefdModule):
             raise NotImplementedError("CRN on the HIP path: T-F masking only (cfg.masking_mode 'E' semantics, models.py:519-526)")
         return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=1, rnn_units=2 * self.rnn_units, win_len=self.win_len,
                     win_inc=self.win_inc, fft_len=self.fft_len, masking_mode="E", lstm="real", skip_type=self._skip,
-                    act_dtype=self.act_dtype, training=training, model="CRN")
+                    act_dtype=self.act_dtype, training=training, model="CRN", bn_world=getattr(self, "_bn_world", 1))
 
     def forward(self, inputs, targets=0):
         """models.py:467-532: returns (est_mags, target_mags, out_wav).  Only out_wav carries gradient."""

@@ -16,7 +16,7 @@ DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 class Plan:
     def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
                  win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
-                 kernel_size=5, training=True, model="DCCRN", fsn=None):
+                 kernel_size=5, training=True, model="DCCRN", fsn=None, bn_world=1):
         self.lib = _lib.lib()
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
@@ -43,6 +43,7 @@ class Plan:
         cfg.act_dtype = DTYPES[act_dtype]
         cfg.kernel_size = kernel_size
         cfg.training = 1 if training else 0
+        cfg.bn_world = int(bn_world)
         self.cfg = cfg
         self.h = self.lib.sefd_plan_create(C.byref(cfg))
         err = self.lib.sefd_plan_error(self.h).decode()
@@ -58,6 +59,29 @@ class Plan:
         self.state = self._param_table(1)
         self.n_param = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.params.values()) if self.params else 0
         self.n_state = sum(int(np.prod(s)) if len(s) else 1 for _, s in self.state.values())
+
+    def sync_points(self):
+        """SyncBN (bn_world > 1): [(phase, op, arena, byte offset, element count, torch dtype)] in execution order."""
+        out = []
+        ph, op, ar, dt = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        off, cnt = C.c_int64(), C.c_int64()
+        for i in range(self.lib.sefd_plan_num_syncs(self.h)):
+            self.lib.sefd_plan_sync(self.h, i, C.byref(ph), C.byref(op), C.byref(ar), C.byref(off), C.byref(cnt), C.byref(dt))
+            out.append((ph.value, op.value, ar.value, off.value, cnt.value, torch.float64 if dt.value else torch.float32))
+        return out
+
+    def run_synced(self, phase, arenas, stream, all_reduce):
+        """Run a whole phase of a SyncBN plan: op ranges between the sync points, `all_reduce(tensor)` (in-place sum over
+        the ranks) on each statistics buffer in between."""
+        cur = 0
+        for ph, op, ar, off, cnt, dtype in self.sync_points():
+            if ph != phase:
+                continue
+            self.run(phase, arenas, stream, cur, op + 1)
+            nbytes = cnt * (8 if dtype == torch.float64 else 4)
+            all_reduce(arenas[ar].view(torch.uint8)[off:off + nbytes].view(dtype))
+            cur = op + 1
+        self.run(phase, arenas, stream, cur, self.num_ops(phase))
 
     def _param_table(self, kind):
         out = OrderedDict()

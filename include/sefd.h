@@ -35,6 +35,10 @@ typedef struct sefd_model_config {
   int32_t act_dtype;      /* 0 fp32, 1 bf16 storage / MFMA dtype */
   int32_t kernel_size;    /* 5 */
   int32_t training;       /* 1 train (batch statistics + backward plan), 0 eval */
+  int32_t bn_world;       /* 0/1: BatchNorm statistics of this process only (standard DDP).  N > 1: SyncBN over N ranks - the plan
+                             exposes sync points (sefd_plan_num_syncs / sefd_plan_sync) where the caller sum-all-reduces a small
+                             statistics buffer between two op ranges; counts are scaled by N.  Makes N ranks x B/N utterances
+                             equal to the reference's single process with batch B */
 } sefd_model_config;
 
 enum { SEFD_ARENA_WS = 0, SEFD_ARENA_PARAM = 1, SEFD_ARENA_GRAD = 2, SEFD_ARENA_STATE = 3, SEFD_ARENA_CONST = 4, SEFD_ARENA_IO = 5,
@@ -56,6 +60,10 @@ int64_t sefd_plan_param_numel(const sefd_plan* p, int kind, int i);
 int32_t sefd_plan_param_shape(const sefd_plan* p, int kind, int i, int64_t* shape4);  /* returns ndim */
 /* named workspace / io buffers (tests, debugging). returns 0 if found */
 int32_t sefd_plan_buffer(const sefd_plan* p, const char* name, int32_t* arena, int64_t* off, int64_t* bytes, int32_t* dtype);
+/* SyncBN (bn_world > 1): sync point i says "after op `op` of `phase` has been enqueued, sum-all-reduce `count` elements
+   (dtype 0 fp32 / 1 fp64) at byte offset `off` of arena `arena` over the ranks, then continue with op + 1". */
+int32_t sefd_plan_num_syncs(const sefd_plan* p);
+int32_t sefd_plan_sync(const sefd_plan* p, int i, int32_t* phase, int32_t* op, int32_t* arena, int64_t* off, int64_t* count, int32_t* dtype);
 int32_t sefd_plan_num_buffers(const sefd_plan* p);
 const char* sefd_plan_buffer_name(const sefd_plan* p, int i);
 /* host image of the constant arena (STFT bases, OLA normaliser, index tables): copy it to device memory once */

@@ -403,7 +403,17 @@ void run_op(const Op& op, const AB& ab) {
         }
         const float* part = (const float*)rp(ab, d.part);
         double s1 = 0, s2 = 0;
-        for (int b = 0; b < d.nblk; ++b) { s1 += part[((int64_t)b * 2) * d.Cpad + c]; s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c]; }
+        if (d.mode == 2) {
+          const double* tot = (const double*)rp(ab, d.totals);
+          s1 = tot[c]; s2 = tot[d.C + c];
+        } else {
+          for (int b = 0; b < d.nblk; ++b) { s1 += part[((int64_t)b * 2) * d.Cpad + c]; s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c]; }
+          if (d.mode == 1) {
+            double* tot = (double*)rp(ab, d.totals);
+            tot[c] = s1; tot[d.C + c] = s2;
+            continue;
+          }
+        }
         const double mean = s1 / d.count;
         double var = s2 / d.count - mean * mean;
         if (var < 0) var = 0;

@@ -76,3 +76,95 @@ def test_shard_batch_partitions():
     spans = [shard_batch(64, r, 8) for r in range(8)]
     assert spans[0] == (0, 8) and spans[-1] == (56, 64)
     assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+
+
+# ------------------------------------------------------------------------------------------------ SyncBN
+SMALL = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128)
+
+
+def _syncbn_worker(rank, world, port, q):
+    """Each rank interprets a SyncBN plan (bn_world = 2) for its half of the batch with the host simulator; the statistics
+    buffers are all-reduced over gloo at the plan's sync points - the same call sequence models.py issues on the GPUs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle.dccrn import DCCRNConfig, dccrn_state_shapes
+    from oracle.weights import formula_state_dict
+    from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, read_params, sim_run
+    from sefd_amd.plan import ARENA_GRAD, ARENA_STATE
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, L = 4, 3000
+        Bl = B // world
+        P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode="C", **SMALL)))
+        x, _ = make_signals(B, L)
+        torch.manual_seed(7)
+        gw = torch.randn(B, L)
+
+        def run(plan, xs, gs, synced):
+            ar = plan.alloc_arenas("cpu")
+            fill_params(plan, ar, P)
+            plan.io(ar, "wav", xs.shape).copy_(xs)
+
+            def phase(ph):
+                if not synced:
+                    sim_run(plan, ph, ar)
+                    return
+                cur = 0
+                for sph, op, a, off, cnt, dtype in plan.sync_points():
+                    if sph != ph:
+                        continue
+                    sim_run(plan, ph, ar, cur, op + 1)
+                    nb = cnt * (8 if dtype == torch.float64 else 4)
+                    dist.all_reduce(ar[a].view(torch.uint8)[off:off + nb].view(dtype))
+                    cur = op + 1
+                sim_run(plan, ph, ar, cur, plan.num_ops(ph))
+
+            phase(PHASE_FWD)
+            wav = plan.io(ar, "out_wav", xs.shape).clone()
+            plan.io(ar, "grad_wav", xs.shape).copy_(gs)
+            plan.io(ar, "grad_real", (xs.shape[0], plan.NF, plan.T)).zero_()
+            plan.io(ar, "grad_imag", (xs.shape[0], plan.NF, plan.T)).zero_()
+            phase(PHASE_BWD)
+            return wav, read_params(plan, ar, ARENA_GRAD), read_params(plan, ar, ARENA_STATE, plan.state)
+
+        lo, hi = rank * Bl, (rank + 1) * Bl
+        plan = Plan(Bl, L, masking_mode="C", bn_world=world, **SMALL)
+        assert len(plan.sync_points()) == 2 * 11                 # 11 BatchNorm layers, forward and backward
+        wav, grads, state = run(plan, x[lo:hi], gw[lo:hi], True)
+        flat = torch.cat([grads[k].reshape(-1) for k in grads])
+        dist.all_reduce(flat)                                    # the DDP gradient exchange (sum; upstream gradient given directly)
+        res = None
+        if rank == 0:
+            full = Plan(B, L, masking_mode="C", **SMALL)
+            assert len(full.sync_points()) == 0
+            fwav, fgrads, fstate = run(full, x, gw, False)
+            fflat = torch.cat([fgrads[k].reshape(-1) for k in fgrads])
+            keep = torch.cat([torch.full((fgrads[k].numel(),), not (k.endswith("conv.bias") and not k.startswith("decoder.5.")))
+                              for k in fgrads])                  # biases in front of BatchNorm: analytically zero, noise on both sides
+            res = dict(wav=float((wav - fwav[lo:hi]).abs().max() / fwav.abs().max()),
+                       grad=float(((flat - fflat)[keep]).abs().max() / fflat[keep].abs().max()),
+                       state=max(float((state[k] - fstate[k]).abs().max() / (fstate[k].abs().max() + 1e-12)) for k in fstate))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_syncbn_equals_single_process_big_batch():
+    """2 ranks x 2 utterances with SyncBN == the reference's single process with batch 4 (outputs, gradients
+    after the sum exchange, BatchNorm running statistics)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    r0 = res[0]
+    assert r0["wav"] < 2e-5 and r0["state"] < 2e-5, r0
+    assert r0["grad"] < 2e-4, r0

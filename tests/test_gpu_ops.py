@@ -167,3 +167,68 @@ def test_adam_step_matches_torch_formula():
     qd, gq, mq, vq = torch.ones(8).cuda(), q.grad.cuda(), torch.zeros(8).cuda(), torch.zeros(8).cuda()
     L_.sefd_adam_step(vp(qd), vp(gq), vp(mq), vp(vq), 8, 1, 1e-3, 0.9, 0.999, 1e-8, 1.0, None)
     assert rel_err(qd.cpu(), q.detach()) < 1e-6
+
+
+def test_syncbn_plans_two_ranks_emulated_on_one_gpu():
+    """SyncBN op modes on the HIP kernels: two bn_world=2 plans (the two "ranks", 2 utterances each) are advanced in lock
+    step on one GPU, their statistics buffers summed at every sync point (what RCCL does between the ranks), and must
+    reproduce the single plan over all 4 utterances: outputs, gradients (summed), BatchNorm running statistics."""
+    from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, read_params
+    from sefd_amd.plan import ARENA_GRAD, ARENA_STATE
+    kn, ru, B, L = (16, 32, 32, 64, 64, 64), 128, 4, 3000
+    P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode="C", kernel_num=kn, rnn_units=ru)))
+    x, _ = make_signals(B, L)
+    torch.manual_seed(7)
+    gw = torch.randn(B, L)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def prep(plan, xs):
+        ar = plan.alloc_arenas("cuda")
+        fill_params(plan, ar, P)
+        plan.io(ar, "wav", xs.shape).copy_(xs.cuda())
+        return ar
+
+    def seed_grad(plan, ar, gs):
+        plan.io(ar, "grad_wav", gs.shape).copy_(gs.cuda())
+        plan.io(ar, "grad_real", (gs.shape[0], plan.NF, plan.T)).zero_()
+        plan.io(ar, "grad_imag", (gs.shape[0], plan.NF, plan.T)).zero_()
+
+    full = Plan(B, L, masking_mode="C", kernel_num=kn, rnn_units=ru)
+    far = prep(full, x)
+    full.run(PHASE_FWD, far, stream)
+    seed_grad(full, far, gw)
+    full.run(PHASE_BWD, far, stream)
+    ranks = [Plan(B // 2, L, masking_mode="C", kernel_num=kn, rnn_units=ru, bn_world=2) for _ in range(2)]
+    ars = [prep(p, x[2 * r:2 * r + 2]) for r, p in enumerate(ranks)]
+    for ph in (PHASE_FWD, PHASE_BWD):
+        if ph == PHASE_BWD:
+            for r in range(2):
+                seed_grad(ranks[r], ars[r], gw[2 * r:2 * r + 2])
+        cur = 0
+        for sph, op, a, off, cnt, dtype in ranks[0].sync_points():
+            if sph != ph:
+                continue
+            views = []
+            for r in range(2):
+                ranks[r].run(ph, ars[r], stream, cur, op + 1)
+                nb = cnt * (8 if dtype == torch.float64 else 4)
+                views.append(ars[r][a].view(torch.uint8)[off:off + nb].view(dtype))
+            tot = views[0] + views[1]
+            views[0].copy_(tot)
+            views[1].copy_(tot)
+            cur = op + 1
+        for r in range(2):
+            ranks[r].run(ph, ars[r], stream, cur, ranks[r].num_ops(ph))
+    torch.cuda.synchronize()
+    fw = full.io(far, "out_wav", (B, L))
+    for r in range(2):
+        assert rel_err(ranks[r].io(ars[r], "out_wav", (2, L)), fw[2 * r:2 * r + 2]) < 1e-4
+    fg = read_params(full, far, ARENA_GRAD)
+    g0, g1 = read_params(ranks[0], ars[0], ARENA_GRAD), read_params(ranks[1], ars[1], ARENA_GRAD)
+    for k in fg:
+        if k.endswith("conv.bias") and not k.startswith("decoder.5."):
+            continue
+        assert rel_err(g0[k] + g1[k], fg[k]) < 1e-3, k
+    fs, s0 = read_params(full, far, ARENA_STATE, full.state), read_params(ranks[0], ars[0], ARENA_STATE, ranks[0].state)
+    for k in fs:
+        assert rel_err(s0[k], fs[k]) < 1e-4, k
