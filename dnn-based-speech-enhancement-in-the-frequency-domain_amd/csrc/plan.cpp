@@ -342,14 +342,15 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   const int KS = cfg.kernel_size;
   P->T = T;
   P->NF = NF;
-  if (cfg.model != 0 || !cfg.lstm_complex || KS != 5 || n < 1 || n > 7) { P->error = "unsupported configuration"; return P; }
+  if (cfg.model != 0 || KS != 5 || n < 1 || n > 7) { P->error = "unsupported configuration"; return P; }
+  const bool cx = cfg.lstm_complex != 0;     // cfg.lstm: 'complex' (NavieComplexLSTM stack) or 'real' (nn.LSTM(2 layers) + tranform, models.py:96-105)
   std::vector<int> ch(n + 1), Fe(n + 1);
   ch[0] = 2;
   for (int i = 0; i < n; ++i) ch[i + 1] = cfg.kernel_num[i];
   Fe[0] = NF - 1;
   for (int i = 0; i < n; ++i) Fe[i + 1] = Fe[i] / 2;
   const int D = Fe[n];                       // hidden_dim (models.py:81)
-  const int H = cfg.rnn_units / 2;           // per-part hidden size of the complex LSTM
+  const int H = cfg.lstm_complex ? cfg.rnn_units / 2 : cfg.rnn_units;   // per-part hidden size of the complex LSTM / hidden size of the real one
   const int NL = cfg.rnn_layers;
   const int Cl = ch[n];                      // channels entering the LSTM
   for (int i = 1; i <= n; ++i)
@@ -391,7 +392,18 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     }
   }
   const int hid = D * Cl;                    // LSTM feature size real+imag
-  for (int l = 0; l < NL; ++l) {
+  if (!cx) {                                  // nn.LSTM(hid, rnn_units, num_layers=2) then nn.Linear(rnn_units, hid)
+    for (int l = 0; l < 2; ++l) {
+      const std::string sl = std::to_string(l);
+      b.add_param("enhance.weight_ih_l" + sl, {4 * H, l == 0 ? hid : H}, true);
+      b.add_param("enhance.weight_hh_l" + sl, {4 * H, H}, true);
+      b.add_param("enhance.bias_ih_l" + sl, {4 * H}, true);
+      b.add_param("enhance.bias_hh_l" + sl, {4 * H}, true);
+    }
+    b.add_param("tranform.weight", {hid, H}, true);
+    b.add_param("tranform.bias", {hid}, true);
+  }
+  for (int l = 0; l < (cx ? NL : 0); ++l) {
     const int I = (l == 0 ? hid : cfg.rnn_units) / 2;
     const std::string p = "enhance." + std::to_string(l);
     for (const char* part : {"real_lstm", "imag_lstm"}) {
@@ -555,7 +567,82 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   struct Lstm { RunGemm gx[2]; Builder::Coef cgx[2]; std::function<void(int, int32_t*)> bgx; Ptr gxb, h, gates, cst, hc; RunGemm hh[4]; Builder::Coef chh[4]; };
   std::vector<Lstm> ls(NL);
   Ptr lin = encz[n - 1];
-  for (int l = 0; l < NL; ++l) {
+  // ---- cfg.lstm == 'real': two stacked real LSTM layers over all D*Cl features (feature order c*D + d, models.py:214-218)
+  struct RealL { RunGemm gx, hh; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gxb, h, gates, cst; const ParamInfo* Whh; };
+  RealL rl[2];
+  auto real_cell = [&](LstmCell& cl, int l, int t, bool fwd, Ptr dh, Ptr dcb, Ptr dgates) {
+    cl.gates = b.mk(A_WS, rl[l].gxb.off + (int64_t)t * 4 * H * 4);
+    cl.c = b.mk(A_WS, rl[l].cst.off + (int64_t)t * H * 4);
+    cl.c_prev = t > 0 ? b.mk(A_WS, rl[l].cst.off + (int64_t)(t - 1) * H * 4) : b.none();
+    cl.h = fwd ? b.mk(A_WS, rl[l].h.off + (int64_t)t * H * esize(adt)) : b.none();
+    cl.dh = fwd ? b.none() : b.mk(A_WS, dh.off + (int64_t)t * H * 4);
+    cl.dc = fwd ? b.none() : dcb;
+    cl.dgates = fwd ? b.none() : b.mk(A_WS, dgates.off + (int64_t)t * 4 * H * esize(adt));
+    cl.rows = B; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = fwd ? t == 0 : t == T - 1;
+    cl.G = 1; cl.Bg = B; cl.unit_major = 1;
+    cl.rs[0] = (int64_t)T * 4 * H; cl.rs[1] = cl.rs[2] = cl.rs[3] = (int64_t)T * H; cl.rs[4] = (int64_t)T * 4 * H;
+  };
+  if (!cx) {
+    for (int l = 0; l < 2; ++l) {
+      const std::string nm = "lstm" + std::to_string(l), sl = std::to_string(l);
+      const ParamInfo &Wih = b.par("enhance.weight_ih_l" + sl), &Whh = b.par("enhance.weight_hh_l" + sl);
+      const ParamInfo &bih = b.par("enhance.bias_ih_l" + sl), &bhh = b.par("enhance.bias_hh_l" + sl);
+      RealL& Lr = rl[l];
+      Lr.Whh = &Whh;
+      Lr.gxb = b.ws(nm + ".gx", BT * 4 * H, DT_F32);
+      Lr.h = b.ws(nm + ".h", BT * H, adt);
+      Lr.gates = b.ws(nm + ".gates", BT * 4 * H, DT_F32);
+      Lr.cst = b.ws(nm + ".c", BT * H, DT_F32);
+      RunGemm g = Builder::gemm0();
+      g.x[0] = lin; g.xdt = adt; g.ydt = DT_F32;
+      const int rowlen = l == 0 ? D * Cl : H;
+      g.bstride[0] = (int64_t)T * rowlen; g.tstride[0] = rowlen; g.rowlen[0] = rowlen; g.Tin[0] = T;
+      g.M = (int)BT; g.Tout = T; g.Fo = 1;
+      if (l == 0) { g.nseg = D; for (int dd = 0; dd < D; ++dd) g.seg[dd] = Seg{0, 0, dd * Cl, Cl, 0}; }
+      else { g.nseg = 1; g.seg[0] = Seg{0, 0, 0, H, 0}; }
+      g.N = 4 * H;
+      Builder::layout_segs(g);
+      const int I = l == 0 ? hid : H;
+      const ParamInfo* Wp = &Wih;
+      Lr.cgx = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)gate_torch_row(nn, H) * I + (l == 0 ? j * D + sg : j), 1); };
+      const ParamInfo *bi = &bih, *bh = &bhh;
+      Lr.bgx = [=](int nn, int32_t* o) { o[0] = pe(*bi, gate_torch_row(nn, H), 1); o[1] = pe(*bh, gate_torch_row(nn, H), 1); };
+      b.pack_weights(F, g, Lr.cgx, nm + ".ih", 200 + l, &Lr.bgx);
+      g.y = Lr.gxb; g.y_bstride = (int64_t)T * 4 * H; g.y_tstride = 4 * H;
+      b.push(F, OP_RUNGEMM, 200 + l).g = g;
+      Lr.gx = g;
+      if (!stepped) {
+        LstmRec& r = b.push(F, OP_LSTM_FWD, 200 + l).lstm;
+        r.gx = Lr.gxb; r.whh[0] = r.whh[1] = b.pptr("enhance.weight_hh_l" + sl);
+        r.h = Lr.h; r.gates = Lr.gates; r.c = Lr.cst; r.dh = r.dgates = b.none();
+        r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = DT_F32;
+      } else {
+        RunGemm hg = Builder::gemm0();
+        hg.x[0] = Lr.h; hg.xdt = adt; hg.ydt = DT_F32;
+        hg.fstride[0] = T * H; hg.rowlen[0] = (int)(BT * H); hg.Tin[0] = 1;
+        hg.M = B; hg.Tout = 1; hg.Fo = B;
+        hg.nseg = 1; hg.seg[0] = Seg{0, 0, 0, H, 0};
+        hg.N = 4 * H;
+        Builder::layout_segs(hg);
+        const ParamInfo* Wh = &Whh;
+        Builder::Coef chh = [=](int nn, int sg, int j) -> int32_t { return pe(*Wh, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
+        b.pack_weights(F, hg, chh, nm + ".hh", 200 + l);
+        hg.y = Lr.gxb; hg.y_fstride = T * 4 * H; hg.flags = kRunAccum;
+        Lr.hh = hg;
+        for (int t = 0; t < T; ++t) {
+          if (t > 0) {
+            RunGemm q = hg;
+            q.base[0] = (t - 1) * H;
+            q.y_off = t * 4 * H;
+            b.push(F, OP_RUNGEMM, 200 + l).g = q;
+          }
+          real_cell(b.push(F, OP_CELL_FWD, 200 + l).cell, l, t, true, b.none(), b.none(), b.none());
+        }
+      }
+      lin = Lr.h;
+    }
+  }
+  for (int l = 0; l < (cx ? NL : 0); ++l) {
     const std::string nm = "lstm" + std::to_string(l);
     const std::string pp = "enhance." + std::to_string(l);
     const ParamInfo* Wih[2] = {&b.par(pp + ".real_lstm.weight_ih_l0"), &b.par(pp + ".imag_lstm.weight_ih_l0")};
@@ -660,7 +747,22 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   RunGemm proj = Builder::gemm0();
   Builder::Coef cproj;
   std::function<void(int, int32_t*)> bproj;
-  {
+  if (!cx) {                                   // tranform: Linear(rnn_units -> D*Cl), output feature c*D + d -> decoder input [B][T][D][Cl]
+    const ParamInfo &Wt = b.par("tranform.weight"), &bt = b.par("tranform.bias");
+    RunGemm& g = proj;
+    g.x[0] = lin; g.xdt = adt; g.ydt = adt;
+    g.bstride[0] = (int64_t)T * H; g.tstride[0] = H; g.rowlen[0] = H; g.Tin[0] = T;
+    g.M = (int)BT; g.Tout = T; g.Fo = 1;
+    g.nseg = 1; g.seg[0] = Seg{0, 0, 0, H, 0};
+    g.N = D * Cl;
+    Builder::layout_segs(g);
+    const ParamInfo *Wp = &Wt, *bp = &bt;
+    cproj = [=](int nn, int s_, int j) -> int32_t { const int dd = nn / Cl, cc = nn % Cl; return pe(*Wp, (int64_t)(cc * D + dd) * H + j, 1); };
+    bproj = [=](int nn, int32_t* o) { const int dd = nn / Cl, cc = nn % Cl; o[0] = pe(*bp, cc * D + dd, 1); o[1] = 0; };
+    b.pack_weights(F, g, cproj, "proj", 300, &bproj);
+    g.y = decin; g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl;
+    b.push(F, OP_RUNGEMM, 300).g = g;
+  } else {
     const std::string pp = "enhance." + std::to_string(NL - 1);
     const ParamInfo* Wt[2] = {&b.par(pp + ".r_trans.weight"), &b.par(pp + ".i_trans.weight")};
     const ParamInfo* bt[2] = {&b.par(pp + ".r_trans.bias"), &b.par(pp + ".i_trans.bias")};
@@ -921,9 +1023,94 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         b.push(R, OP_RUNGEMM, 400 + d).g = g;
       }
     }
+    // ---- cfg.lstm == 'real': tranform, then the two LSTM layers last to first, then the gradient into the encoder output
+    if (!cx) {
+      Ptr dh[2] = {b.ws("lstm0.dh", BT * H, DT_F32), b.ws("lstm1.dh", BT * H, DT_F32)};
+      b.cur_lane = 1;
+      b.wgrad(R, proj, d_decin, cproj, 300, &bproj);
+      b.cur_lane = 0;
+      {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = d_decin; g.xdt = adt; g.ydt = DT_F32;
+        g.bstride[0] = (int64_t)T * D * Cl; g.tstride[0] = D * Cl; g.rowlen[0] = D * Cl; g.Tin[0] = T;
+        g.M = (int)BT; g.Tout = T; g.Fo = 1;
+        g.nseg = 1; g.seg[0] = Seg{0, 0, 0, D * Cl, 0};
+        g.N = H;
+        Builder::layout_segs(g);
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return cproj(j, 0, nn); };
+        b.pack_weights(R, g, coef, "proj.dg", 300);
+        g.y = dh[1]; g.y_bstride = (int64_t)T * H; g.y_tstride = H;
+        b.push(R, OP_RUNGEMM, 300).g = g;
+      }
+      for (int l = 1; l >= 0; --l) {
+        const std::string nm = "lstm" + std::to_string(l), sl = std::to_string(l);
+        RealL& Lr = rl[l];
+        Ptr dgates = b.ws(nm + ".dgates", BT * 4 * H, adt);
+        if (!stepped) {
+          LstmRec& r = b.push(R, OP_LSTM_BWD, 200 + l).lstm;
+          r.gx = Lr.gxb; r.whh[0] = r.whh[1] = b.pptr("enhance.weight_hh_l" + sl);
+          r.h = Lr.h; r.gates = Lr.gates; r.c = Lr.cst; r.dh = dh[l]; r.dgates = dgates;
+          r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = adt;
+        } else {
+          Ptr dcb = b.ws(nm + ".dc", (int64_t)B * H, DT_F32);
+          RunGemm rb = Builder::gemm0();
+          rb.x[0] = dgates; rb.xdt = adt; rb.ydt = DT_F32;
+          rb.fstride[0] = T * 4 * H; rb.rowlen[0] = (int)(BT * 4 * H); rb.Tin[0] = 1;
+          rb.M = B; rb.Tout = 1; rb.Fo = B;
+          rb.nseg = 1; rb.seg[0] = Seg{0, 0, 0, 4 * H, 0};
+          rb.N = H;
+          Builder::layout_segs(rb);
+          const ParamInfo* Wh = Lr.Whh;
+          Builder::Coef cT = [=](int nn, int sg, int j) -> int32_t { return pe(*Wh, (int64_t)gate_torch_row(j, H) * H + nn, 1); };
+          b.pack_weights(R, rb, cT, nm + ".hhT", 200 + l);
+          rb.y = dh[l]; rb.y_fstride = T * H; rb.flags = kRunAccum;
+          for (int t = T - 1; t >= 0; --t) {
+            real_cell(b.push(R, OP_CELL_BWD, 200 + l).cell, l, t, false, dh[l], dcb, dgates);
+            if (t > 0) {
+              RunGemm q = rb;
+              q.base[0] = t * 4 * H;
+              q.y_off = (t - 1) * H;
+              b.push(R, OP_RUNGEMM, 200 + l).g = q;
+            }
+          }
+        }
+        RunGemm fw = Lr.gx;
+        fw.ydt = adt;
+        b.wgrad(R, fw, dgates, Lr.cgx, 200 + l, &Lr.bgx);
+        {                                                // W_hh: dW[n][k] = sum_t dgates[t][n] * h[t-1][k]
+          RunGemm f = Builder::gemm0();
+          f.x[0] = Lr.h; f.xdt = adt; f.ydt = adt;
+          f.bstride[0] = (int64_t)T * H; f.tstride[0] = H; f.rowlen[0] = H; f.Tin[0] = T;
+          f.M = (int)BT; f.Tout = T; f.Fo = 1;
+          f.nseg = 1; f.seg[0] = Seg{0, -1, 0, H, 0};
+          f.N = 4 * H;
+          Builder::layout_segs(f);
+          f.y_bstride = (int64_t)T * 4 * H; f.y_tstride = 4 * H;
+          const ParamInfo* Wh = Lr.Whh;
+          Builder::Coef chh = [=](int nn, int sg, int j) -> int32_t { return pe(*Wh, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
+          b.wgrad(R, f, dgates, chh, 200 + l, nullptr);
+        }
+        const int nout = l == 0 ? D : 1;                 // input gradient: layer 1 -> dh of layer 0 ; layer 0 -> encoder output, one slice per d
+        for (int q = 0; q < nout; ++q) {
+          RunGemm g = Builder::gemm0();
+          g.x[0] = dgates; g.xdt = adt;
+          g.bstride[0] = (int64_t)T * 4 * H; g.tstride[0] = 4 * H; g.rowlen[0] = 4 * H; g.Tin[0] = T;
+          g.M = (int)BT; g.Tout = T; g.Fo = 1;
+          g.nseg = 1; g.seg[0] = Seg{0, 0, 0, 4 * H, 0};
+          g.N = l == 0 ? Cl : H;
+          Builder::layout_segs(g);
+          const Builder::Coef cf = Lr.cgx;
+          Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return l == 0 ? cf(j, q, nn) : cf(j, 0, nn); };
+          b.pack_weights(R, g, coef, nm + ".dx" + std::to_string(q), 200 + l);
+          if (l == 0) { g.ydt = adt; g.y = d_encz[n - 1]; g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl; g.y_off = q * Cl; }
+          else { g.ydt = DT_F32; g.y = dh[0]; g.y_bstride = (int64_t)T * H; g.y_tstride = H; }
+          b.push(R, OP_RUNGEMM, 200 + l).g = g;
+        }
+      }
+    }
     // ---- projection backward
     Ptr dhc_next = b.ws("dhc" + std::to_string(NL - 1), BT * 2 * H, DT_F32);
-    {
+    if (cx) {
       b.cur_lane = 1;
       b.wgrad(R, proj, d_decin, cproj, 300, &bproj);
       b.cur_lane = 0;
@@ -940,7 +1127,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.push(R, OP_RUNGEMM, 300).g = g;
     }
     // ---- LSTM backward
-    for (int l = NL - 1; l >= 0; --l) {
+    for (int l = cx ? NL - 1 : -1; l >= 0; --l) {
       const std::string nm = "lstm" + std::to_string(l);
       const std::string pp = "enhance." + std::to_string(l);
       const ParamInfo* Whh[2] = {&b.par(pp + ".real_lstm.weight_hh_l0"), &b.par(pp + ".imag_lstm.weight_hh_l0")};

@@ -291,8 +291,6 @@ class DCCRN(_SefdModule):
         self.act_dtype = cfg.act_dtype
         self._lstm_kind = cfg.lstm
         self._skip = bool(cfg.skip_type)
-        if cfg.lstm != 'complex':
-            raise NotImplementedError("cfg.lstm == 'real' is not on the HIP path yet")
         self.stft = ConvSTFT(win_len, win_inc, fft_len, win_type, 'complex')
         self.istft = ConviSTFT(win_len, win_inc, fft_len, win_type, 'complex')
         self.encoder = nn.ModuleList()
@@ -303,12 +301,17 @@ class DCCRN(_SefdModule):
                 ComplexConv2d(kn[idx], kn[idx + 1], kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 1)),
                 nn.BatchNorm2d(kn[idx + 1]), nn.PReLU()))
         hidden_dim = fft_len // (2 ** len(kn))
-        rnns = []
-        for idx in range(rnn_layers):
-            rnns.append(NavieComplexLSTM(
-                input_size=hidden_dim * kn[-1] if idx == 0 else rnn_units, hidden_size=rnn_units,
-                projection_dim=hidden_dim * kn[-1] if idx == rnn_layers - 1 else None))
-        self.enhance = nn.Sequential(*rnns)      # registered here: the reference assigns it before the decoder is filled
+        if cfg.lstm == 'complex':
+            rnns = []
+            for idx in range(rnn_layers):
+                rnns.append(NavieComplexLSTM(
+                    input_size=hidden_dim * kn[-1] if idx == 0 else rnn_units, hidden_size=rnn_units,
+                    projection_dim=hidden_dim * kn[-1] if idx == rnn_layers - 1 else None))
+            self.enhance = nn.Sequential(*rnns)  # registered here: the reference assigns it before the decoder is filled
+        else:                                    # models.py:96-105: two real layers over all features + `tranform` (sic)
+            self.enhance = nn.LSTM(input_size=hidden_dim * kn[-1], hidden_size=rnn_units, num_layers=2, dropout=0.0,
+                                   bidirectional=False, batch_first=False)
+            self.tranform = nn.Linear(rnn_units, hidden_dim * kn[-1])
         mult = 2 if cfg.skip_type else 1
         for idx in range(len(kn) - 1, 0, -1):
             mods = [ComplexConvTranspose2d(kn[idx] * mult, kn[idx - 1], kernel_size=(kernel_size, 2), stride=(2, 1),
@@ -319,6 +322,8 @@ class DCCRN(_SefdModule):
         # state_dict order of the reference: stft, istft, encoder, decoder, enhance
         enh = self._modules.pop('enhance')
         self._modules['enhance'] = enh
+        if 'tranform' in self._modules:
+            self._modules['tranform'] = self._modules.pop('tranform')
         self._init_runtime_state()
 
     def _make_plan(self, B, L, training):

@@ -71,12 +71,12 @@ SMALL_PARAMS = lambda name: (name.startswith("encoder.0.0.") or name.endswith(".
                              or name.startswith("decoder.5.0.") or name.endswith("bias_hh_l0"))
 
 
-def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True):
+def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True, lstm="complex"):
     cfg.dccrn_kernel_num = list(kernel_num)
     cfg.masking_mode = mask
     cfg.loss = loss
     cfg.perceptual = perceptual
-    cfg.lstm = "complex"
+    cfg.lstm = lstm
     cfg.skip_type = True
     torch.manual_seed(0)
     m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask)
@@ -323,6 +323,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "wide":          # only the wide-LSTM case (rnn_units 512, DCCRN-large's LSTM width)
         dccrn_case(cfg, models, "wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR", False, 1, 2000, store_taps=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "real":          # only the cfg.lstm == 'real' case
+        dccrn_case(cfg, models, "real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR", False, 2, 3000, store_taps=False, lstm="real")
+        cfg.lstm = "complex"
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "eval":          # regenerate only the validation-path case
         dccrn_eval_case(cfg, models, "small_eval", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", 2, 4000, 3, 5000)
         return
@@ -343,6 +347,8 @@ def main():
     fsn_case(cfg, models, tfm, "small_mse", 2, 6000, hidden=(128, 64))
     dccrn_eval_case(cfg, models, "small_eval", small, 128, "C", "SI-SNR", 2, 4000, 3, 5000)
     dccrn_case(cfg, models, "wide_C_sdr", small, 512, "C", "SDR", False, 1, 2000, store_taps=False)
+    dccrn_case(cfg, models, "real_E_sisnr", small, 256, "E", "SI-SNR", False, 2, 3000, store_taps=False, lstm="real")
+    cfg.lstm = "complex"
 
 
 if __name__ == "__main__":

@@ -20,17 +20,18 @@ CASES = [
     ("small_E_sisdr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SDR"),
     ("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR"),
     ("wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR"),        # rnn_units 512: per-time-step LSTM path (plan.cpp `stepped`)
+    ("real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR"),   # cfg.lstm == 'real': nn.LSTM(2 layers) + tranform
 ]
 
 
-def make_model(kn, ru, mask, loss):
+def make_model(kn, ru, mask, loss, lstm="complex"):
     import sefd_amd
     from sefd_amd import config as cfg, models
     cfg.dccrn_kernel_num = list(kn)
     cfg.masking_mode = mask
     cfg.loss = loss
     cfg.perceptual = False
-    cfg.lstm = "complex"
+    cfg.lstm = lstm
     cfg.skip_type = True
     cfg.act_dtype = "fp32"
     m = models.DCCRN(rnn_units=ru, masking_mode=mask)
@@ -46,7 +47,7 @@ def noise_bias(k):
 def test_module_step_against_reference_golden(name, kn, ru, mask, loss):
     g = load_golden("dccrn_" + name)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
-    m = make_model(kn, ru, mask, loss)
+    m = make_model(kn, ru, mask, loss, lstm="real" if name.startswith("real") else "complex")
     m.train()
     x, y = make_signals(B, L)
     x, y = x.cuda(), y.cuda()

@@ -91,13 +91,14 @@ CASES = [
     ("small_E_sisnr_lms", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", "LMS"),
     ("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR", False),
     ("wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR", False),
+    ("real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR", False),      # cfg.lstm == 'real'
 ]
 
 
 @pytest.mark.parametrize("name,kn,ru,mask,loss,perc", CASES)
 def test_dccrn_step_against_reference(name, kn, ru, mask, loss, perc):
     g = load_golden("dccrn_" + name)
-    cfg = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode=mask)
+    cfg = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode=mask, lstm="real" if name.startswith("real") else "complex")
     P = oracle_params(cfg)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     x, y = make_signals(B, L)

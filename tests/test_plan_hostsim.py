@@ -62,6 +62,13 @@ def test_hostsim_forced_per_step_lstm_matches_too(monkeypatch):
     _check_plan_vs_oracle("E", "SI-SNR", SMALL, 2, 4000)
 
 
+@pytest.mark.parametrize("ru", [128, 256])
+def test_hostsim_real_lstm_variant(ru):
+    """cfg.lstm == 'real' (models.py:96-105, 214-218): nn.LSTM(2 layers) over all D*C features + `tranform`; rnn_units 128
+    runs the persistent recurrence kernels' op, 256 (the reference default) the per-time-step path."""
+    _check_plan_vs_oracle("E", "SI-SNR", dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=ru, lstm="real"), 2, 3000)
+
+
 def _check_plan_vs_oracle(mode, loss, SMALL, B, L):
     cfg = DCCRNConfig(masking_mode=mode, **SMALL)
     P = oracle_params(cfg)
