@@ -559,6 +559,11 @@ __global__ void mask_fwd_kernel(const Mask d, const ArenaBases ab) {
         sincosf(atan2f(si, sr), &sn, &cs);
         er = em * cs; ei = em * sn;
         emag = em;
+      } else if (d.mode == 5) {                  // CRN spectral mapping: magnitude = decoder output, noisy phase
+        float sn, cs;
+        sincosf(atan2f(si, sr), &sn, &cs);
+        er = mr * cs; ei = mr * sn;
+        emag = mr;
       } else if (d.mode == 0) {
         const float mag = sqrtf(sr * sr + si * si + 1e-8f);
         const float ph = atan2f(si, sr);
@@ -578,7 +583,7 @@ __global__ void mask_fwd_kernel(const Mask d, const ArenaBases ab) {
     }
     est[i * 2] = er;
     est[i * 2 + 1] = ei;
-    if (d.mode == 3 && slot >= 1) reinterpret_cast<float*>(rp(ab, d.estm))[f * d.NF + slot - 1] = emag;
+    if ((d.mode == 3 || d.mode == 5) && slot >= 1) reinterpret_cast<float*>(rp(ab, d.estm))[f * d.NF + slot - 1] = emag;
   }
 }
 
@@ -606,11 +611,17 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
       const float sr = spec[si_], si = spec[si_ + 1];
       const float der = dest[si_], dei = dest[si_ + 1];
       const float mr = ld_elem(mask, d.mdt, mo), mi = d.mch >= 2 ? ld_elem(mask, d.mdt, mo + 1) : 0.f;
-      if (d.mode == 3) {
-        const float tm = tanhf(mr);
+      if (d.mode == 3 || d.mode == 5) {
         float sn, cs;
         sincosf(atan2f(si, sr), &sn, &cs);
-        gr = (der * cs + dei * sn) * sqrtf(sr * sr + si * si) * (1.f - tm * tm);
+        float d_em = der * cs + dei * sn;
+        if (d.destm.arena >= 0) d_em += reinterpret_cast<const float*>(rp(ab, d.destm))[f * d.NF + k + 1];
+        if (d.mode == 3) {
+          const float tm = tanhf(mr);
+          gr = d_em * sqrtf(sr * sr + si * si) * (1.f - tm * tm);
+        } else {
+          gr = d_em;
+        }
       } else if (d.mode == 0) {
         const float mag = sqrtf(sr * sr + si * si + 1e-8f);
         const float ph = atan2f(si, sr);
@@ -753,7 +764,7 @@ __global__ __launch_bounds__(256) void specout_bwd_kernel(const SpecOut d, const
   __shared__ float tr[32][33], ti[32][33];
   float* dest = reinterpret_cast<float*>(rp(ab, d.est));
   const float* gr = reinterpret_cast<const float*>(rp(ab, d.out_real));
-  const float* gi = reinterpret_cast<const float*>(rp(ab, d.out_imag));
+  const float* gi = d.mode == 2 ? nullptr : reinterpret_cast<const float*>(rp(ab, d.out_imag));
   const int NS = d.NF + 1;
   const int b = blockIdx.z, t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -762,7 +773,7 @@ __global__ __launch_bounds__(256) void specout_bwd_kernel(const SpecOut d, const
     float vr = 0.f, vi = 0.f;
     if (t < d.T && k < d.NF) {
       const int64_t o = ((int64_t)b * d.NF + k) * d.T + t;
-      vr = gr[o]; vi = gi[o];
+      vr = gr[o]; vi = d.mode == 2 ? 0.f : gi[o];
     }
     tr[r][tx] = vr; ti[r][tx] = vi;
   }
@@ -770,6 +781,7 @@ __global__ __launch_bounds__(256) void specout_bwd_kernel(const SpecOut d, const
   for (int r = ty; r < 32; r += 8) {
     const int t = t0 + r, k = k0 + tx;
     if (t < d.T && k < d.NF) {
+      if (d.mode == 2) { dest[((int64_t)b * d.T + t) * d.NF + k] = tr[tx][r]; continue; }     // d est_mags [B][NF][T] -> [B*T][NF]
       const int64_t o = (((int64_t)b * d.T + t) * NS + k + 1) * 2;
       if (d.accumulate) { dest[o] += tr[tx][r]; dest[o + 1] += ti[tx][r]; }
       else { dest[o] = tr[tx][r]; dest[o + 1] = ti[tx][r]; }

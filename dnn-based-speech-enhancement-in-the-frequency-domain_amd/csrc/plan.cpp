@@ -886,7 +886,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   {
     const int Fo = Fe[0], Co = std::max(2, CP);
     mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.dest = mk.dmask = b.none();
-    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt; mk.mch = Co; mk.estm = b.none();
+    mk.frames = BT; mk.NF = NF; mk.mode = cfg.mask_mode; mk.mdt = adt; mk.mch = Co; mk.estm = mk.destm = b.none();
     mk.mask_fstride = (int64_t)Fo * Co; mk.mask_bstride = (int64_t)(T + 1) * Fo * Co; mk.mask_base = (int64_t)Fo * Co; mk.T = T;
     b.push(F, OP_MASK_FWD, 500).mask = mk;
   }
@@ -1305,7 +1305,9 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   const int MS = NF + 7, MO = 7;            // magnitude rows: bin k at element k + 7 -> bin 1 is 16-byte aligned in fp32 and bf16
   P->T = T;
   P->NF = NF;
-  if (KS != 5 || n < 1 || n > 7 || cfg.mask_mode != 0) { P->error = "CRN: unsupported configuration (only masking mode 'E')"; return P; }
+  // models.py:506-532: 'Direct(None make)' (mask_mode 4) = spectral mapping, every other cfg.masking_mode = the tanh magnitude mask
+  if (KS != 5 || n < 1 || n > 7) { P->error = "CRN: unsupported configuration"; return P; }
+  const bool direct = cfg.mask_mode == 4;
   std::vector<int> ch(n + 1), Fe(n + 1);
   ch[0] = 1;
   for (int i = 0; i < n; ++i) ch[i + 1] = cfg.kernel_num[i] / 2;
@@ -1358,7 +1360,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   Ptr io_or = b.io("out_real", (int64_t)B * NF * T);      // est_mags
   Ptr io_oi = b.io("out_imag", (int64_t)B * NF * T);      // target_mags
   Ptr io_gw = b.io("grad_wav", (int64_t)B * L);
-  b.io("grad_real", (int64_t)B * NF * T);
+  Ptr io_gr = b.io("grad_real", (int64_t)B * NF * T);     // gradient w.r.t. est_mags (crn_direct_train's loss lives there)
   b.io("grad_imag", (int64_t)B * NF * T);
   Ptr io_tgt = b.io("tgt", (int64_t)B * L);
 
@@ -1602,8 +1604,8 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   std::memset(&mk, 0, sizeof(mk));
   {
     const int Fo = Fe[0];
-    mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.estm = estm; mk.dest = mk.dmask = b.none();
-    mk.frames = BT; mk.NF = NF; mk.mode = 3; mk.mdt = adt; mk.mch = 1;
+    mk.spec = spec; mk.mask = decy[n - 1]; mk.est = est; mk.estm = estm; mk.dest = mk.dmask = mk.destm = b.none();
+    mk.frames = BT; mk.NF = NF; mk.mode = direct ? 5 : 3; mk.mdt = adt; mk.mch = 1;
     mk.mask_fstride = Fo; mk.mask_bstride = (int64_t)(T + 1) * Fo; mk.mask_base = Fo; mk.T = T;
     b.push(F, OP_MASK_FWD, 500).mask = mk;
   }
@@ -1667,8 +1669,13 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
     }
     Ptr d_decin = b.ws("decin.d", BT * D * Cl, adt);
     {
+      Ptr d_estm = b.ws("destm", BT * NF, DT_F32);       // io.grad_real [B][NF][T] -> [B*T][NF]
+      SpecOut s2;
+      std::memset(&s2, 0, sizeof(s2));
+      s2.est = d_estm; s2.out_real = io_gr; s2.out_imag = b.none(); s2.B = B; s2.T = T; s2.NF = NF; s2.mode = 2;
+      b.push(R, OP_SPECOUT_BWD, 503).so = s2;
       Mask m2 = mk;
-      m2.dest = dest; m2.dmask = d_decy[n - 1];
+      m2.dest = dest; m2.dmask = d_decy[n - 1]; m2.destm = d_estm;
       b.push(R, OP_MASK_BWD, 500).mask = m2;
     }
     auto bn_bwd = [&](int tag, Ptr y, Ptr dz0, Ptr dz1, Ptr mi, const std::string& pp, int C, int64_t Rr, int64_t rpb, int skip, Ptr dy,

@@ -178,7 +178,9 @@ struct Mask {
   int64_t mask_bstride, mask_base;
   int32_t T;
   int32_t mch;                 // channels of the mask tensor: 2 (DCCRN complex mask) or 1 (CRN magnitude mask, mode 3)
-  Ptr estm;                    // mode 3 only: est_mags = tanh(mask) * |spec|  as [B*T][NF] fp32 (CRN.forward's first output)
+  Ptr estm;                    // modes 3 / 5: CRN.forward's first output as [B*T][NF] fp32 (mode 3: tanh(mask) * |spec| ; mode 5, CRN
+                               // 'Direct(None make)' models.py:506-517: the decoder output itself, bin 0 = 0, noisy phase re-attached)
+  Ptr destm;                   // backward, modes 3 / 5, optional: gradient w.r.t. that first output (crn_direct_train's loss, trainer.py:169-170)
 };
 
 // |spec| for the CRN encoder (ConvSTFT 'real', tools_for_model.py:62-68: no eps): mags[f][MO + k] = sqrt(re^2 + im^2), k < NF;

@@ -437,14 +437,15 @@ class CRN(_SefdModule):
         self._init_runtime_state()
 
     def _make_plan(self, B, L, training):
-        if self.masking_mode != 'E':
-            raise NotImplementedError("CRN on the HIP path: T-F masking only (cfg.masking_mode 'E' semantics, models.py:519-526)")
+        # models.py:506-532: 'Direct(None make)' = spectral mapping; any other cfg.masking_mode = tanh magnitude mask
+        mode = self.masking_mode if self.masking_mode == 'Direct(None make)' else "E"
         return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=1, rnn_units=2 * self.rnn_units, win_len=self.win_len,
-                    win_inc=self.win_inc, fft_len=self.fft_len, masking_mode="E", lstm="real", skip_type=self._skip,
+                    win_inc=self.win_inc, fft_len=self.fft_len, masking_mode=mode, lstm="real", skip_type=self._skip,
                     act_dtype=self.act_dtype, training=training, model="CRN", bn_world=getattr(self, "_bn_world", 1))
 
     def forward(self, inputs, targets=0):
-        """models.py:467-532: returns (est_mags, target_mags, out_wav).  Only out_wav carries gradient."""
+        """models.py:467-532: returns (est_mags, target_mags, out_wav).  est_mags (the network's magnitude output: mask x noisy
+        magnitude, or the mapped magnitude in 'Direct(None make)' mode) and out_wav carry gradient; target_mags does not."""
         if not torch.is_tensor(targets):
             raise AttributeError("CRN.forward needs targets (the reference calls self.stft(targets) unconditionally, models.py:505)")
         if not inputs.is_cuda:
@@ -456,7 +457,7 @@ class CRN(_SefdModule):
             self._flat_nbt += 1
         params = [p for _, p in self._trainable()]
         est_mags, target_mags, out_wav = _DCCRNFunction.apply(self, rt, inputs, targets.float().contiguous(), *params)
-        return est_mags.detach(), target_mags.detach(), out_wav
+        return est_mags, target_mags.detach(), out_wav
 
     def loss(self, estimated, target, out_mags=0, target_mags=0, perceptual=False):
         if perceptual:

@@ -624,6 +624,10 @@ void run_op(const Op& op, const AB& ab) {
               emag = std::tanh(mr) * std::sqrt(sr * sr + si * si);
               const double ph = std::atan2(si, sr);
               er = emag * std::cos(ph); ei = emag * std::sin(ph);
+            } else if (d.mode == 5) {
+              emag = mr;
+              const double ph = std::atan2(si, sr);
+              er = emag * std::cos(ph); ei = emag * std::sin(ph);
             } else if (d.mode == 0) {
               const double mag = std::sqrt(sr * sr + si * si + 1e-8), ph = std::atan2(si, sr), mm = std::sqrt(mr * mr + mi * mi);
               const double mph = std::atan2(mi / (mm + 1e-8), mr / (mm + 1e-8));
@@ -634,7 +638,7 @@ void run_op(const Op& op, const AB& ab) {
             else { er = sr * mr; ei = si * mi; }
           }
           est[i * 2] = (float)er; est[i * 2 + 1] = (float)ei;
-          if (d.mode == 3 && slot >= 1) ((float*)rp(ab, d.estm))[f * d.NF + slot - 1] = (float)emag;
+          if ((d.mode == 3 || d.mode == 5) && slot >= 1) ((float*)rp(ab, d.estm))[f * d.NF + slot - 1] = (float)emag;
         }
       break;
     }
@@ -655,9 +659,11 @@ void run_op(const Op& op, const AB& ab) {
               const int64_t s_ = (f * NS + k + 2) * 2;
               const double sr = spec[s_], si = spec[s_ + 1], der = dest[s_], dei = dest[s_ + 1];
               const double mr = ld(rp(ab, d.mask), d.mdt, mo), mi = d.mch >= 2 ? ld(rp(ab, d.mask), d.mdt, mo + 1) : 0.0;
-              if (d.mode == 3) {
+              if (d.mode == 3 || d.mode == 5) {
                 const double tm = std::tanh(mr), ph = std::atan2(si, sr);
-                gr = (der * std::cos(ph) + dei * std::sin(ph)) * std::sqrt(sr * sr + si * si) * (1 - tm * tm);
+                double d_em = der * std::cos(ph) + dei * std::sin(ph);
+                if (d.destm.arena >= 0) d_em += ((const float*)rp(ab, d.destm))[f * d.NF + k + 1];
+                gr = d.mode == 3 ? d_em * std::sqrt(sr * sr + si * si) * (1 - tm * tm) : d_em;
               } else if (d.mode == 0) {
                 const double mag = std::sqrt(sr * sr + si * si + 1e-8), ph = std::atan2(si, sr), mm = std::sqrt(mr * mr + mi * mi);
                 const double den = mm + 1e-8, rpv = mr / den, ipv = mi / den, mph = std::atan2(ipv, rpv), tm = std::tanh(mm), em = tm * mag;
@@ -721,6 +727,7 @@ void run_op(const Op& op, const AB& ab) {
         for (int t = 0; t < d.T; ++t)
           for (int k = 0; k < d.NF; ++k) {
             const int64_t e = (((int64_t)b * d.T + t) * NS + k + 1) * 2, o = ((int64_t)b * d.NF + k) * d.T + t;
+            if (op.kind == OP_SPECOUT_BWD && d.mode == 2) { est[((int64_t)b * d.T + t) * d.NF + k] = orr[o]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 3) { orr[2 * o] = est[e]; orr[2 * o + 1] = est[e + 1]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 2) { orr[o] = est[((int64_t)b * d.T + t) * d.NF + k]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 1) { orr[o] = std::sqrt(est[e] * est[e] + est[e + 1] * est[e + 1]); continue; }

@@ -200,6 +200,41 @@ def test_crn_hostsim_forward_backward_vs_oracle():
         assert rel_err(got[k], grads[k]) < (2e-3 if k.endswith(".2.weight") else 2e-4), k
 
 
+def test_crn_direct_mode_hostsim_vs_oracle():
+    """CRN 'Direct(None make)' (models.py:506-517) with crn_direct_train's loss (trainer.py:169-170): MSE between the mapped
+    magnitudes (first output) and the target magnitudes, plus a waveform term so both gradient entry points are exercised."""
+    from oracle.crn import CRNConfig, crn_forward, crn_state_shapes
+    B, L = 2, 3000
+    kn = (16, 32, 32, 64, 64, 64)
+    cfg = CRNConfig(kernel_num=kn, rnn_units=128, rnn_input_size=128, masking_mode="Direct(None make)")
+    P = formula_state_dict(crn_state_shapes(cfg))
+    plan = Plan(B, L, kernel_num=kn, rnn_units=128, model="CRN", masking_mode="Direct(None make)")
+    T, NF = plan.T, plan.NF
+    ar = plan.alloc_arenas("cpu")
+    fill_params(plan, ar, P)
+    x, y = make_signals(B, L)
+    plan.io(ar, "wav", (B, L)).copy_(x)
+    plan.io(ar, "tgt", (B, L)).copy_(y)
+    sim_run(plan, PHASE_FWD, ar)
+    Pg = {k: (v.clone().requires_grad_(True) if is_trainable(k) else v.clone()) for k, v in P.items()}
+    (out_mags, tmags, wav), _ = crn_forward(Pg, x, y, cfg, train=True)
+    assert rel_err(plan.io(ar, "out_real", (B, NF, T)), out_mags) < 5e-5
+    assert rel_err(plan.io(ar, "out_imag", (B, NF, T)), tmags) < 5e-5
+    assert rel_err(plan.io(ar, "out_wav", (B, L)), wav) < 5e-5
+    lossv = torch.nn.functional.mse_loss(out_mags, tmags) + 0.5 * main_loss("SI-SNR", wav, y)
+    names = [k for k in Pg if is_trainable(k)]
+    grads = dict(zip(names, torch.autograd.grad(lossv, [Pg[k] for k in names], retain_graph=True)))
+    gm, gw = torch.autograd.grad(lossv, [out_mags, wav])
+    plan.io(ar, "grad_real", (B, NF, T)).copy_(gm)
+    plan.io(ar, "grad_wav", (B, L)).copy_(gw)
+    sim_run(plan, PHASE_BWD, ar)
+    got = read_params(plan, ar, ARENA_GRAD)
+    for k in names:
+        if k.endswith("conv.bias") and not k.startswith("decoder.5."):
+            continue
+        assert rel_err(got[k], grads[k]) < (2e-3 if k.endswith(".2.weight") else 2e-4), k
+
+
 # ------------------------------------------------------------------------------------------------ FullSubNet
 def test_fsn_hostsim_forward_backward_vs_oracle():
     from oracle.fullsubnet import FSNConfig, fsn_forward, fsn_state_shapes, fsn_targets
