@@ -100,6 +100,25 @@ def dccrn_direct_train(model, optimizer, train_loader, DEVICE):
     return train_loss / max(batch_num, 1)
 
 
+def crn_direct_train(model, optimizer, train_loader, DEVICE):
+    """trainer.py:150-181: CRN spectral mapping ('Direct(None make)'): the loss compares the mapped magnitudes (first output
+    of `CRN.forward`) with the target magnitudes; the waveform output carries no loss."""
+    train_loss = torch.zeros((), device=DEVICE)
+    batch_num = 0
+    model.train()
+    for inputs, targets in train_loader:
+        batch_num += 1
+        inputs = inputs.float().to(DEVICE, non_blocking=True)
+        targets = targets.float().to(DEVICE, non_blocking=True)
+        output_mag, target_mag, _ = model(inputs, targets)
+        loss = model.loss(output_mag, target_mag)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        train_loss += loss.detach()
+    return train_loss / max(batch_num, 1)
+
+
 # ------------------------------------------------------------------------------------------------ validation
 def model_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers=None):
     """Validation pass of the T-F masking models (reference trainer.py:188-241): eval-mode plans (BatchNorm running

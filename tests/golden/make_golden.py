@@ -175,7 +175,8 @@ def crn_case(cfg, models, name, kernel_num, rnn_units, rnn_input, mask, loss, B,
     est_mags, target_mags, wav = m(x, y)
     for h in hooks:
         h.remove()
-    lossv = m.loss(wav, y)
+    # crn_direct_train (trainer.py:169-170) puts the loss on the magnitudes; the masking trainer on the waveform
+    lossv = m.loss(est_mags, target_mags) if mask == "Direct(None make)" else m.loss(wav, y)
     opt.zero_grad()
     lossv.backward()
     g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
@@ -323,6 +324,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "wide":          # only the wide-LSTM case (rnn_units 512, DCCRN-large's LSTM width)
         dccrn_case(cfg, models, "wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR", False, 1, 2000, store_taps=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "crn_direct":    # only CRN spectral mapping
+        crn_case(cfg, models, "small_direct_mse", (16, 32, 32, 64, 64, 64), 128, 128, "Direct(None make)", "MSE", 2, 4000)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "real":          # only the cfg.lstm == 'real' case
         dccrn_case(cfg, models, "real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR", False, 2, 3000, store_taps=False, lstm="real")
         cfg.lstm = "complex"
@@ -343,6 +347,7 @@ def main():
     dccrn_direct_case(cfg, models, "small_direct_mse", small, 128, "MSE", 2, 4000)
     crn_case(cfg, models, "default_E_mse", dflt, 256, 512, "E", "MSE", 2, 4000)
     crn_case(cfg, models, "small_E_sisnr", small, 128, 128, "E", "SI-SNR", 2, 4000)
+    crn_case(cfg, models, "small_direct_mse", small, 128, 128, "Direct(None make)", "MSE", 2, 4000)
     fsn_case(cfg, models, tfm, "default_mse", 2, 6000)
     fsn_case(cfg, models, tfm, "small_mse", 2, 6000, hidden=(128, 64))
     dccrn_eval_case(cfg, models, "small_eval", small, 128, "C", "SI-SNR", 2, 4000, 3, 5000)

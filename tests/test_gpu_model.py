@@ -246,6 +246,40 @@ def test_crn_module_step_against_reference_golden(name, kn, ru, ri, loss):
         m(x)                      # the reference crashes without targets too (models.py:505)
 
 
+def test_crn_direct_mode_against_reference_golden():
+    """CRN spectral mapping through `trainer.crn_direct_train` (trainer.py:150-181): loss on the mapped magnitudes."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models, trainer
+    g = load_golden("crn_small_direct_mse")
+    B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
+    kn = (16, 32, 32, 64, 64, 64)
+    cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.perceptual, cfg.skip_type, cfg.act_dtype = list(kn), "Direct(None make)", "MSE", False, True, "fp32"
+    m = models.CRN(rnn_units=128, rnn_input_size=128, masking_mode="Direct(None make)")
+    fill_state_dict_(m)
+    m = m.to("cuda").train()
+    x, y = make_signals(B, L)
+    out_mags, target_mags, wav = m(x.cuda(), y.cuda())
+    lossv = m.loss(out_mags, target_mags)
+    lossv.backward()
+    assert rel_err(out_mags, g["g/est_mags"]) < TOL
+    assert rel_err(target_mags, g["g/target_mags"]) < TOL
+    assert rel_err(wav, g["g/out_wav"]) < 2e-2          # phase of numerically-zero noisy bins decides a sign (tests/test_plan_hostsim.py)
+    assert abs(float(lossv) - float(g["g/loss"])) < TOL * max(1.0, abs(float(g["g/loss"])))
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    for k, v in sub(g, "g/grad_norm").items():
+        if not noise_bias(k):
+            assert abs(float(grads[k].double().norm()) - float(v)) <= TOL * float(v) + 1e-7, k
+    for k, v in sub(g, "g/grad").items():
+        if not noise_bias(k):
+            assert rel_l2(grads[k], v) < (5e-3 if k.endswith(".2.weight") else TOL), k
+    # one epoch of the trainer mirror over a single batch returns that batch's loss
+    m.zero_grad()
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    ep = trainer.crn_direct_train(m, opt, [(x, y)], "cuda")
+    assert abs(float(ep) - float(g["g/loss"])) < TOL * max(1.0, abs(float(g["g/loss"])))
+    cfg.masking_mode = "E"
+
+
 # ------------------------------------------------------------------------------------------------ LMS (tools_for_loss.py:120-249)
 def test_lms_loss_kernel_vs_oracle():
     import sefd_amd  # noqa: F401
