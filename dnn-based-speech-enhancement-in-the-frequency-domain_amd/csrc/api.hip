@@ -117,6 +117,7 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (!h->side) {
+    // (a lowest-priority side stream was measured: 14.44 / 14.57 vs 14.33 / 14.42 ms per step with equal priorities - kept equal)
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return -3;

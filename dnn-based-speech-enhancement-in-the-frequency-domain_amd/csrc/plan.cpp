@@ -358,6 +358,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // H <= 128: persistent recurrence kernels (W_hh resident in VGPRs).  Larger H (DCCRN-large: rnn_units 512) does not fit
   // the register file of one CU: the recurrence becomes one GEMM + one cell launch per time step on the same buffers.
   const bool stepped = H > 128 || getenv("SEFD_LSTM_STEPPED") != nullptr;
+  // all weight gradients ride the second stream (after the fork they run next to the encoder's dgrad / BatchNorm chain and
+  // fill the tails of its kernels: 14.42 -> 14.30 ms/step); SEFD_LANE_ALL=0 keeps only the decoder's there
+  const bool lane_all = !(getenv("SEFD_LANE_ALL") != nullptr && atoi(getenv("SEFD_LANE_ALL")) == 0);
   if (H % 16 != 0 || (adt == DT_BF16 && H % 32 != 0)) { P->error = "rnn_units/2 must be a multiple of 16 (32 for bf16)"; return P; }
   if (adt == DT_BF16 && H % 32 != 0) { P->error = "bf16: rnn_units/2 must be a multiple of 32"; return P; }
   if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
@@ -1193,7 +1196,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);
         RunGemm fw = ls[l].gx[p];
         fw.ydt = adt;                       // WGRAD reads dy = dgates (act dtype), not the fp32 gx the forward wrote
+        b.cur_lane = lane_all ? 1 : 0;
         b.wgrad(R, fw, dyp, ls[l].cgx[p], 200 + l, &ls[l].bgx);
+        b.cur_lane = 0;
       }
       for (int g4 = 0; g4 < 4; ++g4) {       // W_hh: dW[n][k] = sum_t dgates[g][t][n] * h[g][t-1][k]
         const int p = g4 / 2, set = g4 % 2;
@@ -1208,7 +1213,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         const ParamInfo* Wp = Whh[set];
         Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return pe(*Wp, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
         Ptr dyp = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);
+        b.cur_lane = lane_all ? 1 : 0;
         b.wgrad(R, f, dyp, coef, 200 + l, nullptr);
+        b.cur_lane = 0;
       }
       // input gradient of the layer
       Ptr dx_full;
@@ -1244,7 +1251,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const std::string nm = "enc" + std::to_string(i);
       const std::string pp = "encoder." + std::to_string(i);
       bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm);
+      b.cur_lane = lane_all ? 1 : 0;             // encoder weight gradients next to the dgrad chain
       b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
+      b.cur_lane = 0;
       if (i == 0) continue;
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]
       for (int par = 0; par < 2; ++par) {
