@@ -108,11 +108,11 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
   static const bool no_overlap = getenv("SEFD_NO_OVERLAP") != nullptr;
   bool two_lane = !no_overlap && first == 0 && last == (int)ops.size();
   if (two_lane) {
-    bool any = false, lstm = false;
-    for (const Op& op : ops) { any |= op.lane == 1; lstm |= op.kind == OP_LSTM_BWD; }
-    two_lane = any && lstm;
+    bool any1 = false, any2 = false, lstm = false;
+    for (const Op& op : ops) { any1 |= op.lane == 1; any2 |= op.lane == 2; lstm |= op.kind == OP_LSTM_BWD; }
+    two_lane = any2 || (any1 && lstm);
   }
-  if (!two_lane) {
+  if (!two_lane) {                                       // program order on one stream is always a valid schedule
     for (int i = first; i < last; ++i) launch(ops[i], st);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
@@ -123,35 +123,39 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return -3;
   }
   std::vector<int> held;
-  bool forked = false, joined = false;
+  bool has_lstm_bwd = false;
+  for (const Op& op : ops) has_lstm_bwd |= op.kind == OP_LSTM_BWD;
+  bool forked = !has_lstm_bwd;                           // no LSTM backward in this phase: lane-1 ops are never held back
+  bool side_busy = false;                                // the side stream holds work the main stream has not waited for
+  auto side_launch = [&](const Op& op) {                 // program order up to here is satisfied on the main stream
+    (void)hipEventRecord(h->ev_fork, st);
+    (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+    launch(op, h->side);
+    side_busy = true;
+  };
+  auto join = [&]() {
+    if (!side_busy) return;
+    (void)hipEventRecord(h->ev_join, h->side);
+    (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    side_busy = false;
+  };
   for (int i = first; i < last; ++i) {
     const Op& op = ops[i];
     if (op.lane == 1 && !forked) { held.push_back(i); continue; }
-    if (op.lane == 1) {                                  // after the fork point: program order is already satisfied up to here
-      (void)hipEventRecord(h->ev_fork, st);
-      (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-      launch(op, h->side);
-      continue;
-    }
+    if (op.lane == 1 || op.lane == 2) { side_launch(op); continue; }
     if (op.kind == OP_LSTM_BWD && !forked) {
       (void)hipEventRecord(h->ev_fork, st);              // everything the held ops read has been produced before this point
       launch(op, st);                                    // the recurrence takes its CUs first
       (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
       for (int j : held) launch(ops[j], h->side);
+      side_busy = side_busy || !held.empty();
       forked = true;
       continue;
     }
-    if (op.kind == OP_UNPACK && forked && !joined) {     // gathers every gradient partial: needs the side lane's results
-      (void)hipEventRecord(h->ev_join, h->side);
-      (void)hipStreamWaitEvent(st, h->ev_join, 0);
-      joined = true;
-    }
+    if (op.join || op.kind == OP_UNPACK) join();         // UNPACK gathers every gradient partial: needs the side lane's results
     launch(op, st);
   }
-  if (forked && !joined) {
-    (void)hipEventRecord(h->ev_join, h->side);
-    (void)hipStreamWaitEvent(st, h->ev_join, 0);
-  }
+  join();
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

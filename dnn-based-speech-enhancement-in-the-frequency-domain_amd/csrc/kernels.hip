@@ -516,10 +516,14 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_kernel(const LstmRec d, con
 __global__ void combine_fwd_kernel(const Combine d, const ArenaBases ab) {
   const char* h = rp(ab, d.h);
   char* out = rp(ab, d.out);
-  const int64_t n = d.rows * d.H, gsz = d.rows * d.H;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / d.H;
-    const int j = (int)(i - row * d.H);
+  const int64_t gsz = d.rows * d.H;
+  const int Tc = d.t1 > 0 ? d.t1 - d.t0 : 0;                 // chunked: rows (b, t0 <= t < t1)
+  const int64_t n = Tc > 0 ? (d.rows / d.T) * Tc * d.H : gsz;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row = q / d.H;
+    const int j = (int)(q - row * d.H);
+    if (Tc > 0) { const int64_t b = row / Tc; row = b * d.T + d.t0 + (row - b * Tc); }
+    const int64_t i = row * d.H + j;
     const float h0 = ld_elem(h, d.dt, i), h1 = ld_elem(h, d.dt, gsz + i), h2 = ld_elem(h, d.dt, 2 * gsz + i), h3 = ld_elem(h, d.dt, 3 * gsz + i);
     st_elem(out, d.dt, row * 2 * d.H + j, h0 - h3);
     st_elem(out, d.dt, row * 2 * d.H + d.H + j, h2 + h1);

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     }
   for (int i = threadIdx.x; i < 2 * 16 * hs; i += blockDim.x) ldsh[i] = 0;
   __syncthreads();
+  const int tb = d.t0, te = d.t1 > 0 ? d.t1 : T;         // this launch covers frames [tb, te); tb > 0 resumes from the saved state
 
   bool rvalid[4];
   int64_t rowbt[4];
@@ -70,9 +71,14 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
   int64_t so[4];                                // (g*GBT + row*T + t) * H + unit : element offset of the cell in h / c, x4 in gates
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    gxp[r] = gx + rowbt[r] * d.gx_ld + gate_col(0, unit);            // rows >= B alias row 0, never stored
-    so[r] = ((int64_t)g * GBT + rowbt[r]) * H + unit;
+    gxp[r] = gx + (rowbt[r] + tb) * d.gx_ld + gate_col(0, unit);     // rows >= B alias row 0, never stored
+    so[r] = ((int64_t)g * GBT + rowbt[r] + tb) * H + unit;
+    if (tb > 0) {                                                    // h[tb-1] into the LDS buffer step tb reads, c[tb-1] into registers
+      c[r] = cs[so[r] - H];
+      ldsh[(tb & 1) * 16 * hs + (4 * kq + r) * hs + unit] = hout[so[r] - H];
+    }
   }
+  if (tb > 0) __syncthreads();
   const int64_t gx_ld = d.gx_ld;
   auto load_gx = [&](int t, float4 (&dst)[4]) {                        // t is clamped: the last two prefetches re-read step T-1
     const int64_t inc = t < T - 1 ? gx_ld : 0;
@@ -120,16 +126,16 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     lds_barrier();
   };
   float4 b0v[4], b1v[4], b2v[4];
-  load_gx(0, b0v);
-  load_gx(1, b1v);
-  int t = 0;
-  for (; t + 3 <= T; t += 3) {
+  load_gx(tb, b0v);
+  load_gx(tb + 1, b1v);
+  int t = tb;
+  for (; t + 3 <= te; t += 3) {
     step(t, b0v, b2v);
     step(t + 1, b1v, b0v);
     step(t + 2, b2v, b1v);
   }
-  if (t < T) { step(t, b0v, b2v); ++t; }
-  if (t < T) { step(t, b1v, b0v); ++t; }
+  if (t < te) { step(t, b0v, b2v); ++t; }
+  if (t < te) { step(t, b1v, b0v); ++t; }
 }
 
 template <int HMAX>

@@ -645,6 +645,15 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       lin = Lr.h;
     }
   }
+  // Two complex layers, persistent bf16 kernels: the sequence is cut into chunks of frames and layer 1 (combine + input
+  // GEMM + recurrence of a chunk, second HIP stream) runs while layer 0 already works on the next chunk - the two 481-step
+  // recurrences (8 workgroups each, latency-bound) overlap instead of running back to back.  SEFD_LSTM_CHUNKS=1 disables.
+  // Measured (B = 32, T = 481): 1 chunk 14.08 ms/step, 2-6 chunks 13.84-13.94, 8: 13.94, 16: 14.50 -> 4.
+  int nchunk = getenv("SEFD_LSTM_CHUNKS") ? atoi(getenv("SEFD_LSTM_CHUNKS")) : 4;
+  if (!(cx && !stepped && adt == DT_BF16 && NL == 2) || nchunk < 2 || T < 8 * nchunk) nchunk = 1;
+  const bool pipe = nchunk > 1;
+  LstmRec pipe_rec[2];
+  RunGemm pipe_gx1[2];
   for (int l = 0; l < (cx ? NL : 0); ++l) {
     const std::string nm = "lstm" + std::to_string(l);
     const std::string pp = "enhance." + std::to_string(l);
@@ -686,18 +695,19 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       if (p == 1) g.bias = ls[l].gx[0].bias;
       g.y = b.mk(A_WS, ls[l].gxb.off + (int64_t)p * BT * 8 * H * 4);
       g.y_bstride = (int64_t)T * 8 * H; g.y_tstride = 8 * H; g.y_fstride = 0; g.y_off = 0;
-      b.push(F, OP_RUNGEMM, 200 + l).g = g;
+      if (pipe && l == 1) pipe_gx1[p] = g; else b.push(F, OP_RUNGEMM, 200 + l).g = g;
       ls[l].gx[p] = g; ls[l].cgx[p] = coef;
     }
     if (!stepped) {
-      Op& op = b.push(F, OP_LSTM_FWD, 200 + l);
-      LstmRec& r = op.lstm;
+      LstmRec r;
+      std::memset(&r, 0, sizeof(r));
       r.gx = ls[l].gxb;
       r.whh[0] = b.pptr(pp + ".real_lstm.weight_hh_l0"); r.whh[1] = b.pptr(pp + ".imag_lstm.weight_hh_l0");
       r.h = ls[l].h; r.gates = ls[l].gates; r.c = ls[l].cst;
       r.dh = r.dgates = b.none();
       for (int g4 = 0; g4 < 4; ++g4) r.gx_goff[g4] = (int64_t)(g4 / 2) * BT * 8 * H + (int64_t)(g4 % 2) * 4 * H;
       r.gx_ld = 8 * H; r.G = 4; r.nset = 2; r.B = B; r.T = T; r.H = H; r.hdt = adt; r.gdt = DT_F32;
+      if (pipe) pipe_rec[l] = r; else b.push(F, OP_LSTM_FWD, 200 + l).lstm = r;
     } else {
       // per time step: gx[t] += h[t-1] . W_hh^T (one GEMM per parameter set over the 2B rows (part, b)), then one cell launch
       // over the 4 groups; gx is overwritten in place by the gates i,f,g,o, which is what the backward cells read
@@ -739,11 +749,43 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         }
       }
     }
-    {
+    if (!pipe) {
       Op& op = b.push(F, OP_COMBINE_FWD, 200 + l);
-      op.comb.h = ls[l].h; op.comb.out = ls[l].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt;
+      op.comb.h = ls[l].h; op.comb.out = ls[l].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt; op.comb.T = T;
     }
     lin = ls[l].hc;
+  }
+  if (pipe) {
+    for (int c = 0; c < nchunk; ++c) {
+      const int t0 = (int)((int64_t)T * c / nchunk), t1 = (int)((int64_t)T * (c + 1) / nchunk), Tc = t1 - t0;
+      {
+        LstmRec r = pipe_rec[0];
+        r.t0 = t0; r.t1 = t1;
+        b.push(F, OP_LSTM_FWD, 200).lstm = r;
+      }
+      b.cur_lane = 2;
+      {
+        Op& op = b.push(F, OP_COMBINE_FWD, 200);
+        op.comb.h = ls[0].h; op.comb.out = ls[0].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt;
+        op.comb.T = T; op.comb.t0 = t0; op.comb.t1 = t1;
+      }
+      for (int p = 0; p < 2; ++p) {                        // input GEMM of layer 1 for the frames of this chunk
+        RunGemm g = pipe_gx1[p];
+        g.M = B * Tc; g.Tout = Tc; g.Tin[0] = Tc;
+        g.base[0] += t0 * g.tstride[0];
+        g.y_off += t0 * g.y_tstride;
+        b.push(F, OP_RUNGEMM, 201).g = g;
+      }
+      {
+        LstmRec r = pipe_rec[1];
+        r.t0 = t0; r.t1 = t1;
+        b.push(F, OP_LSTM_FWD, 201).lstm = r;
+      }
+      b.cur_lane = 0;
+    }
+    Op& op = b.push(F, OP_COMBINE_FWD, 201);
+    op.join = 1;                                           // the main stream needs layer 1's last chunk
+    op.comb.h = ls[1].h; op.comb.out = ls[1].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt; op.comb.T = T;
   }
   // projection r_trans / i_trans (tools_for_model.py:173-175) writing the decoder input [B][T][D][Cl] directly
   Ptr decin = b.ws("decin", BT * D * Cl, adt);
@@ -1139,7 +1181,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const int64_t dg_half = BT * 8 * H * esize(adt);
       {
         Op& op = b.push(R, OP_COMBINE_BWD, 200 + l);
-        op.comb.h = dh; op.comb.out = dhc_next; op.comb.rows = BT; op.comb.H = H; op.comb.dt = DT_F32;
+        op.comb.h = dh; op.comb.out = dhc_next; op.comb.rows = BT; op.comb.H = H; op.comb.dt = DT_F32; op.comb.T = T;
       }
       if (!stepped) {
         Op& op = b.push(R, OP_LSTM_BWD, 200 + l);

@@ -156,13 +156,17 @@ struct LstmRec {
   int64_t gx_goff[4];
   int32_t gx_ld;
   int32_t G, nset, B, T, H, hdt, gdt;
+  int32_t t0, t1;              // forward only: time range [t0, t1) of this launch (t1 == 0: the whole sequence).  t0 > 0 resumes
+                               // from the saved h[t0-1], c[t0-1]: the planner chunks the sequence so that layer l+1 can start on
+                               // a chunk while layer l works on the next one (two HIP streams)
 };
 
 // Complex combine (tools_for_model.py:171-172): out[b,t, 0:H] = h[g0] - h[g3];  out[b,t,H:2H] = h[g2] + h[g1]
 struct Combine {
   Ptr h, out;                  // h [4][B*T][H], out [B*T][2H]   (forward)   /  dout -> dh (backward)
-  int64_t rows;
+  int64_t rows;                // B*T
   int32_t H, dt;
+  int32_t T, t0, t1, pad_;     // forward only, t1 > 0: just the frames [t0, t1) of every batch item (rows are b*T + t)
 };
 
 // Mask application (models.py:253-276) on interleaved spectra.
@@ -279,10 +283,12 @@ enum OpKind : int32_t {
 struct Op {
   int32_t kind;
   int32_t tag;                 // layer id for profiling / debugging
-  int32_t lane;                // 0: critical path.  1: off the critical path (decoder weight gradients): a full-phase run
+  int32_t lane;                // 0: critical path.  2: second stream, issued at its program position (waits for everything the main
+                               // stream has been given so far); a lane-0 op with `join` set makes the main stream wait for the
+                               // second one first.  1: off the critical path (decoder weight gradients): a full-phase run
                                // holds these back and runs them on a second HIP stream next to the LSTM backward, whose
                                // recurrence occupies only 8 of the 256 CUs for ~1.5 ms (api.hip sefd_plan_run)
-  int32_t pad_;
+  int32_t join;
   union {
     RunGemm g;
     Pack pack;

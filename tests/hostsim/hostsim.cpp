@@ -517,7 +517,12 @@ void run_op(const Op& op, const AB& ab) {
         if (d.hdt == DT_BF16) for (auto& x : whh) x = bf2f(f2bf(x));     // bf16 mode: recurrent operands are bf16
         for (int b = 0; b < d.B; ++b) {
           std::vector<double> h(H, 0.0), c(H, 0.0), hn(H);
-          for (int t = 0; t < T; ++t) {
+          const int tb = d.t0, te = d.t1 > 0 ? d.t1 : T;
+          if (tb > 0) {                                   // resume from the saved state of frame tb - 1
+            const int64_t rp_ = ((int64_t)g * d.B + b) * T + tb - 1;
+            for (int j = 0; j < H; ++j) { h[j] = ld(rp(ab, d.h), d.hdt, rp_ * H + j); c[j] = cs[rp_ * H + j]; }
+          }
+          for (int t = tb; t < te; ++t) {
             const float* gx = gxb + d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld;
             const int64_t row = ((int64_t)g * d.B + b) * T + t;
             for (int j = 0; j < H; ++j) {
@@ -529,7 +534,7 @@ void run_op(const Op& op, const AB& ab) {
                 pre[q] = s;
               }
               const double ig = 1 / (1 + std::exp(-pre[0])), fg = 1 / (1 + std::exp(-pre[1])), gg = std::tanh(pre[2]), og = 1 / (1 + std::exp(-pre[3]));
-              c[j] = fg * c[j] + ig * gg;
+              c[j] = (double)(float)(fg * c[j] + ig * gg);      // the kernels carry the cell state in fp32 (and resume chunks from the stored value)
               hn[j] = og * std::tanh(c[j]);
               float* gq = gates + (row * H + j) * 4;
               gq[0] = (float)ig; gq[1] = (float)fg; gq[2] = (float)gg; gq[3] = (float)og;
@@ -588,6 +593,7 @@ void run_op(const Op& op, const AB& ab) {
       const int64_t gsz = d.rows * d.H;
       for (int64_t i = 0; i < gsz; ++i) {
         const int64_t row = i / d.H; const int j = (int)(i % d.H);
+        if (d.t1 > 0) { const int t = (int)(row % d.T); if (t < d.t0 || t >= d.t1) continue; }
         const char* h = rp(ab, d.h);
         st(rp(ab, d.out), d.dt, row * 2 * d.H + j, ld(h, d.dt, i) - ld(h, d.dt, 3 * gsz + i));
         st(rp(ab, d.out), d.dt, row * 2 * d.H + d.H + j, ld(h, d.dt, 2 * gsz + i) + ld(h, d.dt, gsz + i));

@@ -36,6 +36,7 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 3, 4000, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),
                                                         ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM: per-step path
+                                                        ("DCCRN", 2, 7000, "C", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # T = 71: chunked two-lane LSTM forward
                                                         ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
                                                         ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("FullSubNet", 2, 13, "E", (128, 64), 0, "fp32"),

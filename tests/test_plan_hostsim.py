@@ -69,6 +69,27 @@ def test_hostsim_real_lstm_variant(ru):
     _check_plan_vs_oracle("E", "SI-SNR", dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=ru, lstm="real"), 2, 3000)
 
 
+def test_chunked_lstm_pipeline_plan_equals_unchunked(monkeypatch):
+    """bf16 plans cut the two complex-LSTM recurrences into chunks of frames (layer 1 of a chunk on the second stream while
+    layer 0 runs the next chunk).  Interpreted in program order the chunked plan must give exactly the unchunked result."""
+    B, L = 2, 8000
+    P = oracle_params(DCCRNConfig(masking_mode="C", **SMALL))
+    x, _ = make_signals(B, L)
+    outs = []
+    for chunks in ("1", "8"):
+        monkeypatch.setenv("SEFD_LSTM_CHUNKS", chunks)
+        plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **SMALL)
+        n_lstm = sum(plan.op_info(PHASE_FWD, i)["kind"] == 9 for i in range(plan.num_ops(PHASE_FWD)))
+        assert n_lstm == 2 * int(chunks), n_lstm
+        ar = plan.alloc_arenas("cpu")
+        fill_params(plan, ar, P)
+        plan.io(ar, "wav", (B, L)).copy_(x)
+        sim_run(plan, PHASE_FWD, ar)
+        outs.append((plan.io(ar, "out_wav", (B, L)).clone(), plan.view(ar, "lstm1.h").clone(), plan.view(ar, "lstm1.c").clone()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+
+
 def _check_plan_vs_oracle(mode, loss, SMALL, B, L):
     cfg = DCCRNConfig(masking_mode=mode, **SMALL)
     P = oracle_params(cfg)
