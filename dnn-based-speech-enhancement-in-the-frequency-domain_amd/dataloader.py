@@ -1,0 +1,121 @@
+"""Data path of the training loop (reference dataloader.py:1-71): `[N, 2, L]` .npy files of (noisy, clean) pairs.
+
+Same surface - `create_dataloader(mode, type, snr)` returning an iterable of `(inputs, targets)` batches of size
+`cfg.batch`, `Wave_Dataset.__getitem__` = `(input[idx][0], input[idx][1])`, train: shuffled + drop_last, valid/test:
+in order - re-designed for one process per GPU feeding an MI355X:
+
+* the file is memory-mapped (the reference `np.load`s the whole array into every process);
+* under torch.distributed each rank iterates its own contiguous-stride shard of a per-epoch permutation that is the same
+  on all ranks (seed + epoch), every rank gets the same number of batches (remainder dropped), so the gradient all-reduce
+  never waits for a rank that has one batch more;
+* a batch is gathered straight into a pinned staging buffer (two of them) and copied to the GPU on a dedicated copy stream
+  while the previous step computes: 12.3 MB per B=32 batch of 3 s clips, ~0.2 ms over PCIe Gen5, fully hidden.
+The file paths of the reference are placeholders ("DATASET_FILE_PATH"); here they come from `cfg.train_data_path` /
+`cfg.valid_data_path` / `cfg.test_data_path` or the `path=` argument.
+"""
+import numpy as np
+import torch
+
+from . import config as cfg
+
+
+class Wave_Dataset(torch.utils.data.Dataset):
+    def __init__(self, mode, type=0, snr=0, path=None):
+        self.mode = mode
+        path = path or getattr(cfg, f"{mode}_data_path", None)
+        if path is None:
+            raise ValueError(f"no data file for mode {mode!r}: pass path= or set cfg.{mode}_data_path")
+        self.input_path = path
+        arr = np.load(path, mmap_mode="r")
+        if mode == "test" and arr.ndim == 5:        # [type][snr][N][2][L]  (dataloader.py:57-58)
+            arr = arr[type][snr]
+        if arr.ndim != 3 or arr.shape[1] != 2:
+            raise ValueError(f"{path}: expected [N, 2, L] (noisy, clean) pairs, got {arr.shape}")
+        self.input = arr
+
+    def __len__(self):
+        return len(self.input)
+
+    def __getitem__(self, idx):
+        pair = self.input[idx]
+        return torch.from_numpy(np.array(pair[0])), torch.from_numpy(np.array(pair[1]))
+
+
+class ShardedBatchLoader:
+    """Iterable of (inputs [B, L], targets [B, L]) batches for this rank; see the module docstring."""
+
+    def __init__(self, dataset, batch_size, shuffle, drop_last, rank=0, world=1, seed=0, device=None):
+        self.ds, self.B, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
+        self.device = torch.device(device) if device is not None else None
+        self._pinned = None
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _batches(self):
+        n = len(self.ds)
+        order = np.arange(n)
+        if self.shuffle:
+            order = np.random.default_rng(self.seed + self.epoch).permutation(n)
+        per_step = self.B * self.world
+        nfull = n // per_step
+        idx = [order[s * per_step + self.rank * self.B: s * per_step + (self.rank + 1) * self.B] for s in range(nfull)]
+        if not self.drop_last and self.world == 1 and n % self.B:
+            idx.append(order[nfull * self.B:])
+        return idx
+
+    def __len__(self):
+        return len(self._batches())
+
+    def _gather(self, ids, slot):
+        arr = self.ds.input
+        L = arr.shape[2]
+        if self.device is not None and self.device.type == "cuda":
+            if self._pinned is None or self._pinned[0].shape[2] != L or self._pinned[0].shape[0] < self.B:
+                self._pinned = [torch.empty(self.B, 2, L, dtype=torch.float32).pin_memory() for _ in range(2)]
+            buf = self._pinned[slot][:len(ids)]
+        else:
+            buf = torch.empty(len(ids), 2, L, dtype=torch.float32)
+        ids = np.sort(ids)                           # ascending file offsets (order inside a batch is irrelevant)
+        if arr.dtype == np.float32:
+            np.take(arr, ids, axis=0, out=buf.numpy())
+        else:
+            buf.copy_(torch.from_numpy(arr[ids].astype(np.float32)))
+        return buf
+
+    def __iter__(self):
+        batches = self._batches()
+        if self.device is None or self.device.type != "cuda":
+            for ids in batches:
+                buf = self._gather(ids, 0)
+                yield buf[:, 0], buf[:, 1]
+            return
+        copy = torch.cuda.Stream(device=self.device)
+        pending = None
+        for k, ids in enumerate(batches + [None]):
+            nxt = None
+            if ids is not None:
+                buf = self._gather(ids, k & 1)
+                with torch.cuda.stream(copy):
+                    dev = buf.to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy)
+                nxt = (dev, ev)
+            if pending is not None:
+                dev, ev = pending
+                torch.cuda.current_stream().wait_event(ev)
+                dev.record_stream(torch.cuda.current_stream())
+                yield dev[:, 0], dev[:, 1]
+            pending = nxt
+
+
+def create_dataloader(mode, type=0, snr=0, path=None, rank=None, world=None, device=None, seed=0):
+    import torch.distributed as dist
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    ds = Wave_Dataset(mode, type, snr, path)
+    train = mode == "train"
+    return ShardedBatchLoader(ds, cfg.batch, shuffle=train, drop_last=train, rank=rank, world=world, seed=seed, device=device)
