@@ -49,3 +49,28 @@ def test_valid_loader_keeps_order_and_the_tail(tmp_path):
     dl = create_dataloader("valid", path=p)
     xs = torch.cat([x for x, _ in dl])
     assert xs.shape[0] == 23 and torch.equal(xs, torch.from_numpy(arr[:, 0]))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_prefetching_loader_feeds_a_train_step_on_the_gpu(tmp_path):
+    """Pinned double-buffered H2D on the copy stream: values arrive intact and in order, and feed `model.train_step`."""
+    n, L = 10, 4000
+    rng = np.random.default_rng(0)
+    clean = 0.1 * rng.standard_normal((n, L)).astype(np.float32)
+    arr = np.stack([clean + 0.05 * rng.standard_normal((n, L)).astype(np.float32), clean], 1)
+    p = tmp_path / "pairs.npy"
+    np.save(p, arr)
+    cfg.batch = 4
+    dl = create_dataloader("valid", path=str(p), device="cuda")
+    got = torch.cat([torch.stack([x, y], 1).cpu() for x, y in dl])
+    assert torch.equal(got, torch.from_numpy(arr))
+    from sefd_amd import models
+    from sefd_amd.optim import Adam
+    cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.act_dtype, cfg.lstm = [16, 32, 32, 64, 64, 64], "C", "SI-SNR", "fp32", "complex"
+    m = models.DCCRN(rnn_units=128, masking_mode="C").to("cuda").train()
+    opt = Adam(m.parameters(), lr=1e-3)
+    losses = [float(m.train_step(x, y, opt)) for x, y in create_dataloader("train", path=str(p), device="cuda")]
+    assert len(losses) == 2 and all(l == l for l in losses)
