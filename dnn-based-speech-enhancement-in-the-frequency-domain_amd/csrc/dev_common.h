@@ -99,6 +99,7 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);
+void launch_istft_fft(const IstftFft& d, const ArenaBases& ab, hipStream_t st);
 void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);

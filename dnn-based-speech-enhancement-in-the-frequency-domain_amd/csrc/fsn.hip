@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void reflectpad_kernel(const ReflectPad d, con
 void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
   switch (op.kind) {
     case OP_STFT_FFT: launch_stft_fft(op.fft, ab, st); break;
+    case OP_ISTFT_FFT: launch_istft_fft(op.ifft, ab, st); break;
     case OP_REFLECTPAD: hipLaunchKernelGGL(reflectpad_kernel, dim3(gridn((int64_t)op.rpad.B * (op.rpad.L + 2 * op.rpad.pad))), dim3(256), 0, st, op.rpad, ab); break;
     case OP_CELL_FWD: hipLaunchKernelGGL(cell_fwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
     case OP_CELL_BWD: hipLaunchKernelGGL(cell_bwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;

@@ -151,9 +151,53 @@ struct Builder {
     Op& op = push(ops, OP_STFT_FFT, tag);
     op.fft.src = src; op.fft.spec = spec; op.fft.tw = fft_tw; op.fft.win = cst(wf.data(), 2048);
     op.fft.B = B; op.fft.L = L; op.fft.T = T; op.fft.hop = hop; op.fft.off = off; op.fft.pad_ = 0;
+    op.fft.corr = none(); op.fft.scale = 1.f;
     return true;
   }
   Ptr fft_tw = Ptr{-1, 0, 0};
+  Ptr fft_corr = Ptr{-1, 0, 0};
+  // rank-2 correction of the closed-form pinv synthesis basis: cE/cO[part][k] = sum over even/odd j < W of the
+  // un-windowed analysis basis, divided by (NFFT/2 + number of such j)
+  Ptr istft_corr(int W) {
+    if (fft_corr.arena >= 0) return fft_corr;
+    std::vector<float> c(4 * 257, 0.f);
+    const double ne = (W + 1) / 2, no = W / 2;
+    for (int part = 0; part < 2; ++part)
+      for (int k = 0; k <= 256; ++k) {
+        double se = 0, so = 0;
+        for (int m = 0; m < W; ++m) {
+          const double ang = 2.0 * kPi * (double)(((int64_t)k * m) % 512) / 512.0;
+          (m % 2 == 0 ? se : so) += part == 0 ? std::cos(ang) : -std::sin(ang);
+        }
+        c[(0 * 2 + part) * 257 + k] = (float)(se / (256.0 + ne));
+        c[(1 * 2 + part) * 257 + k] = (float)(so / (256.0 + no));
+      }
+    fft_corr = cst(c.data(), (int64_t)c.size() * 4);
+    return fft_corr;
+  }
+  Ptr win512(const std::vector<double>& win) {
+    std::vector<float> wf(512, 0.f);
+    for (size_t j = 0; j < win.size(); ++j) wf[j] = (float)win[j];
+    return cst(wf.data(), 2048);
+  }
+  // iSTFT synthesis est -> frames as an inverse FFT (istft_fft_kernel); false: plan the synthesis GEMM instead
+  bool istft_fft(std::vector<Op>& ops, int tag, Ptr est, Ptr frames, int64_t nframes, int NFFT, const std::vector<double>& win) {
+    if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM")) return false;
+    if (fft_tw.arena < 0) return false;                      // the STFT helper creates the twiddle table first
+    Op& op = push(ops, OP_ISTFT_FFT, tag);
+    op.ifft.est = est; op.ifft.frames = frames; op.ifft.tw = fft_tw; op.ifft.win = win512(win); op.ifft.corr = istft_corr((int)win.size());
+    op.ifft.nframes = nframes; op.ifft.W = (int)win.size();
+    return true;
+  }
+  // its backward: d est = Kinv . (frames of the padded waveform gradient) = the analysis transform with the same correction
+  bool istft_bwd_fft(std::vector<Op>& ops, int tag, Ptr dpad, Ptr dest, int B, int Lp, int T, int hop, int NFFT, const std::vector<double>& win) {
+    if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM") || fft_tw.arena < 0) return false;
+    Op& op = push(ops, OP_STFT_FFT, tag);
+    op.fft.src = dpad; op.fft.spec = dest; op.fft.tw = fft_tw; op.fft.win = win512(win);
+    op.fft.B = B; op.fft.L = Lp; op.fft.T = T; op.fft.hop = hop; op.fft.off = 0; op.fft.pad_ = 0;
+    op.fft.corr = istft_corr((int)win.size()); op.fft.scale = 1.f / 256.f;
+    return true;
+  }
 
   // WGRAD for the layer whose forward descriptor is `f` (same A runs + a ones run) against upstream gradient `dy`.
   void wgrad(std::vector<Op>& ops, const RunGemm& f, Ptr dy, const Coef& coef, int tag,
@@ -936,7 +980,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     b.push(F, OP_MASK_FWD, 500).mask = mk;
   }
   RunGemm gi = Builder::gemm0();
-  {
+  if (!b.istft_fft(F, 501, est, frames, BT, NFFT, win)) {
     RunGemm& g = gi;
     g.x[0] = est; g.xdt = DT_F32; g.ydt = DT_F32;
     g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.rowlen[0] = SW; g.Tin[0] = T;
@@ -966,16 +1010,18 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       Ola o = ola;
       o.dwav = io_gw; o.dpad = dpad;
       b.push(R, OP_OLA_BWD, 502).ola = o;
-      RunGemm g = Builder::gemm0();
-      g.x[0] = dpad; g.xdt = DT_F32; g.ydt = DT_F32;
-      g.bstride[0] = Lp; g.tstride[0] = 0; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
-      g.M = (int)BT; g.Tout = 1; g.Fo = T;
-      g.nseg = 1; g.seg[0] = Seg{0, 0, 0, W, 0};
-      g.N = SW;
-      Builder::layout_segs(g);
-      const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kinv[((size_t)(nn & 1) * NF + (nn / 2 - 1)) * W + j]; });
-      g.y = dest; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
-      b.push(R, OP_RUNGEMM, 501).g = g;
+      if (!b.istft_bwd_fft(R, 501, dpad, dest, B, Lp, T, hop, NFFT, win)) {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = dpad; g.xdt = DT_F32; g.ydt = DT_F32;
+        g.bstride[0] = Lp; g.tstride[0] = 0; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
+        g.M = (int)BT; g.Tout = 1; g.Fo = T;
+        g.nseg = 1; g.seg[0] = Seg{0, 0, 0, W, 0};
+        g.N = SW;
+        Builder::layout_segs(g);
+        const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kinv[((size_t)(nn & 1) * NF + (nn / 2 - 1)) * W + j]; });
+        g.y = dest; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+        b.push(R, OP_RUNGEMM, 501).g = g;
+      }
       SpecOut s2 = so;
       s2.est = dest; s2.out_real = io_gr; s2.out_imag = io_gi; s2.accumulate = 1;
       b.push(R, OP_SPECOUT_BWD, 503).so = s2;
@@ -1660,7 +1706,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
     mk.mask_fstride = Fo; mk.mask_bstride = (int64_t)(T + 1) * Fo; mk.mask_base = Fo; mk.T = T;
     b.push(F, OP_MASK_FWD, 500).mask = mk;
   }
-  {
+  if (!b.istft_fft(F, 501, est, frames, BT, NFFT, win)) {
     RunGemm g = Builder::gemm0();
     g.x[0] = est; g.xdt = DT_F32; g.ydt = DT_F32;
     g.bstride[0] = (int64_t)T * SW; g.tstride[0] = SW; g.rowlen[0] = SW; g.Tin[0] = T;
@@ -1694,16 +1740,18 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
       Ola o = ola;
       o.dwav = io_gw; o.dpad = dpad;
       b.push(R, OP_OLA_BWD, 502).ola = o;
-      RunGemm g = Builder::gemm0();
-      g.x[0] = dpad; g.xdt = DT_F32; g.ydt = DT_F32;
-      g.bstride[0] = Lp; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
-      g.M = (int)BT; g.Tout = 1; g.Fo = T;
-      g.nseg = 1; g.seg[0] = Seg{0, 0, 0, W, 0};
-      g.N = SW;
-      Builder::layout_segs(g);
-      const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kinv[((size_t)(nn & 1) * NF + (nn / 2 - 1)) * W + j]; });
-      g.y = dest; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
-      b.push(R, OP_RUNGEMM, 501).g = g;
+      if (!b.istft_bwd_fft(R, 501, dpad, dest, B, Lp, T, hop, NFFT, win)) {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = dpad; g.xdt = DT_F32; g.ydt = DT_F32;
+        g.bstride[0] = Lp; g.rowlen[0] = Lp; g.fstride[0] = hop; g.Tin[0] = 1;
+        g.M = (int)BT; g.Tout = 1; g.Fo = T;
+        g.nseg = 1; g.seg[0] = Seg{0, 0, 0, W, 0};
+        g.N = SW;
+        Builder::layout_segs(g);
+        const_weights(g, [&](int nn, int j) { return nn < 2 ? 0.0 : Kinv[((size_t)(nn & 1) * NF + (nn / 2 - 1)) * W + j]; });
+        g.y = dest; g.y_bstride = (int64_t)T * SW; g.y_fstride = SW;
+        b.push(R, OP_RUNGEMM, 501).g = g;
+      }
     }
     std::vector<Ptr> d_decy(n), d_decz(n), d_skip(n), d_encz(n), d_ency(n);
     for (int d = 0; d < n; ++d) {

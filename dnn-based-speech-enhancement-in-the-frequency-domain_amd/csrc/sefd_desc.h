@@ -222,6 +222,19 @@ struct Memset {
 struct StftFft {
   Ptr src, spec, tw, win;
   int32_t B, L, T, hop, off, pad_;
+  // Backward of the pinv synthesis (ConviSTFT, tools_for_model.py:64-112): d spec = Kinv . d frames is the SAME transform of
+  // the padded waveform gradient, with a rank-2 term and the 1/256:  out[part][k] = scale * ( FFT(v)[part][k]
+  //   - cE[part][k] * sum_{n even} v[n] - cO[part][k] * sum_{n odd} v[n] ),  v = windowed frame.  corr = A_NONE: plain STFT.
+  Ptr corr;                    // fp32 [2 (even, odd)][2 (re, im)][257]  (A_CONST)
+  float scale, pad2_;
+};
+// iSTFT synthesis as an inverse 512-point FFT (fft_len == 512): frames[fr][j] = win[j] / 256 * ( Re sum_{k<=256} X[k] e^{+2 pi i k j / 512}
+//   - C_parity(j) ),  C_even = sum_{part,k} X[part][k] cE[part][k], C_odd likewise with cO: the closed form of the reference's
+// pinv(analysis basis) (init_kernels(invers=True), tools_for_model.py:16-33).  est [frames][258][2] -> frames [frames][W].
+struct IstftFft {
+  Ptr est, frames, tw, win, corr;
+  int64_t nframes;
+  int32_t W, pad_;
 };
 // torch.stft(center=True, pad_mode='reflect'): dst[b][i] = src[b][reflect(i - pad)], i < L + 2*pad
 struct ReflectPad {
@@ -277,7 +290,8 @@ enum OpKind : int32_t {
   OP_FSN_OUT_BWD, OP_FSN_SBBWD_SUM, OP_FSN_SBBWD_APPLY, OP_REFLECTPAD,
   OP_SPECPAD,       // Mags struct reused: spec fp32 [frames][NF][2] -> mags [frames][NF][MS] (dtype dt), channels 2..MS-1 zero (NF = slots here)
   OP_STFT_FFT,
-  OP_PACKMULTI
+  OP_PACKMULTI,
+  OP_ISTFT_FFT
 };
 
 struct Op {
@@ -309,6 +323,7 @@ struct Op {
     Fsn fsn;
     ReflectPad rpad;
     StftFft fft;
+    IstftFft ifft;
     PackMulti packm;
   };
 };

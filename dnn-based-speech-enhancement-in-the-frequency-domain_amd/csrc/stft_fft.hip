@@ -34,6 +34,35 @@ __device__ __forceinline__ void dft8(const cf* x, cf* X) {
   X[3] = cadd(E[3], o3);   X[7] = csub(E[3], o3);
 }
 
+// 512-point forward DFT of the wave's 512 values: lane holds x[j] = value n = lane + 64 j on entry and
+// X[mb] = bin k = (lane >> 3) + 8 (lane & 7) + 64 mb on exit.  buf: this wave's private 4 KiB of LDS; twl: (cos, sin)(2 pi k / 512).
+__device__ __forceinline__ void fft512_wave(cf* x, cf* X, float2* buf, const float2* twl, int lane) {
+  dft8(x, X);
+#pragma unroll
+  for (int k0 = 0; k0 < 8; ++k0) {
+    const float2 w = twl[(lane * k0) & 511];
+    const cf z = cmul(X[k0], cf{w.x, -w.y});                 // W512^(l k0) = cos - i sin
+    buf[k0 * 64 + lane] = make_float2(z.x, z.y);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private LDS slice: ordering inside the wave is enough
+  const int k0 = lane >> 3, l0 = lane & 7;
+#pragma unroll
+  for (int l1 = 0; l1 < 8; ++l1) { const float2 v = buf[k0 * 64 + l0 + 8 * l1]; x[l1] = {v.x, v.y}; }
+  dft8(x, X);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ma = 0; ma < 8; ++ma) {
+    const float2 w = twl[(8 * l0 * ma) & 511];
+    const cf z = cmul(X[ma], cf{w.x, -w.y});                 // W64^(l0 ma)
+    buf[k0 * 64 + ma * 8 + l0] = make_float2(z.x, z.y);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int ma = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const float2 v = buf[k0 * 64 + ma * 8 + q]; x[q] = {v.x, v.y}; }
+  dft8(x, X);
+}
+
 __global__ __launch_bounds__(256) void stft_fft_kernel(const StftFft d, const ArenaBases ab) {
   __shared__ float2 lds[4][512];
   __shared__ float2 twl[512];
@@ -48,51 +77,82 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const StftFft d, const Ar
   if (fr >= (int64_t)d.B * d.T) return;                      // wave-uniform
   const int64_t b = fr / d.T;
   const int t = (int)(fr - b * d.T);
-  float2* buf = lds[wv];
-  // ---- stage 1: 8 windowed samples per lane, stride 64
   cf x[8], X[8];
   const int p0 = t * d.hop - d.off;
+  float vs = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int n = lane + 64 * j, p = p0 + n;
     const float v = (p >= 0 && p < d.L) ? src[b * d.L + p] * win[n] : 0.f;
     x[j] = {v, 0.f};
+    vs += v;
   }
-  dft8(x, X);
-#pragma unroll
-  for (int k0 = 0; k0 < 8; ++k0) {
-    const float2 w = twl[(lane * k0) & 511];
-    const cf z = cmul(X[k0], cf{w.x, -w.y});                 // W512^(l k0) = cos - i sin
-    buf[k0 * 64 + lane] = make_float2(z.x, z.y);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private LDS slice: ordering inside the wave is enough
-  // ---- stage 2: DFT over l1 for (k0, l0)
-  const int k0 = lane >> 3, l0 = lane & 7;
-#pragma unroll
-  for (int l1 = 0; l1 < 8; ++l1) { const float2 v = buf[k0 * 64 + l0 + 8 * l1]; x[l1] = {v.x, v.y}; }
-  dft8(x, X);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int ma = 0; ma < 8; ++ma) {
-    const float2 w = twl[(8 * l0 * ma) & 511];
-    const cf z = cmul(X[ma], cf{w.x, -w.y});                 // W64^(l0 ma)
-    buf[k0 * 64 + ma * 8 + l0] = make_float2(z.x, z.y);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // ---- stage 3: DFT over l0 for (k0, ma) -> bins k0 + 8 ma + 64 mb
-  const int ma = lane & 7;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) { const float2 v = buf[k0 * 64 + ma * 8 + q]; x[q] = {v.x, v.y}; }
-  dft8(x, X);
+  fft512_wave(x, X, lds[wv], twl, lane);
+  const int k0 = lane >> 3, ma = lane & 7;
   float2* out = spec + fr * 258;
+  if (d.corr.arena >= 0) {                                   // backward of the pinv synthesis (see sefd_desc.h)
+    const float* cr = reinterpret_cast<const float*>(rp(ab, d.corr));
+    const float ge = wave_sum((lane & 1) ? 0.f : vs), go = wave_sum((lane & 1) ? vs : 0.f);   // n = lane + 64 j has the parity of lane
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) {
+      const int k = k0 + 8 * ma + 64 * mb;
+      if (k <= 256)
+        out[1 + k] = make_float2(d.scale * (X[mb].x - cr[k] * ge - cr[2 * 257 + k] * go),
+                                 d.scale * (X[mb].y - cr[257 + k] * ge - cr[3 * 257 + k] * go));
+    }
+    if (lane == 0) out[0] = make_float2(0.f, 0.f);
+    return;
+  }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) out[1 + k0 + 8 * ma + 64 * mb] = make_float2(X[mb].x, X[mb].y);
   if (lane == 0) { out[1 + 256] = make_float2(X[4].x, X[4].y); out[0] = make_float2(0.f, 0.f); }
 }
 
+__global__ __launch_bounds__(256) void istft_fft_kernel(const IstftFft d, const ArenaBases ab) {
+  __shared__ float2 lds[4][512];
+  __shared__ float2 twl[512];
+  const float2* est = reinterpret_cast<const float2*>(rp(ab, d.est));
+  const float* win = reinterpret_cast<const float*>(rp(ab, d.win));
+  const float* cr = reinterpret_cast<const float*>(rp(ab, d.corr));
+  const float2* tw = reinterpret_cast<const float2*>(rp(ab, d.tw));
+  float* frames = reinterpret_cast<float*>(rp(ab, d.frames));
+  for (int i = threadIdx.x; i < 512; i += 256) twl[i] = tw[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t fr = (int64_t)blockIdx.x * 4 + wv;
+  if (fr >= d.nframes) return;                               // wave-uniform
+  const float2* in = est + fr * 258 + 1;
+  cf x[8], X[8];
+  float ce = 0.f, co = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = lane + 64 * j;
+    float2 v = make_float2(0.f, 0.f);
+    if (k <= 256) {
+      v = in[k];
+      ce += v.x * cr[k] + v.y * cr[257 + k];
+      co += v.x * cr[2 * 257 + k] + v.y * cr[3 * 257 + k];
+    }
+    x[j] = {v.x, -v.y};                                      // inverse transform = conj(DFT(conj Y)); only the real part is needed
+  }
+  ce = wave_sum(ce);
+  co = wave_sum(co);
+  fft512_wave(x, X, lds[wv], twl, lane);
+  const int k0 = lane >> 3, ma = lane & 7;
+  float* out = frames + fr * d.W;
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int j = k0 + 8 * ma + 64 * mb;
+    if (j < d.W) out[j] = (X[mb].x - ((j & 1) ? co : ce)) * win[j] * (1.f / 256.f);
+  }
+}
+
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st) {
   const int64_t frames = (int64_t)d.B * d.T;
   hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, st, d, ab);
+}
+void launch_istft_fft(const IstftFft& d, const ArenaBases& ab, hipStream_t st) {
+  hipLaunchKernelGGL(istft_fft_kernel, dim3((unsigned)((d.nframes + 3) / 4)), dim3(256), 0, st, d, ab);
 }
 
 }  // namespace sefd

@@ -317,10 +317,38 @@ bool run_fsn(const Op& op, const AB& ab) {
         for (int n = 0; n < 512; ++n) { const int p = t * d.hop - d.off + n; v[n] = (p >= 0 && p < d.L) ? (double)src[b * d.L + p] * win[n] : 0.0; }
         float* o = spec + fr * 516;
         o[0] = o[1] = 0.f;
+        double ge = 0, go = 0;
+        for (int n = 0; n < 512; ++n) (n & 1 ? go : ge) += v[n];
+        const float* cr = d.corr.arena >= 0 ? (const float*)rp(ab, d.corr) : nullptr;
         for (int k = 0; k <= 256; ++k) {
           double re = 0, im = 0;
           for (int n = 0; n < 512; ++n) { const double a = 2.0 * 3.14159265358979323846 * (double)((k * n) % 512) / 512.0; re += v[n] * std::cos(a); im -= v[n] * std::sin(a); }
+          if (cr) { re = d.scale * (re - cr[k] * ge - cr[2 * 257 + k] * go); im = d.scale * (im - cr[257 + k] * ge - cr[3 * 257 + k] * go); }
           o[2 * (k + 1)] = (float)re; o[2 * (k + 1) + 1] = (float)im;
+        }
+      }
+      return true;
+    }
+    case OP_ISTFT_FFT: {
+      const IstftFft& d = op.ifft;
+      const float* est = (const float*)rp(ab, d.est);
+      const float* win = (const float*)rp(ab, d.win);
+      const float* cr = (const float*)rp(ab, d.corr);
+      float* frames = (float*)rp(ab, d.frames);
+      for (int64_t fr = 0; fr < d.nframes; ++fr) {
+        const float* in = est + fr * 516 + 2;
+        double ce = 0, co = 0;
+        for (int k = 0; k <= 256; ++k) {
+          ce += in[2 * k] * (double)cr[k] + in[2 * k + 1] * (double)cr[257 + k];
+          co += in[2 * k] * (double)cr[2 * 257 + k] + in[2 * k + 1] * (double)cr[3 * 257 + k];
+        }
+        for (int j = 0; j < d.W; ++j) {
+          double sre = 0;
+          for (int k = 0; k <= 256; ++k) {
+            const double a = 2.0 * 3.14159265358979323846 * (double)((k * j) % 512) / 512.0;
+            sre += in[2 * k] * std::cos(a) - in[2 * k + 1] * std::sin(a);
+          }
+          frames[fr * d.W + j] = (float)((sre - ((j & 1) ? co : ce)) * win[j] / 256.0);
         }
       }
       return true;
