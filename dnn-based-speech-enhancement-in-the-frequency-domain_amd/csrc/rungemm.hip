@@ -976,7 +976,7 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 
 template <int TN>
 static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
-  static const int stages = env_stages("SEFD_WG_STAGES", 4);
+  static const int stages = env_stages("SEFD_WG_STAGES", 3);   // 3 stages = 48 KiB (128-wide) / 36 KiB: co-resides better with the other stream (13.63 -> 13.24 ms per step vs 4)
   dim3 grid(((d.Npad + TN - 1) / TN) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
   if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 2>), grid, dim3(256), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 3>), grid, dim3(256), 0, st, d, ab);
