@@ -213,7 +213,8 @@ struct Builder {
     g.stats = none();
     // Row splits: every workgroup of a WGRAD launch does the same amount of work, so the grid is sized to fill the
     // co-resident slots of the 256 CUs in ONE wave of workgroups and never spill a few stragglers into a second one
-    // (the 4-stage bf16 kernel keeps 64 KiB (128-wide n tile) or 48 KiB (64-wide) of LDS: 2 or 3 workgroups per CU).
+    // (sized for the 4-stage ring: 64 KiB (128-wide n tile) or 48 KiB (64-wide) of LDS, 2 or 3 workgroups per CU; the shipped
+    //  3-stage ring needs 48 / 36 KiB, so the same grids still fit in one wave with room for the other stream's kernels).
     const int tn = (g.xdt == DT_BF16 && g.Npad >= 128) ? 128 : kWgTN;
     const int slots = g.xdt == DT_BF16 ? (tn == 128 ? 512 : 768) : 768;
     const int tiles = (int)(rup(g.Npad, tn) / tn * rup(g.ldw, kWgTK) / kWgTK);
