@@ -691,9 +691,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     }
   }
   // Two complex layers, persistent bf16 kernels: the sequence is cut into chunks of frames and layer 1 (combine + input
-  // GEMM + recurrence of a chunk, second HIP stream) runs while layer 0 already works on the next chunk - the two 481-step
+  // GEMM + recurrence of a chunk, second HIP stream) runs while layer 0 already works on the next chunk - the two 483-step
   // recurrences (8 workgroups each, latency-bound) overlap instead of running back to back.  SEFD_LSTM_CHUNKS=1 disables.
-  // Measured (B = 32, T = 481): 1 chunk 14.08 ms/step, 2-6 chunks 13.84-13.94, 8: 13.94, 16: 14.50 -> 4.
+  // Measured (B = 32, T = 483): 1 chunk 14.08 ms/step, 2-6 chunks 13.84-13.94, 8: 13.94, 16: 14.50 -> 4.
   int nchunk = getenv("SEFD_LSTM_CHUNKS") ? atoi(getenv("SEFD_LSTM_CHUNKS")) : 4;
   if (!(cx && !stepped && adt == DT_BF16 && NL == 2) || nchunk < 2 || T < 8 * nchunk) nchunk = 1;
   const bool pipe = nchunk > 1;
