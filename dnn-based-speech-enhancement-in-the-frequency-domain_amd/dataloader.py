@@ -61,8 +61,13 @@ class ShardedBatchLoader:
         per_step = self.B * self.world
         nfull = n // per_step
         idx = [order[s * per_step + self.rank * self.B: s * per_step + (self.rank + 1) * self.B] for s in range(nfull)]
-        if not self.drop_last and self.world == 1 and n % self.B:
-            idx.append(order[nfull * self.B:])
+        if not self.drop_last and n % per_step:
+            # valid / test (drop_last=False in the reference, dataloader.py:23-31): the remainder is dealt out as one ragged last
+            # batch per rank (sizes differ by at most one, an empty one is skipped), so every utterance is scored exactly once over all ranks
+            rem = order[nfull * per_step:]
+            mine = rem[self.rank::self.world] if self.world > 1 else rem
+            if len(mine):
+                idx.append(mine)
         return idx
 
     def __len__(self):
@@ -93,14 +98,20 @@ class ShardedBatchLoader:
             return
         copy = torch.cuda.Stream(device=self.device)
         pending = None
+        slot_ev = [None, None]                   # last H2D copy issued from each pinned staging buffer
         for k, ids in enumerate(batches + [None]):
             nxt = None
             if ids is not None:
+                # the training step is asynchronous, so the host can run ahead of the GPU: before slot k&1 is rewritten, the copy
+                # that was issued from it two iterations ago must have left the pinned memory
+                if slot_ev[k & 1] is not None:
+                    slot_ev[k & 1].synchronize()
                 buf = self._gather(ids, k & 1)
                 with torch.cuda.stream(copy):
                     dev = buf.to(self.device, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(copy)
+                slot_ev[k & 1] = ev
                 nxt = (dev, ev)
             if pending is not None:
                 dev, ev = pending

@@ -118,13 +118,17 @@ class _DCCRNFunction(torch.autograd.Function):
         if rt.tgt is not None:
             rt.tgt.copy_(targets)
         rt.run(PHASE_FWD)
-        ctx.owner, ctx.rt = owner, rt
+        rt.stamp = getattr(rt, "stamp", 0) + 1     # the saved activations live in the runtime's arena, not in ctx
+        ctx.owner, ctx.rt, ctx.stamp = owner, rt, rt.stamp
         ctx.n = len(params)
         return rt.out_real.clone(), rt.out_imag.clone(), rt.out_wav.clone()
 
     @staticmethod
     def backward(ctx, g_real, g_imag, g_wav):
         rt, owner = ctx.rt, ctx.owner
+        if ctx.stamp != rt.stamp:
+            raise RuntimeError("sefd: a later forward of the same (batch, length, mode) overwrote the activations this backward needs; "
+                               "call backward before the next forward of that shape")
         for dst, g in ((rt.g_real, g_real), (rt.g_imag, g_imag), (rt.g_wav, g_wav)):
             if g is None:
                 dst.zero_()
@@ -141,9 +145,17 @@ class _SefdModule(nn.Module):
     """Flat parameter storage + per-(B, L) device runtimes shared by the HIP-backed models."""
 
     def _init_runtime_state(self):
+        import weakref
         self._flat_param = self._flat_grad = self._flat_state = self._flat_nbt = None
         self._param_slices = None
         self._runtimes = {}
+        ref = weakref.ref(self)
+        for p in self.parameters():              # lets sefd_amd.optim.Adam(model.parameters()) find the model (optim.py)
+            p._sefd_owner = ref
+        if getattr(self, "win_type", "hanning") not in ("hanning", "hann"):
+            # the kernels window with the periodic Hann of cfg.window = 'hanning' (config.py:61); a rectangular-window module
+            # (win_type None) would register buffers the computation does not use
+            raise NotImplementedError(f"win_type {self.win_type!r}: only the Hann window ('hanning') is on the HIP path")
 
     def flatten_parameters(self):
         pass
@@ -487,12 +499,15 @@ class _FSNFunction(torch.autograd.Function):
         plan.io(ar, "mag", (B, F, T)).copy_(noisy_mag)
         plan.view(ar, "io.seed").view(torch.int32)[:1].add_(1)        # fresh dropout masks every forward (device-side counter)
         plan.run(PHASE_FWD, ar, torch.cuda.current_stream().cuda_stream)
-        ctx.owner, ctx.rt, ctx.shape = owner, rt, (B, F, T)
+        plan.stamp = getattr(plan, "stamp", 0) + 1
+        ctx.owner, ctx.rt, ctx.shape, ctx.stamp = owner, rt, (B, F, T), plan.stamp
         return plan.io(ar, "crm", (B, F, T, 2)).clone()
 
     @staticmethod
     def backward(ctx, g):
         plan, ar = ctx.rt
+        if ctx.stamp != plan.stamp:
+            raise RuntimeError("sefd: a later forward of the same shape overwrote the activations this backward needs")
         B, F, T = ctx.shape
         plan.io(ar, "grad_crm", (B, F, T, 2)).copy_(g)
         plan.run(PHASE_BWD, ar, torch.cuda.current_stream().cuda_stream)

@@ -9,7 +9,8 @@ from . import config as cfg
 from .optim import Adam
 
 
-def model_train(model, optimizer, train_loader, DEVICE):
+def model_train(model, optimizer, train_loader, DEVICE, exchange=None):
+    """trainer.py:15-42.  `exchange` (sefd_amd.ddp.GradientExchange, optional, not in the reference): data-parallel run."""
     train_loss = torch.zeros((), device=DEVICE)
     batch_num = 0
     model.train()
@@ -19,7 +20,7 @@ def model_train(model, optimizer, train_loader, DEVICE):
         inputs = inputs.float().to(DEVICE, non_blocking=True)
         targets = targets.float().to(DEVICE, non_blocking=True)
         if fused:
-            loss = model.train_step(inputs, targets, optimizer)
+            loss = model.train_step(inputs, targets, optimizer, exchange=exchange)
         else:
             _, _, outputs = model(inputs, targets)
             loss = model.loss(outputs, targets)
@@ -53,7 +54,7 @@ def model_perceptual_train(model, optimizer, train_loader, DEVICE):
     return train_loss / n, train_main / n, train_perc / n
 
 
-def fullsubnet_train(model, optimizer, train_loader, DEVICE):
+def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:85-118."""
     from . import tools_for_model as tools
     train_loss = torch.zeros((), device=DEVICE)
@@ -65,7 +66,7 @@ def fullsubnet_train(model, optimizer, train_loader, DEVICE):
         inputs = inputs.float().to(DEVICE)
         targets = targets.float().to(DEVICE)
         if fused:
-            loss = model.train_step(inputs, targets, optimizer)
+            loss = model.train_step(inputs, targets, optimizer, exchange=exchange)
         else:
             noisy_complex = tools.stft(inputs)
             clean_complex = tools.stft(targets)

@@ -71,19 +71,22 @@ SMALL_PARAMS = lambda name: (name.startswith("encoder.0.0.") or name.endswith(".
                              or name.startswith("decoder.5.0.") or name.endswith("bias_hh_l0"))
 
 
-def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True, lstm="complex"):
+def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True, lstm="complex", skip=True, gstride=53, scale=1.0):
     cfg.dccrn_kernel_num = list(kernel_num)
     cfg.masking_mode = mask
     cfg.loss = loss
     cfg.perceptual = perceptual
     cfg.lstm = lstm
-    cfg.skip_type = True
+    cfg.skip_type = skip
     torch.manual_seed(0)
     m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask)
+    cfg.skip_type = True            # read at construction AND in forward (models.py:107, 222): restored after the forward below
     fill_state_dict_(m)
     m.train()
     x, y = test_signals(B, L)
+    x, y = x * scale, y * scale
     taps = {}
+    cfg.skip_type = skip
     hooks = []
     if store_taps:
         def mk(key):
@@ -111,20 +114,21 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
         perc = torch.zeros(())
     for h in hooks:
         h.remove()
+    cfg.skip_type = True
     opt.zero_grad()
     lossv.backward()
     g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
     opt.step()
     sd = m.state_dict()
     rec = dict(
-        meta=dict(B=B, L=L, kernel_num=np.array(kernel_num), rnn_units=rnn_units,
+        meta=dict(B=B, L=L, kernel_num=np.array(kernel_num), rnn_units=rnn_units, skip=int(skip), gstride=gstride, scale=float(scale),
                   mask=np.array(mask), loss=np.array(loss), perceptual=np.array(str(perceptual))),
         out_real=o_r.detach().numpy(), out_imag=o_i.detach().numpy(), out_wav=wav.detach().numpy(),
         loss=float(lossv), main_loss=float(main), perc_loss=float(perc),
         taps=taps,
         grad_norm={k: float(v.double().norm()) for k, v in g.items()},
         grad={k: v.numpy() for k, v in g.items() if SMALL_PARAMS(k)},
-        grad_samp={k: sample(v, 53)["samp"] for k, v in g.items() if not SMALL_PARAMS(k)},
+        grad_samp={k: sample(v, gstride)["samp"] for k, v in g.items() if not SMALL_PARAMS(k)},
         after_adam={k: sd[k].numpy().copy() for k in g if SMALL_PARAMS(k)},
         running={k: v.numpy().copy() for k, v in sd.items() if "running_" in k},
     )
@@ -331,6 +335,12 @@ def main():
         dccrn_case(cfg, models, "real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR", False, 2, 3000, store_taps=False, lstm="real")
         cfg.lstm = "complex"
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "large":         # BASELINE configs[4]: DCCRN-large (2x channels, rnn_units 512), short clip
+        dccrn_case(cfg, models, "large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", False, 2, 1600, store_taps=False, gstride=997, scale=0.125)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "noskip":        # cfg.skip_type = False (models.py:107-137, 222-223)
+        dccrn_case(cfg, models, "noskip_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False, 2, 3000, store_taps=False, skip=False)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "eval":          # regenerate only the validation-path case
         dccrn_eval_case(cfg, models, "small_eval", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", 2, 4000, 3, 5000)
         return
@@ -354,6 +364,8 @@ def main():
     dccrn_case(cfg, models, "wide_C_sdr", small, 512, "C", "SDR", False, 1, 2000, store_taps=False)
     dccrn_case(cfg, models, "real_E_sisnr", small, 256, "E", "SI-SNR", False, 2, 3000, store_taps=False, lstm="real")
     cfg.lstm = "complex"
+    dccrn_case(cfg, models, "large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", False, 2, 1600, store_taps=False, gstride=997, scale=0.125)
+    dccrn_case(cfg, models, "noskip_E_sisnr", small, 128, "E", "SI-SNR", False, 2, 3000, store_taps=False, skip=False)
 
 
 if __name__ == "__main__":

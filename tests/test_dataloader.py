@@ -74,3 +74,16 @@ def test_prefetching_loader_feeds_a_train_step_on_the_gpu(tmp_path):
     opt = Adam(m.parameters(), lr=1e-3)
     losses = [float(m.train_step(x, y, opt)) for x, y in create_dataloader("train", path=str(p), device="cuda")]
     assert len(losses) == 2 and all(l == l for l in losses)
+
+
+def test_valid_loader_under_ddp_scores_every_utterance_exactly_once(tmp_path):
+    """drop_last=False modes with world > 1: the remainder is dealt out as ragged last batches."""
+    p, arr = _file(tmp_path, n=23)
+    cfg.batch = 4
+    seen = []
+    for rank in range(3):
+        dl = create_dataloader("valid", path=p, rank=rank, world=3)
+        for x, y in dl:
+            assert 1 <= x.shape[0] <= 4
+            seen += [int(round(float(v) * 1000)) // 100 for v in x[:, 0]]
+    assert sorted(seen) == list(range(23))

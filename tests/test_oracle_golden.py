@@ -9,7 +9,7 @@ from oracle import losses as ol
 from oracle.dccrn import DCCRNConfig, dccrn_forward, dccrn_state_shapes, is_trainable
 from oracle.step import dccrn_train_step
 from oracle.weights import formula_state_dict, test_signals as make_signals
-from util import load_golden, rel_err, sub, tap_stats
+from util import load_golden, rel_err, rel_l2, sub, tap_stats
 
 
 def oracle_params(cfg):
@@ -92,16 +92,26 @@ CASES = [
     ("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR", False),
     ("wide_C_sdr", (16, 32, 32, 64, 64, 64), 512, "C", "SDR", False),
     ("real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR", False),      # cfg.lstm == 'real'
+    ("large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", False),   # BASELINE configs[4]: DCCRN-large
+    ("noskip_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False),       # cfg.skip_type = False
 ]
+
+
+def case_meta(g):
+    """(skip_type, input scale, gradient sample stride) of a golden; older fixtures predate these fields."""
+    return (bool(int(g["g/meta/skip"])) if "g/meta/skip" in g else True, float(g["g/meta/scale"]) if "g/meta/scale" in g else 1.0,
+            int(g["g/meta/gstride"]) if "g/meta/gstride" in g else 53)
 
 
 @pytest.mark.parametrize("name,kn,ru,mask,loss,perc", CASES)
 def test_dccrn_step_against_reference(name, kn, ru, mask, loss, perc):
     g = load_golden("dccrn_" + name)
-    cfg = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode=mask, lstm="real" if name.startswith("real") else "complex")
+    skip, scale, gstride = case_meta(g)
+    cfg = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode=mask, lstm="real" if name.startswith("real") else "complex", skip_type=skip)
     P = oracle_params(cfg)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     x, y = make_signals(B, L)
+    x, y = x * scale, y * scale
     r = dccrn_train_step(P, cfg, x, y, loss_kind=loss, perceptual=perc)
     o_r, o_i, wav = r["outputs"]
     assert rel_err(o_r, g["g/out_real"]) < 2e-5
@@ -119,11 +129,15 @@ def test_dccrn_step_against_reference(name, kn, ru, mask, loss, perc):
         # conv biases in front of a BatchNorm have analytically zero gradient: compare on the layer's weight-grad scale
         floor = 1e-6 * float(gn[k.replace(".bias", ".weight")]) if k.endswith("conv.bias") else 0.0
         err = float(np.abs(r["grads"][k].numpy() - v).max())
-        assert err <= 2e-4 * scale + floor, (k, err, scale)
+        # DCCRN-large at T = 19: one BatchNorm input of encoder.2 sits on the PReLU kink (fp32 round-off decides its slope), which
+        # moves ONE element of that layer's beta gradient by 1.2e-3; the tensor as a whole agrees to 2e-4 (L2)
+        etol = 2e-3 if name.startswith("large") else 2e-4
+        assert err <= etol * scale + floor, (k, err, scale)
+        assert k.endswith("conv.bias") or rel_l2(r["grads"][k], v) < 3e-4, k
     for k, v in sub(g, "g/grad_samp").items():
         if k.endswith("conv.bias"):
             continue
-        assert rel_err(r["grads"][k].reshape(-1)[::53], v) < 3e-4, k
+        assert rel_err(r["grads"][k].reshape(-1)[::gstride], v) < 3e-4, k
     for k, v in sub(g, "g/running").items():
         assert rel_err(r["new_stats"][k], v) < 1e-5, k
     for k, v in sub(g, "g/after_adam").items():

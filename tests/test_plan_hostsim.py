@@ -57,6 +57,11 @@ def test_hostsim_wide_lstm_takes_the_per_step_path():
     _check_plan_vs_oracle("C", "SDR", kw, 1, 2000)
 
 
+def test_hostsim_without_skip_connections():
+    """cfg.skip_type = False (models.py:107-137, 222-223): decoder layers take only the previous layer's output."""
+    _check_plan_vs_oracle("E", "SI-SNR", dict(SMALL, skip_type=False), 2, 3000)
+
+
 def test_hostsim_forced_per_step_lstm_matches_too(monkeypatch):
     monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
     _check_plan_vs_oracle("E", "SI-SNR", SMALL, 2, 4000)
