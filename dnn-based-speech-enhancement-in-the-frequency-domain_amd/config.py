@@ -1,43 +1,76 @@
-"""Configuration surface - same names, defaults and asserts as the reference's config.py (config.py:1-107).
+"""Configuration surface: the names, defaults and two asserts of the reference's config.py (config.py:1-107), because this
+module IS the flag system its callers read (`import config as cfg`).
 
-Like the reference, it is a module of constants imported as `cfg`; constructor defaults of the models are bound at
-import time and `cfg.loss` / `cfg.perceptual` / `cfg.lstm` / `cfg.skip_type` / `cfg.dccrn_kernel_num` are read at
-construction / call time.  Differences: no banner print, DEVICE defaults to 'cuda' (the MI355X), and one build-side
-knob (`act_dtype`) that the reference does not have.  (BatchNorm statistics are per rank under DDP; SyncBN is not built.)
+Like there, it is a module of plain constants; constructor defaults of the models are bound at import time and
+`cfg.loss` / `cfg.perceptual` / `cfg.lstm` / `cfg.skip_type` / `cfg.dccrn_kernel_num` are read at construction / call time.
+Differences: no banner print; one build-side knob (`act_dtype`); data-file paths for the loader (placeholders in the
+reference's dataloader.py).  Under DDP BatchNorm statistics are per rank unless `GradientExchange(sync_bn=True)`.
 """
-_CHOICES = dict(                      # the option lists the reference indexes into (config.py:35-45)
-    model_list=['DCCRN', 'CRN', 'FullSubNet'], loss_list=['MSE', 'SDR', 'SI-SNR', 'SI-SDR'],
-    perceptual_list=[False, 'LMS', 'PMSQE'], lstm_type=['real', 'complex'], main_net=['LSTM', 'GRU'],
-    mask_type=['Direct(None make)', 'E', 'C', 'R'])
+# paths (config.py:11-16)
+job_dir = './models/'
+logs_dir = './logs/'
+chkpt_model = None          # directory name under job_dir of a run to resume
+chkpt = str("EPOCH")
+if chkpt_model is not None:
+    chkpt_path = job_dir + chkpt_model + '/chkpt_' + chkpt + '.pt'
 
-_DEFAULTS = [
-    # (name, value)                                         what reads it
-    ('job_dir', './models/'), ('logs_dir', './logs/'),    # checkpoint / log roots of train_interface.py
-    ('chkpt_model', None), ('chkpt', 'EPOCH'), ('expr_num', 'EXPERIMENT_NUMBER'),
-    ('DEVICE', 'cuda'),                                   # the MI355X; there is no CPU execution path
-    ('model', _CHOICES['model_list'][0]), ('loss', _CHOICES['loss_list'][1]), ('perceptual', _CHOICES['perceptual_list'][0]),
-    ('lstm', _CHOICES['lstm_type'][1]), ('sequence_model', _CHOICES['main_net'][0]),
-    ('masking_mode', _CHOICES['mask_type'][1]), ('skip_type', True),
-    ('max_epochs', 100), ('learning_rate', 0.001), ('batch', 10),
-    ('dccrn_kernel_num', [32, 64, 128, 256, 256, 256]),
-    # front end: 25 ms window, 6.25 ms hop at 16 kHz, 512-point transform
-    ('fs', 16000), ('win_len', 400), ('win_inc', 100), ('ola_ratio', 0.75), ('fft_len', 512), ('window', 'hanning'),
-    ('rnn_layers', 2), ('rnn_units', 256), ('rnn_input_size', 512),
-    # FullSubNet
-    ('sb_num_neighbors', 15), ('fb_num_neighbors', 0), ('look_ahead', 2),
-    ('fb_output_activate_function', 'ReLU'), ('sb_output_activate_function', None),
-    ('fb_model_hidden_size', 512), ('sb_model_hidden_size', 384), ('weight_init', False),
-    ('norm_type', 'offline_laplace_norm'), ('num_groups_in_drop_band', 2),
-    # build-side knob (not in the reference): 'fp32' = parity mode, 'bf16' = storage + MFMA dtype of the conv stack
-    ('act_dtype', 'fp32'),
-]
-globals().update(_CHOICES)
-globals().update(dict(_DEFAULTS))
-sam_sec = fft_len / fs                 # noqa: F821  (derived values, config.py:62-63)
-frm_samp = fs * sam_sec                # noqa: F821
-num_freqs = fft_len // 2 + 1           # noqa: F821
+# option lists the current setting indexes into (config.py:22-27)
+model_list = ['DCCRN', 'CRN', 'FullSubNet']
+loss_list = ['MSE', 'SDR', 'SI-SNR', 'SI-SDR']
+perceptual_list = [False, 'LMS', 'PMSQE']
+lstm_type = ['real', 'complex']
+main_net = ['LSTM', 'GRU']
+mask_type = ['Direct(None make)', 'E', 'C', 'R']
+
+expr_num = 'EXPERIMENT_NUMBER'
+DEVICE = 'cuda'             # the MI355X; there is no CPU execution path
+
+# current setting (config.py:35-50)
+model = model_list[0]
+loss = loss_list[1]
+perceptual = perceptual_list[0]
+lstm = lstm_type[1]
+sequence_model = main_net[0]
+masking_mode = mask_type[1]
+skip_type = True
+max_epochs = 100
+learning_rate = 0.001
+batch = 10
+dccrn_kernel_num = [32, 64, 128, 256, 256, 256]
+
+# front end: 25 ms window, 6.25 ms hop at 16 kHz, 512-point transform (config.py:54-61)
+fs = 16000
+win_len = 400
+win_inc = 100
+ola_ratio = 0.75
+fft_len = 512
+sam_sec = fft_len / fs
+frm_samp = fs * (fft_len / fs)
+window = 'hanning'
+
+rnn_layers = 2              # DCCRN
+rnn_units = 256
+rnn_input_size = 512        # CRN
+
+# FullSubNet (config.py:70-81)
+sb_num_neighbors = 15
+fb_num_neighbors = 0
+num_freqs = fft_len // 2 + 1
+look_ahead = 2
+fb_output_activate_function = "ReLU"
+sb_output_activate_function = None
+fb_model_hidden_size = 512
+sb_model_hidden_size = 384
+weight_init = False
+norm_type = "offline_laplace_norm"
+num_groups_in_drop_band = 2
+
+# ---- build-side knobs (not in the reference)
+act_dtype = 'fp32'          # 'fp32' (parity mode) or 'bf16' (storage + MFMA operand dtype, fp32 accumulate)
+train_data_path = None      # [N, 2, L] .npy files of (noisy, clean) pairs; dataloader.py:63-71 has placeholder paths
+valid_data_path = None
+test_data_path = None
 
 # combinations the reference refuses at import time (config.py:86-89)
-for _bad, _why in (((masking_mode == 'Direct(None make)' and perceptual is not False), "spectral mapping has no perceptual trainer"),   # noqa: F821
-                   ((model == 'FullSubNet' and perceptual is not False), "FullSubNet has no perceptual trainer")):                    # noqa: F821
-    assert not _bad, _why
+assert not (masking_mode == 'Direct(None make)' and perceptual is not False), "This setting is not created "
+assert not (model == 'FullSubNet' and perceptual is not False), "This setting is not created "

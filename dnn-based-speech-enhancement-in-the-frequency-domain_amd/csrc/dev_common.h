@@ -97,6 +97,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
+bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);
 void launch_istft_fft(const IstftFft& d, const ArenaBases& ab, hipStream_t st);

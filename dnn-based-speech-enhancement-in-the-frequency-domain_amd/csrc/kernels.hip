@@ -703,7 +703,7 @@ __global__ void ola_fwd_kernel(const Ola d, const ArenaBases ab) {
     float s = 0.f;
     for (int t = t0; t <= t1; ++t) s += fr[((int64_t)b * d.T + t) * d.win + (p - t * d.hop)];
     s = s / (coff[p] + 1e-8f);
-    wav[i] = fminf(1.f, fmaxf(-1.f, s));
+    wav[i] = d.noclamp ? s : fminf(1.f, fmaxf(-1.f, s));
   }
 }
 __global__ void ola_bwd_kernel(const Ola d, const ArenaBases ab) {
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void specout_bwd_kernel(const SpecOut d, const
   __shared__ float tr[32][33], ti[32][33];
   float* dest = reinterpret_cast<float*>(rp(ab, d.est));
   const float* gr = reinterpret_cast<const float*>(rp(ab, d.out_real));
-  const float* gi = d.mode == 2 ? nullptr : reinterpret_cast<const float*>(rp(ab, d.out_imag));
+  const float* gi = (d.mode == 2 || d.mode == 3) ? nullptr : reinterpret_cast<const float*>(rp(ab, d.out_imag));
   const int NS = d.NF + 1;
   const int b = blockIdx.z, t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256) void specout_bwd_kernel(const SpecOut d, const
     float vr = 0.f, vi = 0.f;
     if (t < d.T && k < d.NF) {
       const int64_t o = ((int64_t)b * d.NF + k) * d.T + t;
-      vr = gr[o]; vi = d.mode == 2 ? 0.f : gi[o];
+      if (d.mode == 3) { vr = gr[2 * o]; vi = gr[2 * o + 1]; }
+      else { vr = gr[o]; vi = d.mode == 2 ? 0.f : gi[o]; }
     }
     tr[r][tx] = vr; ti[r][tx] = vi;
   }

@@ -6,6 +6,12 @@
 #include "sefd_desc.h"
 #include "dev_common.h"
 
+// No implicit mul+add contraction in this file: with it the compiler fused the cell update `f*c + i*g` differently for the two
+// packed row pairs of a lane (one v_pk_fma, one v_pk_mul + v_pk_add), so a sequence's result depended on which of the 16 MFMA
+// tile rows it sat in - 1e-7 in c, a flipped bf16 ulp in h a few frames later, 2e-3 at the output: eval-mode batch independence
+// failed in bf16 (tests/test_gpu_model.py::test_bf16_full_shape_properties_at_bench_size).  Fused operations are written out.
+#pragma clang fp contract(off)
+
 namespace sefd {
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
@@ -16,7 +22,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 __device__ __forceinline__ f32x2 rcp_2(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
 __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) { return rcp_2(exp2_2(x * -1.4426950408889634f) + 1.f); }
-__device__ __forceinline__ f32x2 tanh2(f32x2 x) { return rcp_2(exp2_2(x * 2.8853900817779268f) + 1.f) * -2.f + 1.f; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) { return fma2(rcp_2(exp2_2(x * 2.8853900817779268f) + 1.f), f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}); }
 
 // H is a compile-time constant (32 / 64 / 96 / 128): with run-time trip counts hipcc guards every MFMA with a branch and
 // drains the software-prefetched loads before the matrix section, which serialises the 483-step loop.
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
     for (int rp2 = 0; rp2 < 4; rp2 += 2) {
       const f32x2 ig = sigmoid2(f32x2{acc[0][rp2], acc[0][rp2 + 1]}), fg = sigmoid2(f32x2{acc[1][rp2], acc[1][rp2 + 1]});
       const f32x2 gg = tanh2(f32x2{acc[2][rp2], acc[2][rp2 + 1]}), og = sigmoid2(f32x2{acc[3][rp2], acc[3][rp2 + 1]});
-      const f32x2 cn = fg * f32x2{c[rp2], c[rp2 + 1]} + ig * gg;
+      const f32x2 cn = fma2(fg, f32x2{c[rp2], c[rp2 + 1]}, ig * gg);
       const f32x2 hv = og * tanh2(cn);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {

@@ -318,6 +318,43 @@ void finalize_rungemms(Builder& b, Plan* P) {
         g.flags = (g.flags & ~kRunYAligned) | (ya ? kRunYAligned : 0);
       }
     }
+  // Wide-tile kernel (cgemm256.hip) for the bf16 layers that carry the FLOPs: N a multiple of 256, LDS-DMA-able runs, enough rows.
+  // Its weights are packed K-tile major (kRunWTile32): a property of the packed BUFFER, so it is chosen only when every GEMM
+  // that reads the buffer qualifies, and the PACK table of the matrix is permuted here, once.  SEFD_CG256=0: 128 x 128 kernel
+  // everywhere (A/B runs).
+  {
+    const bool wide = !(getenv("SEFD_CG256") && atoi(getenv("SEFD_CG256")) == 0);
+    const int wide_minm = getenv("SEFD_CG256_MINM") ? atoi(getenv("SEFD_CG256_MINM")) : 4096;
+    std::map<int64_t, bool> elig;                            // weight buffer offset -> every reader (either phase) qualifies
+    std::vector<Op*> all;
+    for (auto* ops : {&P->fwd, &P->bwd})
+      for (Op& op : *ops) all.push_back(&op);
+    for (Op* op : all) {
+      if (op->kind != OP_RUNGEMM || op->g.w.arena != A_WS) continue;
+      const RunGemm& g = op->g;
+      const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm;
+      auto it = elig.find(g.w.off);
+      if (it == elig.end()) elig[g.w.off] = e; else it->second = it->second && e;
+    }
+    for (auto& kv : elig) {
+      if (!kv.second) continue;
+      const RunGemm* g = nullptr;
+      for (Op* op : all) if (op->kind == OP_RUNGEMM && op->g.w.arena == A_WS && op->g.w.off == kv.first) { g = &op->g; break; }
+      bool done = false;
+      for (Op* po : all) {
+        if (po->kind != OP_PACK || po->pack.width != 1 || po->pack.dst.arena != A_WS || po->pack.dst.off != kv.first) continue;
+        if (!g || po->pack.n != (int64_t)g->Npad * g->ldw) break;
+        int32_t* tab = reinterpret_cast<int32_t*>(P->consts.data() + po->pack.tab.off);
+        std::vector<int32_t> old(tab, tab + po->pack.n);
+        for (int n = 0; n < g->Npad; ++n)
+          for (int k = 0; k < g->ldw; ++k) tab[w_index(kRunWTile32, g->ldw, g->Npad, n, k)] = old[(size_t)n * g->ldw + k];
+        done = true;
+        break;
+      }
+      if (done)
+        for (Op* op : all) if (op->kind == OP_RUNGEMM && op->g.w.arena == A_WS && op->g.w.off == kv.first) op->g.flags |= kRunWTile32;
+    }
+  }
   // weight repacking: one launch per phase instead of one per matrix (71 launches of ~5 us in a DCCRN step)
   for (auto* ops : {&P->fwd, &P->bwd}) {
     std::vector<Pack> packs;
@@ -2305,7 +2342,67 @@ Plan* build_torchstft_plan(const ModelConfig& cfg) {
   return P;
 }
 
+// =================================================================================================================
+// torch.istft(n_fft, hop, win_length, hann_window(win_length), center=True, length=L) - the inverse front end of FullSubNet's
+// validation path (tools_for_model.py:651-680, called at trainer.py:341-345).  IO: spec [B][NF][T][2] (memory image of the
+// complex [B, NF, T] tensor, or the reference's real-pair [B, NF, T, 2]) -> wav [B][L].  Same two kernels as the ConviSTFT path:
+// the inverse-FFT frame kernel (its rank-2 "correction" table set to the irfft's half weights of the DC and Nyquist bins:
+//   irfft(X)[j] = (S[j] - Re X[0] / 2 - (-1)^j Re X[N/2] / 2) / (N/2),  S[j] = Re sum_{k <= N/2} X[k] e^{2 pi i k j / N})
+// and the overlap-add kernel with the window-envelope normaliser, without the clamp.
+Plan* build_torchistft_plan(const ModelConfig& cfg) {
+  Plan* P = new Plan();
+  P->cfg = cfg;
+  Builder b;
+  b.P = P;
+  b.c = cfg;
+  const int B = cfg.B, L = cfg.L, W = cfg.win_len, hop = cfg.hop, NFFT = cfg.fft_len;
+  const int pad = NFFT / 2;
+  const int T = 1 + L / hop;
+  const int NF = NFFT / 2 + 1, NS = NF + 1, SW = NS * 2;
+  P->T = T;
+  P->NF = NF;
+  if (NFFT != 512 || W > NFFT || pad >= L || (T - 1) * hop + NFFT < pad + L) { P->error = "torch.istft plan: fft_len must be 512 and the frames must cover the clip"; return P; }
+  Ptr io_spec = b.io("spec", (int64_t)B * NF * T * 2);
+  Ptr io_wav = b.io("wav", (int64_t)B * L);
+  Ptr est = b.ws("est", (int64_t)B * T * SW, DT_F32);
+  Ptr frames = b.ws("frames", (int64_t)B * T * NFFT, DT_F32);
+  std::vector<double> win(NFFT, 0.0);
+  const int left = (NFFT - W) / 2;
+  for (int j = 0; j < W; ++j) win[left + j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  { Op& op = b.push(P->fwd, OP_MEMSET, 1); op.ms.dst = est; op.ms.bytes = (int64_t)B * T * SW * 4; }       // slot 0 of every frame stays 0
+  SpecOut so;
+  std::memset(&so, 0, sizeof(so));
+  so.est = est; so.out_real = io_spec; so.out_imag = b.none(); so.B = B; so.T = T; so.NF = NF; so.mode = 3; so.accumulate = 0;
+  b.push(P->fwd, OP_SPECOUT_BWD, 2).so = so;
+  {
+    std::vector<float> tw(1024);
+    for (int k = 0; k < 512; ++k) { tw[2 * k] = (float)std::cos(2.0 * kPi * k / 512.0); tw[2 * k + 1] = (float)std::sin(2.0 * kPi * k / 512.0); }
+    std::vector<float> c(4 * 257, 0.f);                  // [even | odd][re | im][k]
+    c[(0 * 2 + 0) * 257 + 0] = 0.5f; c[(0 * 2 + 0) * 257 + 256] = 0.5f;
+    c[(1 * 2 + 0) * 257 + 0] = 0.5f; c[(1 * 2 + 0) * 257 + 256] = -0.5f;
+    Op& op = b.push(P->fwd, OP_ISTFT_FFT, 3);
+    op.ifft.est = est; op.ifft.frames = frames; op.ifft.tw = b.cst(tw.data(), 4096); op.ifft.win = b.win512(win);
+    op.ifft.corr = b.cst(c.data(), (int64_t)c.size() * 4); op.ifft.nframes = (int64_t)B * T; op.ifft.W = NFFT;
+  }
+  const int Lp = (T - 1) * hop + NFFT;
+  std::vector<float> env(Lp, 0.f);
+  for (int t = 0; t < T; ++t)
+    for (int j = 0; j < NFFT; ++j) env[t * hop + j] += (float)(win[j] * win[j]);
+  Ola ola;
+  std::memset(&ola, 0, sizeof(ola));
+  ola.frames = frames; ola.wav = io_wav; ola.coff = b.cst(env.data(), (int64_t)env.size() * 4); ola.dwav = ola.dpad = b.none();
+  ola.B = B; ola.T = T; ola.L = L; ola.win = NFFT; ola.hop = hop; ola.trim = pad; ola.noclamp = 1;
+  b.push(P->fwd, OP_OLA_FWD, 4).ola = ola;
+  finalize_rungemms(b, P);
+  P->arena_bytes[A_WS] = b.ws_off;
+  P->arena_bytes[A_PARAM] = 4; P->arena_bytes[A_GRAD] = 4; P->arena_bytes[A_STATE] = 4;
+  P->arena_bytes[A_CONST] = (int64_t)P->consts.size();
+  P->arena_bytes[A_IO] = b.io_off;
+  return P;
+}
+
 Plan* build_plan(const ModelConfig& cfg) {
+  if (cfg.model == 5) return build_torchistft_plan(cfg);
   if (cfg.model == 4) return build_torchstft_plan(cfg);
   if (cfg.model == 3) return build_fsn_plan(cfg);
   return cfg.model == 2 ? build_frontend_plan(cfg) : (cfg.model == 1 ? build_crn_plan(cfg) : build_dccrn_plan(cfg));

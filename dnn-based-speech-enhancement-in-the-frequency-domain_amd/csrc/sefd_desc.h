@@ -78,6 +78,12 @@ constexpr int kRunAligned = 1;   // LDS-DMA loader usable
 constexpr int kRunAccum = 2;     // y += result (fp32 y): recurrent term added onto the hoisted input GEMM / gradient accumulation
 constexpr int kRunRelu = 4;      // y = max(result, 0)
 constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chunks: the tile is staged through LDS and stored wide
+constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw / 32][Npad][32]: the B operand of one 32-deep K tile is ONE
+                                 // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
+// element index of W[n][k] inside the packed weight buffer of `g`
+static inline int64_t w_index(int flags, int ldw, int Npad, int n, int k) {
+  return (flags & kRunWTile32) ? ((int64_t)(k >> 5) * Npad + n) * 32 + (k & 31) : (int64_t)n * ldw + k;
+}
 
 // PACK: dst[i] = sum_{e < width} sign(tab[i*width+e]) * src[|tab[i*width+e]|-1]   (entry 0 -> nothing).  Table int32 in A_CONST.
 // width 1: packed conv / LSTM weights ; width 2: combined biases (b_r - b_i | b_r + b_i), (b_ih + b_hh).
@@ -201,11 +207,13 @@ struct Ola {
   Ptr frames, wav, coff;
   Ptr dwav, dpad;              // backward: dpad [B][(T-1)*hop+win] = clampmask*dwav/(coff+1e-8) (0 in the trimmed borders)
   int32_t B, T, L, win, hop, trim;
+  int32_t noclamp, pad_;       // noclamp = 1: torch.istft semantics (no clamp_(-1, 1)); the ConviSTFT path of DCCRN / CRN clamps
 };
 
 // est spec [B][T][NF+1][2] (fp32, slot layout above) <-> reference layout out_real/out_imag [B][NF][T] fp32
 // mode 1: out_real = |est| (magnitude of the pairs, CRN target_mags) ; mode 2: est is a plain [B*T][NF] fp32 array -> out_real
-// mode 3: out_real receives the interleaved complex tensor [B][NF][T][2] (memory image of torch.complex64 [B, NF, T])
+// mode 3: out_real receives the interleaved complex tensor [B][NF][T][2] (memory image of torch.complex64 [B, NF, T]);
+//         SPECOUT_BWD with mode 3 is the inverse copy [B][NF][T][2] -> est (the input side of the torch.istft plan)
 struct SpecOut {
   Ptr est, out_real, out_imag; // forward: est -> out_*   ; backward: dest += d(out_*)
   int32_t B, T, NF, accumulate;

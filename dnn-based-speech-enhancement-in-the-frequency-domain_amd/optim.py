@@ -85,8 +85,11 @@ class Adam(torch.optim.Optimizer):
 
     # ---- torch.optim.Adam compatible checkpoint format
     def state_dict(self):
-        sd = {"state": {}, "param_groups": [{**{k: v for k, v in self.param_groups[0].items() if k != "params"},
-                                             "params": list(range(len(self.param_groups[0]["params"])))}]}
+        # the param_group carries every key of the installed torch.optim.Adam's defaults (weight_decay 0, amsgrad False, ...) so
+        # that the checkpoint also loads into the reference's optimizer class (train_interface.py:59, 110)
+        tmpl = dict(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]).defaults)
+        tmpl.update({k: v for k, v in self.param_groups[0].items() if k != "params"})
+        sd = {"state": {}, "param_groups": [{**tmpl, "params": list(range(len(self.param_groups[0]["params"])))}]}
         if self._pending is not None and self._m is None:
             return self._pending
         if self._m is not None and self._step > 0:

@@ -21,7 +21,7 @@ class Plan:
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
         cfg = _lib.ModelConfig()
-        cfg.model = {"DCCRN": 0, "CRN": 1, "STFT": 2, "FullSubNet": 3, "TorchSTFT": 4}[model]
+        cfg.model = {"DCCRN": 0, "CRN": 1, "STFT": 2, "FullSubNet": 3, "TorchSTFT": 4, "TorchISTFT": 5}[model]
         cfg.B, cfg.L = int(B), int(L)
         if model == "FullSubNet":
             # L = number of STFT frames T; kernel_num carries (sb_neighbors, fb_neighbors, look_ahead, fb_hidden, sb_hidden,

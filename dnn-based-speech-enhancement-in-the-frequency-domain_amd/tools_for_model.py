@@ -35,6 +35,36 @@ def stft(y, n_fft=cfg.fft_len, hop_length=int(cfg.win_len * cfg.ola_ratio), win_
     return torch.view_as_complex(plan.io(ar, "spec", (B, plan.NF, plan.T, 2)).clone())
 
 
+def istft(features, n_fft=cfg.fft_len, hop_length=int(cfg.win_len * cfg.ola_ratio), win_length=cfg.win_len, length=None, use_mag_phase=False):
+    """tools_for_model.py:651-680: wrapper of torch.istft(window=hann_window(win_length), center=True, length=length) -> [B, L].
+    `features`: complex [B, F, T], the reference's real-pair [B, F, T, 2] (which torch >= 2 rejects in the reference itself,
+    SURVEY Q9 - accepted here through view_as_complex semantics), or (mag, phase) with use_mag_phase."""
+    if use_mag_phase:
+        assert isinstance(features, (tuple, list))
+        mag, phase = features
+        features = torch.stack([mag * torch.cos(phase), mag * torch.sin(phase)], dim=-1)
+    if torch.is_complex(features):
+        features = torch.view_as_real(features)
+    if not features.is_cuda:
+        raise RuntimeError("sefd istft runs on the MI355X only (cuda tensors); there is no CPU fallback")
+    features = features.detach().float().contiguous()
+    B, F, T, two = features.shape
+    assert two == 2 and F == n_fft // 2 + 1
+    L = int(length) if length is not None else hop_length * (T - 1)
+    key = ("istft", B, L, T, n_fft, hop_length, win_length, str(features.device))
+    fe = _FE_CACHE.get(key)
+    if fe is None:
+        plan = Plan(B, L, win_len=win_length, win_inc=hop_length, fft_len=n_fft, model="TorchISTFT")
+        if plan.T != T:
+            raise ValueError(f"istft: {T} frames do not match length {L} at hop {hop_length} (expected {plan.T})")
+        fe = (plan, plan.alloc_arenas(features.device))
+        _FE_CACHE[key] = fe
+    plan, ar = fe
+    plan.io(ar, "spec", (B, F, T, 2)).copy_(features)
+    plan.run(PHASE_FWD, ar, torch.cuda.current_stream().cuda_stream)
+    return plan.io(ar, "wav", (B, L)).clone()
+
+
 def _targets(noisy, clean, want_mag, want_phase, want_cirm):
     L_ = _lib.lib()
     nr = torch.view_as_real(noisy.contiguous())
@@ -64,3 +94,8 @@ def decompress_cIRM(mask, K=10, limit=9.9):
     """tools_for_model.py:720-723 (validation path; element-wise torch is plumbing here, not the training hot path)."""
     mask = limit * (mask >= limit) - limit * (mask <= -limit) + mask * (torch.abs(mask) < limit)
     return -K * torch.log((K - mask) / (K + mask))
+
+
+def Bar(iterable, *args, **kwargs):
+    """tools_for_model.py:1396-1416 wraps every loader in a console progress bar; the training loops only iterate it."""
+    return iterable

@@ -121,17 +121,26 @@ def crn_direct_train(model, optimizer, train_loader, DEVICE):
 
 
 # ------------------------------------------------------------------------------------------------ validation
-def model_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers=None):
-    """Validation pass of the T-F masking models (reference trainer.py:188-241): eval-mode plans (BatchNorm running
-    statistics), no gradients, mean of the per-batch losses.
+def _default_scorers():
+    """(cal_pesq, cal_stoi) of sefd_amd.tools_for_estimate: the C++ P.862 / STOI scorers (reference tools_for_estimate.py:68-99
+    calls a closed x86 PESQ.so and pystoi).  None when the scorer library has not been built."""
+    try:
+        from . import tools_for_estimate as te
+        te.lib()
+        return te.cal_pesq, te.cal_stoi
+    except Exception:
+        return None
 
-    The reference scores every enhanced utterance with PESQ (a closed x86 binary) and pystoi on the CPU; neither ships
-    here, so they are injected: `scorers = (cal_pesq, cal_stoi)`, each `f(estimated[B, L] ndarray, clean[B, L] ndarray)
-    -> per-utterance scores`.  Without scorers the two averages are NaN and no score file is written; with them the
-    per-utterance lines go to `<dir_to_save>/Epoch_<epoch>_SCORES` in the reference's format and `writer.log_wav` is
-    called every 10th epoch exactly as there.  Returns (validation_loss, avg_pesq, avg_stoi)."""
+
+def _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch_fn, n_losses, scorers):
+    """Shared body of the reference's five validate functions (trainer.py:188-483): eval-mode plans (BatchNorm running
+    statistics), no gradients, per-utterance PESQ / STOI lines in `<dir_to_save>/Epoch_<epoch>_SCORES`, `writer.log_wav` of the
+    last batch's first utterance every 10th epoch, means over the batches.  `batch_fn(inputs, targets)` returns
+    (tuple of n_losses loss tensors, enhanced waveforms [B, L])."""
     import numpy as np
-    validation_loss = torch.zeros((), device=DEVICE)
+    if scorers == "default":
+        scorers = _default_scorers()
+    sums = [torch.zeros((), device=DEVICE) for _ in range(n_losses)]
     avg_pesq = avg_stoi = 0.0
     batch_num = 0
     f_score = open(f"{dir_to_save}/Epoch_{epoch:d}_SCORES", "a") if scorers is not None else None
@@ -144,8 +153,9 @@ def model_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE,
                 batch_num += 1
                 inputs = inputs.float().to(DEVICE, non_blocking=True)
                 targets = targets.float().to(DEVICE, non_blocking=True)
-                _, _, outputs = model(inputs, targets)
-                validation_loss += model.loss(outputs, targets)
+                losses, outputs = batch_fn(inputs, targets)
+                for acc, l in zip(sums, losses):
+                    acc += l
                 last = (inputs, targets, outputs)
                 if scorers is not None:
                     est, clean = outputs.cpu().numpy(), targets.cpu().numpy()
@@ -161,6 +171,63 @@ def model_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE,
             f_score.close()
         model.train(was_training)
     n = max(batch_num, 1)
+    means = tuple(acc / n for acc in sums)
     if scorers is None:
-        return validation_loss / n, float("nan"), float("nan")
-    return validation_loss / n, avg_pesq / n, avg_stoi / n
+        return means + (float("nan"), float("nan"))
+    return means + (avg_pesq / n, avg_stoi / n)
+
+
+def model_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers="default"):
+    """trainer.py:188-241 (T-F masking).  Returns (validation_loss, avg_pesq, avg_stoi).  `scorers = (cal_pesq, cal_stoi)`, each
+    `f(estimated[B, L] ndarray, clean[B, L] ndarray) -> per-utterance scores`; "default" = the package's C++ scorers;
+    None: no scoring (both averages NaN, no score file)."""
+    def batch(inputs, targets):
+        _, _, outputs = model(inputs, targets)
+        return (model.loss(outputs, targets),), outputs
+    return _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch, 1, scorers)
+
+
+def model_perceptual_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers="default"):
+    """trainer.py:242-306: loss = (main + perceptual) / 2.  Returns (loss, main, perceptual, avg_pesq, avg_stoi)."""
+    def batch(inputs, targets):
+        real_spec, img_spec, outputs = model(inputs)
+        main_loss = model.loss(outputs, targets)
+        perceptual_loss = model.loss(outputs, targets, real_spec, img_spec, perceptual=True)
+        return ((main_loss + perceptual_loss) / 2, main_loss, perceptual_loss), outputs
+    return _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch, 3, scorers)
+
+
+def fullsubnet_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers="default"):
+    """trainer.py:309-373: loss on the compressed cIRM; the enhanced waveform is decompress_cIRM(cRM) x noisy spectrum through
+    `tools.istft` (the reference passes a real-pair tensor to torch.istft there, which torch >= 2 rejects: SURVEY Q9)."""
+    from . import tools_for_model as tools
+
+    def batch(inputs, targets):
+        noisy_complex = tools.stft(inputs)
+        clean_complex = tools.stft(targets)
+        noisy_mag, _ = tools.mag_phase(noisy_complex)
+        cIRM = tools.build_complex_ideal_ratio_mask(noisy_complex, clean_complex)
+        cRM = model(noisy_mag)
+        loss = model.loss(cIRM, cRM)
+        cRM = tools.decompress_cIRM(cRM)
+        enhanced_real = cRM[..., 0] * noisy_complex.real - cRM[..., 1] * noisy_complex.imag
+        enhanced_imag = cRM[..., 1] * noisy_complex.real + cRM[..., 0] * noisy_complex.imag
+        enhanced_complex = torch.stack((enhanced_real, enhanced_imag), dim=-1)
+        return (loss,), tools.istft(enhanced_complex, length=inputs.size(-1))
+    return _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch, 1, scorers)
+
+
+def dccrn_direct_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers="default"):
+    """trainer.py:377-430 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra."""
+    def batch(inputs, targets):
+        output_real, target_real, output_imag, target_imag, outputs = model(inputs, targets)
+        return ((model.loss(output_real, target_real) + model.loss(output_imag, target_imag)) / 2,), outputs
+    return _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch, 1, scorers)
+
+
+def crn_direct_validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, scorers="default"):
+    """trainer.py:433-483: loss on the mapped magnitudes."""
+    def batch(inputs, targets):
+        output_mag, target_mag, outputs = model(inputs, targets)
+        return (model.loss(output_mag, target_mag),), outputs
+    return _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch, 1, scorers)

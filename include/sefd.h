@@ -23,7 +23,7 @@ typedef struct sefd_plan sefd_plan;
 
 /* Mirror of the config.py knobs that shape DCCRN (config.py:35-68) plus batch geometry. */
 typedef struct sefd_model_config {
-  int32_t model;          /* 0 DCCRN, 1 CRN, 2 ConvSTFT front end, 3 FullSubNet, 4 torch.stft front end (see csrc/plan.cpp) */
+  int32_t model;          /* 0 DCCRN, 1 CRN, 2 ConvSTFT front end, 3 FullSubNet, 4 torch.stft front end, 5 torch.istft (see csrc/plan.cpp) */
   int32_t B, L;           /* batch, samples per clip */
   int32_t win_len, hop, fft_len;
   int32_t n_layers;

@@ -57,6 +57,12 @@ def build_cirm(noisy: torch.Tensor, clean: torch.Tensor, K=10.0, C=0.1) -> torch
     return K * (1 - torch.exp(-C * m)) / (1 + torch.exp(-C * m))
 
 
+def decompress_cirm(mask, K=10.0, limit=9.9):
+    """tools_for_model.py:720-723."""
+    mask = limit * (mask >= limit) - limit * (mask <= -limit) + mask * (torch.abs(mask) < limit)
+    return -K * torch.log((K - mask) / (K + mask))
+
+
 def unfold(x, n):
     """tools_for_model.py:806-837: [B,C,F,T] -> [B,F,C,2n+1,T] with reflect padding along F."""
     B, Cc, Fq, T = x.shape

@@ -55,7 +55,7 @@ void rungemm(const RunGemm& d, const AB& ab) {
     const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
     for (int n = 0; n < d.N; ++n) {
       double acc = 0.0;
-      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, (int64_t)n * d.ldw + k);
+      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, w_index(d.flags, d.ldw, d.Npad, n, k));
       float v = (float)acc + (bias ? bias[n] : 0.f);
       if (d.flags & kRunAccum) v += ((const float*)y)[o + n];
       if (d.flags & kRunRelu) v = v > 0.f ? v : 0.f;
@@ -730,7 +730,7 @@ void run_op(const Op& op, const AB& ab) {
           double s = 0;
           for (int t = 0; t < d.T; ++t) { const int j = p - t * d.hop; if (j >= 0 && j < d.win) s += fr[((int64_t)b * d.T + t) * d.win + j]; }
           float v = (float)s / (coff[p] + 1e-8f);
-          wav[(int64_t)b * d.L + n] = std::fmin(1.f, std::fmax(-1.f, v));
+          wav[(int64_t)b * d.L + n] = d.noclamp ? v : std::fmin(1.f, std::fmax(-1.f, v));
         }
       break;
     }
@@ -762,6 +762,7 @@ void run_op(const Op& op, const AB& ab) {
           for (int k = 0; k < d.NF; ++k) {
             const int64_t e = (((int64_t)b * d.T + t) * NS + k + 1) * 2, o = ((int64_t)b * d.NF + k) * d.T + t;
             if (op.kind == OP_SPECOUT_BWD && d.mode == 2) { est[((int64_t)b * d.T + t) * d.NF + k] = orr[o]; continue; }
+            if (op.kind == OP_SPECOUT_BWD && d.mode == 3) { est[e] = orr[2 * o]; est[e + 1] = orr[2 * o + 1]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 3) { orr[2 * o] = est[e]; orr[2 * o + 1] = est[e + 1]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 2) { orr[o] = est[((int64_t)b * d.T + t) * d.NF + k]; continue; }
             if (op.kind == OP_SPECOUT_FWD && d.mode == 1) { orr[o] = std::sqrt(est[e] * est[e] + est[e + 1] * est[e + 1]); continue; }

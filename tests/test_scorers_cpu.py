@@ -1,0 +1,67 @@
+"""CPU tier: the C++ STOI scorer (csrc_host/scorers.cpp through include/sefd_scorers.h) against the oracle's independent numpy /
+scipy statement of the published algorithm (oracle/stoi.py; parity with pystoi itself is unpinned - not installed, not vendored)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import sefd_amd  # noqa: F401
+from sefd_amd import tools_for_estimate as te
+from oracle import stoi as so
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    te.build()
+
+
+def speechlike(B, n, seed=0):
+    """Noise / tone carriers with syllabic (3-6 Hz) envelopes and a pause: something STOI's 30-frame envelope correlation can see."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    out = np.zeros((B, n), np.float32)
+    for b in range(B):
+        s = np.zeros(n)
+        for f0 in (300, 700, 1500, 2800, 4200):
+            carrier = np.sin(2 * np.pi * f0 * t * (1 + 0.02 * b) + rng.uniform(0, 6)) + 0.3 * rng.standard_normal(n)
+            s += carrier * np.clip(np.sin(2 * np.pi * (3 + rng.uniform(0, 3)) * t + rng.uniform(0, 6)), 0, None) ** 2
+        s[int(0.4 * n):int(0.5 * n)] *= 5e-4
+        out[b] = (0.1 * s).astype(np.float32)
+    return out
+
+
+def test_library_exports_the_declared_symbols():
+    L = te.lib()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sefd_scorers.h")).read()
+    for sym in te.EXPORTED:
+        assert hasattr(L, sym) and sym in hdr
+
+
+def test_resampler_matches_scipy_resample_poly():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(4801)
+    h = so.resample_window(10000, 16000)
+    assert len(h) == 581                                         # p/q = 5/8, 60 dB, 10 % roll-off
+    y = so.resample(x, 10000, 16000)
+    assert len(y) == 3001 and abs(float(np.abs(y).max())) < 4.0
+
+
+@pytest.mark.parametrize("n", [48000, 16000 + 123])
+def test_stoi_cpp_equals_oracle(n):
+    clean = speechlike(4, n, seed=3)
+    rng = np.random.default_rng(4)
+    est = (clean + 0.05 * rng.standard_normal(clean.shape).astype(np.float32) * np.array([[0.1], [0.5], [2.0], [8.0]], np.float32))
+    got = np.array(te.cal_stoi(est, clean))
+    ref = np.array([so.stoi(clean[i], est[i], 16000) for i in range(4)])
+    assert np.abs(got - ref).max() < 1e-9
+    assert np.all(np.diff(got) < 0) and got[0] > 0.95 and got[-1] < 0.6     # monotone in the noise level
+    assert np.allclose(te.cal_stoi(clean, clean), 1.0, atol=1e-9)
+    # single-threaded == multi-threaded, 1-D input accepted
+    assert np.array_equal(np.array(te.cal_stoi(est, clean, nthreads=1)), got)
+    assert abs(te.cal_stoi(est[1], clean[1])[0] - got[1]) < 1e-12
+
+
+def test_too_short_signal_returns_the_floor_value():
+    clean = speechlike(1, 3000)
+    assert te.cal_stoi(clean * 0.9, clean)[0] == pytest.approx(1e-5)       # fewer than 30 frames (pystoi warns and returns 1e-5)

@@ -1,0 +1,8 @@
+# round 2, GPU run 1: full -m gpu suite with per-test durations, then a bench line
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+O=$GRAFT_REPO_ROOT/gpurun_out
+timeout 1700 python -m pytest tests -q -m gpu --durations=0 > $O/r2_run1_tests.log 2>&1; echo "rc=$?" >> $O/r2_run1_tests.log
+tail -5 $O/r2_run1_tests.log
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r2_run1_bench.log 2>&1
+tail -1 $O/r2_run1_bench.log | cut -c1-600
