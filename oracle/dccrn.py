@@ -155,8 +155,9 @@ def prelu(x, a):
     return torch.where(x > 0, x, a * x)
 
 
-def lstm_layer(x, w_ih, w_hh, b_ih, b_hh):
-    """Single-layer unidirectional nn.LSTM, zero initial state; x [T, B, I] -> [T, B, H]. Gate order i,f,g,o."""
+def lstm_layer_loop(x, w_ih, w_hh, b_ih, b_hh):
+    """Single-layer unidirectional nn.LSTM, zero initial state, written out step by step; x [T, B, I] -> [T, B, H].
+    Gate order i,f,g,o.  Kept as the readable statement of the cell; `lstm_layer` is what the oracle runs."""
     T, B, _ = x.shape
     H = w_hh.shape[1]
     gx = x @ w_ih.t() + (b_ih + b_hh)
@@ -170,6 +171,16 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh):
         h = torch.sigmoid(o) * torch.tanh(c)
         outs.append(h)
     return torch.stack(outs, 0)
+
+
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh):
+    """The same cell through ATen's fused CPU LSTM (what nn.LSTM.forward calls, tools_for_model.py:167-170): one call for all T
+    steps instead of T Python iterations, differentiable; tests/test_oracle_golden.py pins it against `lstm_layer_loop`."""
+    T, B, _ = x.shape
+    H = w_hh.shape[1]
+    z = x.new_zeros(1, B, H)
+    out, _, _ = torch._VF.lstm(x, (z, z), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, False, False, False)
+    return out
 
 
 def complex_lstm(xr, xi, P, prefix, project):

@@ -217,3 +217,16 @@ def test_oracle_validation_path_after_one_step():
         vloss = main_loss("SI-SNR", wav, yv)
     assert rel_err(wav, g["g/val_wav"]) < 1e-4
     assert abs(float(vloss) - float(g["g/val_loss"])) < 1e-4 * abs(float(g["g/val_loss"]))
+
+
+def test_vectorised_lstm_equals_the_written_out_cell():
+    """oracle.dccrn.lstm_layer (ATen's fused CPU LSTM, one call for all T steps) == the step-by-step statement of the cell."""
+    from oracle.dccrn import lstm_layer, lstm_layer_loop
+    torch.manual_seed(0)
+    x = torch.randn(50, 3, 40, requires_grad=True)
+    wi, wh = (torch.randn(64, 40) * 0.1).requires_grad_(), (torch.randn(64, 16) * 0.1).requires_grad_()
+    bi, bh = torch.randn(64) * 0.1, torch.randn(64) * 0.1
+    a, b = lstm_layer(x, wi, wh, bi, bh), lstm_layer_loop(x, wi, wh, bi, bh)
+    assert rel_err(a, b) < 1e-6
+    for p, q in zip(torch.autograd.grad(a.square().sum(), [x, wi, wh]), torch.autograd.grad(b.square().sum(), [x, wi, wh])):
+        assert rel_err(p, q) < 1e-5

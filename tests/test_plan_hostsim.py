@@ -95,6 +95,34 @@ def test_chunked_lstm_pipeline_plan_equals_unchunked(monkeypatch):
         assert torch.equal(a, b_)
 
 
+def test_tiled_weight_layout_is_a_pure_relayout(monkeypatch):
+    """Wide-tile GEMMs (cgemm256.hip) read their weights K-tile major (kRunWTile32): same numbers, different addresses.  The
+    plan with every N % 256 == 0 bf16 layer switched to that layout must give bit-identical results on the host simulator."""
+    B, L = 1, 2400
+    kw = dict(kernel_num=(32, 64, 128, 256, 256, 256), rnn_units=256)
+    P = oracle_params(DCCRNConfig(masking_mode="C", **kw))
+    x, _ = make_signals(B, L)
+    outs = []
+    for wide in ("0", "1"):
+        monkeypatch.setenv("SEFD_CG256", wide)
+        monkeypatch.setenv("SEFD_CG256_MINM", "64")
+        plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
+        import ctypes as C
+        n, sz = plan.num_ops(PHASE_FWD), plan.lib.sefd_op_size()
+        raw = np.ctypeslib.as_array((C.c_int32 * (n * sz // 4)).from_address(plan.ops_ptr(PHASE_FWD))).reshape(n, sz // 4)
+        ntiled = sum(1 for i in range(n) if plan.op_info(PHASE_FWD, i)["kind"] == 1 and plan.op_info(PHASE_FWD, i)["N"] % 256 == 0
+                     and plan.op_info(PHASE_FWD, i)["M"] >= 64)
+        assert ntiled >= 6
+        ar = plan.alloc_arenas("cpu")
+        fill_params(plan, ar, P)
+        plan.io(ar, "wav", (B, L)).copy_(x)
+        plan.io(ar, "grad_wav", (B, L)).copy_(x * 1e-3)
+        sim_run(plan, PHASE_FWD, ar)
+        sim_run(plan, PHASE_BWD, ar)
+        outs.append((plan.io(ar, "out_wav", (B, L)).clone(), ar[2].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def _check_plan_vs_oracle(mode, loss, SMALL, B, L):
     cfg = DCCRNConfig(masking_mode=mode, **SMALL)
     P = oracle_params(cfg)
