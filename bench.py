@@ -1,11 +1,16 @@
 #!/usr/bin/env python
-"""DCCRN train-step throughput on MI355X (BASELINE.json metric), with roofline and CPU-baseline legs.
+"""Train-step throughput on MI355X (BASELINE.json metric), with roofline and CPU-baseline legs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = forward + SI-SNR loss + backward + fused Adam (+ RCCL gradient all-reduce when N > 1) on a synthetic batch
-of B = 32 clips of 3 s @ 16 kHz per GPU that is already resident in HBM.  Weak scaling: per-GPU batch fixed.
+One "step" = forward + SI-SNR loss + backward + fused Adam (+ RCCL gradient all-reduce when N > 1) on a synthetic batch of
+B = 32 clips of 3 s @ 16 kHz per GPU that is already resident in HBM (BASELINE configs[1]).  Weak scaling: per-GPU batch fixed.
+`--model dccrn_large` (configs[4]: 2x channels, rnn_units 512) and `--model fullsubnet` (configs[2], B = 64) print the same
+line for the other single-GPU configurations; `--batch 64` is the batch size of the north_star sentence.
+
+Order of the run (N = 1): the bounded CPU baseline first, then warm-up, the timed region, and the roofline leg, so that the GPU
+is busy for the last seconds of the process.
 """
 import argparse
 import json
@@ -19,16 +24,20 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI355X_MICROARCH.md): fp32 / bf16
-KIND_RUNGEMM, KIND_WGRAD = 1, 2
+PEAK_HBM_GBS = 8000.0
+K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
+F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 32; fullsubnet 64)")
     ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--model", default="dccrn", choices=["dccrn", "dccrn_large", "fullsubnet"])
     ap.add_argument("--dtype", default=os.environ.get("SEFD_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -42,82 +51,121 @@ def make_batch(B, L, rank, device):
     return noisy.to(device), clean.to(device)
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel class from the committed PMC summary (tools/pmc_traffic.py over separate
+def pmc_traffic(kernel_prefixes):
+    """HBM bytes per launch of a kernel class from the committed PMC summary (tools/pmc_traffic.py over separate
     `rocprofv3 --pmc TCC_EA0_RDREQ_sum ...` / `... WRREQ_sum` passes of this same command; reads x 64 B x 2 per the gfx950
-    note in MI355X_MICROARCH.md, writes x 64 B).  None when no summary matches this build."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    note in MI355X_MICROARCH.md, writes x 64 B).  None when the summary is missing or was taken with other kernels than the
+    ones this build launches (every prefix must appear in it)."""
+    if not os.path.exists(PMC_SUMMARY):
         return None
     try:
-        summ = json.load(open(path))
+        summ = json.load(open(PMC_SUMMARY))
     except Exception:
         return None
-    want = ("rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float") if key[0] == "rungemm" else ("wgrad_bf16" if key[1] else "wgrad_kernel<float")
     tot, n = 0.0, 0
-    for k, e in summ.items():
-        if k.startswith(want) and "hbm_bytes_per_launch" in e:
+    for want in kernel_prefixes:
+        hit = [(k, e) for k, e in summ.items() if k.startswith(want) and "hbm_bytes_per_launch" in e]
+        if not hit:
+            return None
+        for k, e in hit:
             ln = e.get("launches_TCC_EA0_RDREQ_sum", 1)
             tot += e["hbm_bytes_per_launch"] * ln
             n += ln
     return round(tot / n) if n else None
 
 
-def roofline(model, rt):
-    """Time every MFMA GEMM launch of one step individually (HIP events on the launch stream) and aggregate the
-    dominant kernel class: algorithmic FLOPs (2*M*N*K with the true, unpadded N and K) / measured duration."""
+def roofline(plan, arenas):
+    """Every MFMA GEMM, LSTM recurrence and STFT launch of one step is timed with HIP events on the launch stream while the
+    whole phase runs in program order on that ONE stream (each op sees the cache state its predecessors left; the two-stream
+    overlap of the real step is off, so these are per-kernel rates, not a decomposition of ms_per_step).
+    achieved = algorithmic FLOPs (2*M*N*K, true unpadded N and K; sefd_plan_op_info) / measured duration."""
     from sefd_amd.plan import PHASE_BWD, PHASE_FWD
-    plan = rt.plan
     stream = torch.cuda.current_stream().cuda_stream
     agg = {}
     for phase in (PHASE_FWD, PHASE_BWD):
-        for i in range(plan.num_ops(phase)):
-            info = plan.op_info(phase, i)
-            if info["kind"] not in (KIND_RUNGEMM, KIND_WGRAD):
-                continue
-            key = ("rungemm" if info["kind"] == KIND_RUNGEMM else "wgrad", info["dtype"])
-            reps = 3
-            plan.run(phase, rt.arenas, stream, i, i + 1)            # warm
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                plan.run(phase, rt.arenas, stream, i, i + 1)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            a = agg.setdefault(key, dict(flops=0, ms=0.0, launches=0))
+        n = plan.num_ops(phase)
+        infos = [plan.op_info(phase, i) for i in range(n)]
+        timed = [i for i in range(n) if infos[i]["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT)]
+        acc = {i: 0.0 for i in timed}
+        reps = 3
+        for rep in range(reps + 1):                                  # first pass warms
+            cur = 0
+            evs = []
+            for i in timed:
+                if i > cur:
+                    plan.run(phase, arenas, stream, cur, i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                plan.run(phase, arenas, stream, i, i + 1)
+                e1.record()
+                evs.append((i, e0, e1))
+                cur = i + 1
+            if cur < n:
+                plan.run(phase, arenas, stream, cur, n)
+            torch.cuda.synchronize()
+            if rep:
+                for i, e0, e1 in evs:
+                    acc[i] += e0.elapsed_time(e1) / reps
+        for i in timed:
+            info = infos[i]
+            k = info["kind"]
+            if k == K_RUNGEMM:
+                key = ("cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
+            elif k == K_WGRAD:
+                key = ("wgrad", info["dtype"])
+            elif k in (K_LSTM_FWD, K_LSTM_BWD):
+                key = ("lstm_gate_gemm", info["dtype"])
+            else:
+                key = ("stft_fft" if k == K_STFT else "istft_fft", 0)
+            a = agg.setdefault(key, dict(flops=0, bytes=0, ms=0.0, launches=0))
             a["flops"] += info["flops"]
-            a["ms"] += ms
+            a["bytes"] += info["bytes"]
+            a["ms"] += acc[i]
             a["launches"] += 1
-    key = max(agg, key=lambda k: agg[k]["ms"])
+    detail = {}
+    for (name, dt), v in agg.items():
+        label = f"{name}_{'bf16' if dt else 'f32'}" if name not in ("stft_fft", "istft_fft") else name
+        if name in ("stft_fft", "istft_fft"):
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
+            detail[label] = dict(bound="hbm", gb_s=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4), ms=round(v["ms"], 4), launches=v["launches"],
+                                 bytes_per_launch=int(v["bytes"] / max(v["launches"], 1)))
+        else:
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            detail[label] = dict(bound="mfma", tflops=round(tf, 2), frac=round(tf / PEAK_TFLOPS[dt], 4), ms=round(v["ms"], 3), launches=v["launches"])
+    gemm_keys = [k for k in agg if k[0] in ("rungemm", "cgemm256", "wgrad")]
+    key = max(gemm_keys, key=lambda k: agg[k]["ms"])
     a = agg[key]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[key[1]]
-    detail = {f"{k[0]}_{'bf16' if k[1] else 'f32'}": dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms=round(v["ms"], 3),
-                                                           launches=v["launches"]) for k, v in agg.items()}
-    return dict(bound="mfma", kernel=f"{key[0]}_kernel<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak,
-                unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=pmc_traffic(key), launches_per_step=a["launches"],
-                avg_launch_ms=round(a["ms"] / a["launches"], 4), kernels=detail)
+    prefixes = {"rungemm": ["void sefd::rungemm_kernel<sefd::bf16_t" if key[1] else "void sefd::rungemm_kernel<float"],
+                "cgemm256": ["sefd::cgemm256_kernel"], "wgrad": ["void sefd::wgrad_bf16" if key[1] else "void sefd::wgrad_kernel<float"]}[key[0]]
+    return dict(bound="mfma", kernel=f"{key[0]}<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                frac=round(achieved / peak, 4), traffic=pmc_traffic(prefixes), launches_per_step=a["launches"],
+                avg_launch_ms=round(a["ms"] / a["launches"], 4),
+                timing="per-launch HIP events, whole phase in program order on one stream (no two-stream overlap)", kernels=detail)
 
 
 def cpu_baseline(L, kn, ru):
-    """The oracle (a port of the reference's CPU PyTorch step) on this host's cores, bounded sample."""
+    """The oracle (a port of the reference's CPU PyTorch step, parity-pinned to goldens captured from the real reference) on
+    this host's cores; bounded sample.  profiles/r02_reference_cpu_timing.json holds the REAL reference timed in the build
+    container with the same protocol (B = 4: reference 1.51 utt/s, this port 1.47 utt/s on 8 cores)."""
     from oracle.dccrn import DCCRNConfig, dccrn_state_shapes
     from oracle.step import dccrn_train_step
     from oracle.weights import formula_state_dict
-    Bc = 2
+    Bc, nsteps = 4, 5
     cfgo = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode="C")
     P = formula_state_dict(dccrn_state_shapes(cfgo))
     x, y = make_batch(Bc, L, 0, "cpu")
     dccrn_train_step(P, cfgo, x, y, loss_kind="SI-SNR")          # warm-up
     ts = []
-    for _ in range(2):
+    for _ in range(nsteps):
         t0 = time.time()
         dccrn_train_step(P, cfgo, x, y, loss_kind="SI-SNR")
         ts.append(time.time() - t0)
     med = sorted(ts)[len(ts) // 2]
     return dict(value=round(Bc / med, 3), unit="utt/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + 2 timed steps (median {med:.2f} s/step), fp32")
+                sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + {nsteps} timed steps "
+                       f"(median {med:.2f} s/step, min {min(ts):.2f}), fp32")
 
 
 def main():
@@ -134,13 +182,28 @@ def main():
     from sefd_amd import config as cfg, models
     from sefd_amd.ddp import GradientExchange
     from sefd_amd.optim import Adam
-    kn, ru = (32, 64, 128, 256, 256, 256), 256
-    cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.act_dtype = list(kn), "C", "SI-SNR", args.dtype
+    L = int(args.seconds * 16000)
+    large = args.model == "dccrn_large"
+    kn, ru = ((64, 128, 256, 512, 512, 512), 512) if large else ((32, 64, 128, 256, 256, 256), 256)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "dccrn":
+        cpu = cpu_baseline(L, kn, ru)                    # first: the GPU legs then run back to back until the process ends
     torch.manual_seed(0)
-    model = models.DCCRN(rnn_units=ru, masking_mode="C").to(dev).train()
+    if args.model == "fullsubnet":
+        cfg.loss, cfg.act_dtype = "MSE", args.dtype
+        B = args.batch or 64
+        model = models.FullSubNet().to(dev).train()
+        workload = f"FullSubNet (LSTM) cIRM target, MSE, fwd+bwd+Adam incl. the two torch.stft front ends, B={B}/GPU x {args.seconds:g}s@16kHz clips (BASELINE configs[2])"
+        metric = "train utts/sec (3s@16kHz) FullSubNet"
+    else:
+        cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.act_dtype = list(kn), "C", "SI-SNR", args.dtype
+        B = args.batch or 32
+        model = models.DCCRN(rnn_units=ru, masking_mode="C").to(dev).train()
+        workload = (f"DCCRN{'-large (2x channels, rnn_units 512; BASELINE configs[4] per-GPU shard)' if large else ''} mask C, SI-SNR, fwd+bwd+Adam, "
+                    f"B={B}/GPU x {args.seconds:g}s@16kHz clips" + ("" if large else " (BASELINE configs[1])"))
+        metric = "train utts/sec (3s@16kHz) DCCRN" + ("-large" if large else "")
     opt = Adam(model.parameters(), lr=1e-3)
     ex = GradientExchange() if world > 1 else None
-    B, L = args.batch, int(args.seconds * 16000)
     x, y = make_batch(B, L, rank, dev)
 
     def barrier():
@@ -157,25 +220,42 @@ def main():
         loss = model.train_step(x, y, opt, exchange=ex)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev)
+    mine = torch.tensor([dt], device=dev)
+    tmax = mine.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        per_rank = [torch.zeros(1, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank_ms = [round(float(t) / args.steps * 1e3, 3) for t in per_rank]
+    else:
+        per_rank_ms = [round(dt / args.steps * 1e3, 3)]
     dt = float(tmax)
     lossv = float(loss)
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        out = {"metric": "train utts/sec (3s@16kHz) DCCRN", "value": round(world * B * args.steps / dt, 2), "unit": "utt/s",
+        out = {"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": "utt/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-               "config": {"workload": f"DCCRN mask C, SI-SNR, fwd+bwd+Adam, B={B}/GPU x {args.seconds:g}s@16kHz clips (BASELINE configs[1])",
-                          "global_batch": world * B, "parallelism": f"dp{world}", "bn": "per-rank statistics"},
+               "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "bn": "per-rank statistics",
+                          "collective": (f"RCCL world {dist.get_world_size()}, flat fp32 gradient all-reduce in 2 buckets (decoder+LSTM under the encoder backward)"
+                                         if world > 1 else "none"),
+                          "per_rank_ms": per_rank_ms},
                "final_loss": round(lossv, 5)}
         if not args.no_roofline:
-            rt = next(iter(model._runtimes.values()))
-            out["roofline"] = roofline(model, rt)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, kn, ru)
+            if args.model == "fullsubnet":
+                plan, arenas = next(v for k, v in model._runtimes.items() if k[0] == "fsn")
+            else:
+                rt = next(v for k, v in model._runtimes.items() if isinstance(k[0], int))
+                plan, arenas = rt.plan, rt.arenas
+            out["roofline"] = roofline(plan, arenas)
+            info = [plan.op_info(ph, i) for ph in (0, 1) for i in range(plan.num_ops(ph))]
+            mf = sum(o["flops"] for o in info if o["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD))
+            peak = PEAK_TFLOPS[1 if args.dtype == "bf16" else 0]
+            out["roofline"]["step"] = dict(mfma_tflops=round(mf / (ms * 1e-3) / 1e12, 1), frac=round(mf / (ms * 1e-3) / 1e12 / peak, 4),
+                                           note="all MFMA FLOPs of the step / ms_per_step (two-stream overlap on)")
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -13,7 +13,7 @@ class ModelConfig(C.Structure):
                 ("n_layers", C.c_int32), ("kernel_num", C.c_int32 * 8),
                 ("rnn_layers", C.c_int32), ("rnn_units", C.c_int32), ("mask_mode", C.c_int32),
                 ("lstm_complex", C.c_int32), ("skip", C.c_int32), ("act_dtype", C.c_int32),
-                ("kernel_size", C.c_int32), ("training", C.c_int32), ("bn_world", C.c_int32)]
+                ("kernel_size", C.c_int32), ("training", C.c_int32), ("bn_world", C.c_int32), ("grad_buckets", C.c_int32)]
 
 
 _lib = None
@@ -51,6 +51,8 @@ def lib():
         "sefd_op_size": (i32, []),
         "sefd_plan_op_info": (i32, [vp, i32, i32, C.POINTER(i64)]),
         "sefd_plan_run": (i32, [vp, i32, i32, i32, C.POINTER(vp), vp]),
+        "sefd_plan_grad_bucket": (i32, [vp, C.POINTER(i32), C.POINTER(i64)]),
+        "sefd_plan_run_cb": (i32, [vp, i32, C.POINTER(vp), vp, i32, vp, vp]),
         "sefd_loss_ws_floats": (i64, [i32]),
         "sefd_loss_forward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp]),
         "sefd_loss_backward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp]),
@@ -72,5 +74,6 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_num_params", "sefd_plan_param_name", "sefd_plan_param_offset", "sefd_plan_param_numel",
             "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
+            "sefd_plan_grad_bucket", "sefd_plan_run_cb",
             "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets",
             "sefd_adam_step"]

@@ -80,15 +80,46 @@ int32_t sefd_plan_op_info(const sefd_plan* h, int phase, int i, int64_t* o) {
     const RunGemm& g = op.g;
     int64_t K = 0;
     for (int s = 0; s < g.nseg; ++s) K += g.seg[s].len;
-    o[2] = g.M; o[3] = g.N; o[4] = K; o[5] = g.xdt;
+    o[2] = g.M; o[3] = g.N; o[4] = K; o[5] = g.xdt | ((int64_t)g.flags << 8);        // low byte: operand dtype; above: RunGemm flags
     o[6] = 2 * (int64_t)g.M * g.N * K;                                     // algorithmic flops (true K, true N)
     // algorithmic bytes: every source element once is not well defined for overlapping runs; report A-row + y + w traffic
     o[7] = (int64_t)g.M * g.N * esize(g.ydt) + (int64_t)g.N * K * esize(g.xdt);
+  } else if (op.kind == OP_LSTM_FWD || op.kind == OP_LSTM_BWD) {            // recurrent gate GEMM: rows x 4H x H per launch
+    const LstmRec& r = op.lstm;
+    const int64_t steps = op.kind == OP_LSTM_FWD && r.t1 > 0 ? r.t1 - r.t0 : r.T;
+    const int64_t rows = (int64_t)r.G * r.B * steps;
+    o[2] = rows; o[3] = 4 * r.H; o[4] = r.H; o[5] = r.hdt;
+    o[6] = 2 * rows * 4 * r.H * r.H;
+    o[7] = rows * (4 * r.H * 4 + 4 * r.H * 4 + r.H * (4 + esize(r.hdt)));   // gx read, gates written, c and h written
+  } else if (op.kind == OP_STFT_FFT) {                                     // HBM-bound: samples read + half spectra written
+    const StftFft& f = op.fft;
+    o[2] = (int64_t)f.B * f.T; o[3] = 257; o[4] = 512;
+    o[7] = (int64_t)f.B * f.L * 4 + (int64_t)f.B * f.T * 258 * 8;
+  } else if (op.kind == OP_ISTFT_FFT) {
+    o[2] = op.ifft.nframes; o[3] = op.ifft.W; o[4] = 512;
+    o[7] = op.ifft.nframes * (258 * 8 + (int64_t)op.ifft.W * 4);
   }
   return 0;
 }
 
+int32_t sefd_plan_grad_bucket(const sefd_plan* h, int32_t* op, int64_t* elem) {
+  if (!h || h->p->bucket_op < 0) return -1;
+  *op = h->p->bucket_op; *elem = h->p->bucket_elem;
+  return 0;
+}
+
+static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx);
+
 int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream) {
+  return plan_run(h, phase, first, last, arenas, stream, -1, nullptr, nullptr);
+}
+int32_t sefd_plan_run_cb(const sefd_plan* h, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx) {
+  return plan_run(h, phase, 0, -1, arenas, stream, at, cb, ctx);
+}
+
+}  // extern "C"
+
+static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx) {
   if (!h || !h->p->error.empty()) return -1;
   const std::vector<Op>& ops = phase == 0 ? h->p->fwd : h->p->bwd;
   if (first < 0) first = 0;
@@ -113,7 +144,7 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
     two_lane = any2 || (any1 && lstm);
   }
   if (!two_lane) {                                       // program order on one stream is always a valid schedule
-    for (int i = first; i < last; ++i) launch(ops[i], st);
+    for (int i = first; i < last; ++i) { launch(ops[i], st); if (i == at && cb) cb(ctx); }
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (!h->side) {
@@ -154,12 +185,12 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
     }
     if (op.join || op.kind == OP_UNPACK) join();         // UNPACK gathers every gradient partial: needs the side lane's results
     launch(op, st);
+    if (i == at && cb) cb(ctx);                          // e.g. the first gradient bucket is complete: the caller starts its all-reduce
   }
   join();
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-}  // extern "C"
 
 // =============================================================================================== losses
 // Per-utterance inner products in one pass over est/tgt (HBM-bound: 2 x 4 x L bytes per utterance), then a

@@ -258,28 +258,37 @@ struct Builder {
     }
   }
 
+  int64_t unpack_lo = 0;                                   // flat gradient elements below this are still to be unpacked
+  int64_t unpack_hi = -1;                                  // (set by unpack_range: elements [unpack_hi, end) are already done)
+  // UNPACK of the flat gradient elements [lo, hi): every weight gradient GEMM that contributes to them must have been planned.
+  // The partial-sum base is not known yet (finish_unpack allocates it): recorded as a fix-up.
+  void unpack_range(std::vector<Op>& ops, int64_t lo, int64_t hi, int tag) {
+    const int64_t n = hi - lo;
+    std::vector<int32_t> start(n + 1, 0), ent;
+    for (int64_t j = 0; j < n; ++j) {
+      start[j] = (int32_t)ent.size();
+      for (auto e : inv[lo + j]) ent.push_back(e);
+    }
+    start[n] = (int32_t)ent.size();
+    if (ent.empty()) ent.push_back(0);
+    Op& op = push(ops, OP_UNPACK, tag);
+    op.unpack.start = cst(start.data(), (int64_t)start.size() * 4);
+    op.unpack.ent = cst(ent.data(), (int64_t)ent.size() * 4);
+    op.unpack.part = none();
+    op.unpack.dst = mk(A_GRAD, lo * 4);
+    op.unpack.n = n;
+    op.unpack.sstride = 0;
+    op.unpack.nsplit = 1;
+    fixes.push_back(Fix{(int)ops.size() - 1, 0, 1});
+  }
   void finish_unpack(std::vector<Op>& ops) {
+    const int64_t n = unpack_hi >= 0 ? unpack_hi : (int64_t)inv.size();
+    unpack_range(ops, 0, n, 999);
     Ptr base = ws("gradpart", std::max<int64_t>(gp_off, 1), DT_F32);
     for (auto& f : fixes) {
       Ptr p = mk(A_WS, base.off + f.rel * 4);
       if (f.which == 0) ops[f.op].g.w = p; else ops[f.op].unpack.part = p;
     }
-    const int64_t n = (int64_t)inv.size();
-    std::vector<int32_t> start(n + 1, 0), ent;
-    for (int64_t j = 0; j < n; ++j) {
-      start[j] = (int32_t)ent.size();
-      for (auto e : inv[j]) ent.push_back(e);
-    }
-    start[n] = (int32_t)ent.size();
-    if (ent.empty()) ent.push_back(0);
-    Op& op = push(ops, OP_UNPACK, 999);
-    op.unpack.start = cst(start.data(), (int64_t)start.size() * 4);
-    op.unpack.ent = cst(ent.data(), (int64_t)ent.size() * 4);
-    op.unpack.part = base;
-    op.unpack.dst = mk(A_GRAD, 0);
-    op.unpack.n = n;
-    op.unpack.sstride = 0;
-    op.unpack.nsplit = 1;
   }
 };
 
@@ -1371,6 +1380,15 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       }
       if (l > 0) dhc_next = dx_full;
     }
+    // ---- data-parallel overlap: the gradients of decoder + LSTM (flat range [decoder.0 ..., end)) are complete here - every
+    // weight gradient GEMM and BatchNorm parameter gradient that writes them has been planned above.  Their UNPACK goes here, so
+    // a caller can start their all-reduce while the encoder backward still runs (sefd_plan_grad_bucket / sefd_plan_run_cb).
+    if (cfg.grad_buckets >= 2) {
+      const int64_t lo = b.par("decoder.0.0.real_conv.weight").off;
+      b.unpack_range(R, lo, nparam, 998);
+      b.unpack_hi = lo;
+      P->bucket_elem = lo;                                   // (the op index is looked up after the op list is final)
+    }
     // ---- encoder backward
     for (int i = n - 1; i >= 0; --i) {
       const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
@@ -1408,6 +1426,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   }
 
   finalize_rungemms(b, P);
+  for (size_t k = 0; k < P->bwd.size(); ++k)
+    if (P->bwd[k].kind == OP_UNPACK && P->bwd[k].tag == 998) P->bucket_op = (int32_t)k;
   P->arena_bytes[A_WS] = b.ws_off;
   P->arena_bytes[A_PARAM] = nparam * 4;
   P->arena_bytes[A_GRAD] = nparam * 4;

@@ -22,6 +22,7 @@ struct ModelConfig {
   int32_t kernel_size;      // 5
   int32_t training;         // 1: BatchNorm batch statistics + running update ; 0: eval (running stats)
   int32_t bn_world;         // > 1: SyncBN over that many ranks (sync points, counts scaled)
+  int32_t grad_buckets;     // 2: decoder + LSTM gradients unpacked before the encoder backward (DDP overlap)
 };
 
 struct ParamInfo {
@@ -48,6 +49,8 @@ struct Plan {
   std::vector<char> consts;                    // host image of A_CONST
   std::vector<Op> fwd, bwd;
   std::vector<SyncPoint> syncs;                // SyncBN all-reduce points, in execution order per phase
+  int32_t bucket_op = -1;                      // grad_buckets == 2: backward op index of the first bucket's UNPACK
+  int64_t bucket_elem = 0;                     //                    first flat gradient element of that bucket
   std::string error;
 };
 

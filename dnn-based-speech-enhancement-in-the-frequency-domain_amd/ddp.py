@@ -5,9 +5,10 @@ The reference has no distributed code at all; this is a new capab
   * the gradient already lives in ONE contiguous fp32 arena (14.7 MB for default DCCRN), so the exchange is one large
     all-reduce (or a few caller-chosen buckets) instead of hundreds of per-tensor ones (xGMI is point-to-point, per-link
     bound: few, large messages);
-  * it runs on a side stream that waits for the backward phase and that Adam waits for.  Today the whole arena becomes
-    valid at the UNPACK op that ends the backward phase, so the exchange (about 0.1-0.4 ms for 14.7 MB on 8 GPUs) is NOT
-    yet overlapped with the encoder backward; splitting UNPACK per bucket (decoder + LSTM first) is the planned next step;
+  * two buckets in reverse layer order: DDP plans (`grad_buckets=2`) unpack the gradients of decoder + LSTM (74 % of the
+    arena) BEFORE the encoder backward; `train_step` starts their all-reduce on the communication stream at that op
+    (`Plan.run_cb`), so it rides under the encoder's dgrad / BatchNorm / wgrad kernels; the encoder bucket follows at the end of
+    the phase and Adam waits for both;
   * averaging (1/world) is folded into the fused Adam kernel (grad_scale), no extra pass.
 BatchNorm statistics stay per rank by default (standard DDP semantics), which is what the throughput numbers
 use; `GradientExchange(sync_bn=True)` switches `train_step` to SyncBN plans (statistics over all ranks: N ranks x B/N
@@ -27,6 +28,24 @@ class GradientExchange:
     @property
     def grad_scale(self):
         return 1.0 / self.world
+
+    def begin(self, part: torch.Tensor):
+        """Start the sum all-reduce of `part` (a slice of the flat gradient) behind everything enqueued so far on the current
+        stream, on the communication stream; `finish()` makes the current stream wait for it."""
+        if self.world == 1:
+            return
+        if part.is_cuda:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=part.device)
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def finish(self, part: torch.Tensor):
+        if self.world > 1 and part.is_cuda and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
     def all_reduce(self, flat_grad: torch.Tensor, bounds=None):
         """Sum-all-reduce `flat_grad` in place.  `bounds` = optional list of (lo, hi) element ranges (buckets)."""

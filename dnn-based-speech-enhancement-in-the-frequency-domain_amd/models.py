@@ -213,7 +213,7 @@ class _SefdModule(nn.Module):
     def _runtime(self, B, L, device):
         if not self._flat_ok(device):
             self._flatten(device)
-        key = (B, L, bool(self.training), self.masking_mode, self.act_dtype, getattr(self, "_bn_world", 1))
+        key = (B, L, bool(self.training), self.masking_mode, self.act_dtype, getattr(self, "_bn_world", 1), getattr(self, "_grad_buckets", 1))
         rt = self._runtimes.get(key)
         if rt is None:
             rt = _Runtime(self, B, L, bool(self.training), device)
@@ -257,6 +257,8 @@ class _SefdModule(nn.Module):
         # single-process big batch).  Default: per-rank statistics, whole phases (two-lane backward).
         sync = exchange is not None and exchange.world > 1 and getattr(exchange, "sync_bn", False)
         self._bn_world = exchange.world if sync else 1
+        # data parallel: plans with two gradient buckets (decoder + LSTM complete before the encoder backward, see ddp.py)
+        self._grad_buckets = 2 if (exchange is not None and exchange.world > 1 and not sync) else 1
         rt = self._runtime(B, L, inputs.device)
         optimizer.bind(self)
         self._flat_nbt += 1
@@ -272,12 +274,20 @@ class _SefdModule(nn.Module):
         rt.g_real.zero_()
         rt.g_imag.zero_()
         tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)
+        bucket = rt.plan.grad_bucket() if self._grad_buckets == 2 else None
         if sync:
             rt.plan.run_synced(PHASE_BWD, rt.arenas, stream, exchange.all_reduce_stats)
+        elif bucket is not None:
+            op, lo = bucket                                  # decoder + LSTM gradients are final at op `op`: their all-reduce starts
+            rt.plan.run_cb(PHASE_BWD, rt.arenas, stream, op, lambda: exchange.begin(self._flat_grad[lo:]))   # under the encoder backward
         else:
             rt.run(PHASE_BWD)
         if exchange is not None and exchange.world > 1:      # DDP: sum gradients over ranks (RCCL), average inside Adam
-            exchange.all_reduce(self._flat_grad)
+            if bucket is not None:
+                exchange.begin(self._flat_grad[:bucket[1]])
+                exchange.finish(self._flat_grad)
+            else:
+                exchange.all_reduce(self._flat_grad)
             optimizer.grad_scale = exchange.grad_scale
         optimizer.step_flat()
         return loss
@@ -342,7 +352,7 @@ class DCCRN(_SefdModule):
         return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=self.hidden_layers, rnn_units=self.rnn_units,
                     win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, masking_mode=self.masking_mode,
                     lstm=self._lstm_kind, skip_type=self._skip, act_dtype=self.act_dtype, training=training, model="DCCRN",
-                    bn_world=getattr(self, "_bn_world", 1))
+                    bn_world=getattr(self, "_bn_world", 1), grad_buckets=getattr(self, "_grad_buckets", 1))
 
     # ---- reference surface ----------------------------------------------------------------------------------
     def forward(self, inputs, targets=0):

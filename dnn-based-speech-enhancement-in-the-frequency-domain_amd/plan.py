@@ -16,7 +16,7 @@ DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 class Plan:
     def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
                  win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
-                 kernel_size=5, training=True, model="DCCRN", fsn=None, bn_world=1):
+                 kernel_size=5, training=True, model="DCCRN", fsn=None, bn_world=1, grad_buckets=1):
         self.lib = _lib.lib()
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
@@ -44,6 +44,7 @@ class Plan:
         cfg.kernel_size = kernel_size
         cfg.training = 1 if training else 0
         cfg.bn_world = int(bn_world)
+        cfg.grad_buckets = int(grad_buckets)
         self.cfg = cfg
         self.h = self.lib.sefd_plan_create(C.byref(cfg))
         err = self.lib.sefd_plan_error(self.h).decode()
@@ -114,7 +115,8 @@ class Plan:
         o = (C.c_int64 * 8)()
         if self.lib.sefd_plan_op_info(self.h, phase, i, o) != 0:
             raise IndexError(i)
-        return dict(kind=int(o[0]), tag=int(o[1]), M=int(o[2]), N=int(o[3]), K=int(o[4]), dtype=int(o[5]), flops=int(o[6]), bytes=int(o[7]))
+        return dict(kind=int(o[0]), tag=int(o[1]), M=int(o[2]), N=int(o[3]), K=int(o[4]), dtype=int(o[5]) & 0xff, flags=int(o[5]) >> 8,
+                    flops=int(o[6]), bytes=int(o[7]))
 
     def buffer(self, name):
         a, off, nb, dt = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
@@ -154,6 +156,21 @@ class Plan:
 
     def io(self, arenas, name, shape):
         return self.view(arenas, "io." + name).view(*shape)
+
+    def grad_bucket(self):
+        """(backward op index, first flat element) of the gradient bucket that is complete before the encoder backward, or None."""
+        op, el = C.c_int32(), C.c_int64()
+        if self.lib.sefd_plan_grad_bucket(self.h, C.byref(op), C.byref(el)) != 0:
+            return None
+        return op.value, el.value
+
+    def run_cb(self, phase, arenas, stream, at, fn):
+        """Whole phase (two-lane schedule); `fn()` runs on the host right after op `at` has been enqueued."""
+        ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
+        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _ctx: fn())
+        rc = self.lib.sefd_plan_run_cb(self.h, phase, ptrs, C.c_void_p(stream), at, cb, None)
+        if rc != 0:
+            raise RuntimeError(f"sefd_plan_run_cb failed ({rc})")
 
     def run(self, phase, arenas, stream=0, first=0, last=-1):
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])

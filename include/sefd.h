@@ -39,6 +39,10 @@ typedef struct sefd_model_config {
                              exposes sync points (sefd_plan_num_syncs / sefd_plan_sync) where the caller sum-all-reduces a small
                              statistics buffer between two op ranges; counts are scaled by N.  Makes N ranks x B/N utterances
                              equal to the reference's single process with batch B */
+  int32_t grad_buckets;   /* 0/1: one UNPACK at the end of the backward phase.  2 (DCCRN): the gradients of decoder + LSTM (the flat
+                             range [sefd_plan_grad_bucket elem, end)) are final at op `bucket op` of the backward phase, BEFORE the encoder
+                             backward: a data-parallel caller starts their all-reduce there (sefd_plan_run_cb) and it rides under the
+                             encoder's dgrad / wgrad kernels; the encoder range follows at the end of the phase (reverse layer order) */
 } sefd_model_config;
 
 enum { SEFD_ARENA_WS = 0, SEFD_ARENA_PARAM = 1, SEFD_ARENA_GRAD = 2, SEFD_ARENA_STATE = 3, SEFD_ARENA_CONST = 4, SEFD_ARENA_IO = 5,
@@ -80,6 +84,12 @@ int32_t sefd_plan_op_info(const sefd_plan* p, int phase, int i, int64_t* out8);
  * Forward  = DCCRN.forward  (models.py:176-284): IO.wav -> IO.out_wav, IO.out_real, IO.out_imag.
  * Backward = autograd of it: IO.grad_wav / grad_real / grad_imag -> A_GRAD (all parameters). */
 int32_t sefd_plan_run(const sefd_plan* p, int phase, int first, int last, void* const* arenas, void* stream);
+/* grad_buckets == 2: index (backward phase) of the UNPACK op that completes the first gradient bucket and the first flat element
+   of that bucket; returns -1 when the plan has a single bucket. */
+int32_t sefd_plan_grad_bucket(const sefd_plan* p, int32_t* op, int64_t* elem);
+/* Whole phase as sefd_plan_run(first = 0, last = -1), and `cb(ctx)` is called on the host right after op `at` has been enqueued on
+   `stream` (everything up to and including that op is ordered before whatever the callback enqueues behind an event on `stream`). */
+int32_t sefd_plan_run_cb(const sefd_plan* p, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx);
 
 /* ---- losses (tools_for_loss.py:17-94, models.py:315-323) ---------------------------------------
  * est, tgt: fp32 [B][L] device.  ws: fp32 device scratch of sefd_loss_ws_floats(B) floats.

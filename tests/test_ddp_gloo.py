@@ -168,3 +168,76 @@ def test_world2_syncbn_equals_single_process_big_batch():
     r0 = res[0]
     assert r0["wav"] < 2e-5 and r0["state"] < 2e-5, r0
     assert r0["grad"] < 2e-4, r0
+
+
+# ------------------------------------------------------------------------------------------------ bucketed exchange (DDP overlap)
+def _bucket_worker(rank, world, port, q):
+    """Each rank interprets its shard's DCCRN plan on the host simulator.  grad_buckets=2: the decoder + LSTM range of the flat
+    gradient is complete (and all-reduced) at the plan's bucket op, before the encoder backward has run; the encoder range at the
+    end.  Must equal the single-bucket plan followed by one flat all-reduce, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, sim_run
+    from sefd_amd.ddp import GradientExchange
+    from sefd_amd.plan import ARENA_GRAD
+    from oracle.dccrn import DCCRNConfig, dccrn_state_shapes
+    from oracle.weights import formula_state_dict
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = GradientExchange()
+        kw = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128)
+        P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode="C", **kw)))
+        x, _ = make_signals(world, 3000)
+        torch.manual_seed(5)
+        gw = torch.randn(world, 3000) * 1e-3
+        res = {}
+        for nb in (1, 2):
+            plan = Plan(1, 3000, masking_mode="C", grad_buckets=nb, **kw)
+            ar = plan.alloc_arenas("cpu")
+            fill_params(plan, ar, P)
+            plan.io(ar, "wav", (1, 3000)).copy_(x[rank:rank + 1])
+            sim_run(plan, PHASE_FWD, ar)
+            plan.io(ar, "grad_wav", (1, 3000)).copy_(gw[rank:rank + 1])
+            flat = ar[ARENA_GRAD]
+            if nb == 1:
+                assert plan.grad_bucket() is None
+                sim_run(plan, PHASE_BWD, ar)
+                ex.all_reduce(flat)
+            else:
+                op, lo = plan.grad_bucket()
+                names = list(plan.params.keys())
+                first = names.index("decoder.0.0.real_conv.weight")
+                assert lo == plan.params["decoder.0.0.real_conv.weight"][0] and 0 < lo < flat.numel()
+                assert all(n.startswith("encoder.") for n in names[:first]) and not any(n.startswith("encoder.") for n in names[first:])
+                assert 0 < op < plan.num_ops(PHASE_BWD) - 1          # reverse layer order: decoder + LSTM first, encoder last
+                flat.fill_(float("nan"))
+                sim_run(plan, PHASE_BWD, ar, 0, op + 1)
+                assert bool(torch.isfinite(flat[lo:]).all())         # bucket 0 is final here ...
+                enc_w = plan.params["encoder.3.0.real_conv.weight"]
+                assert bool(torch.isnan(flat[enc_w[0]:enc_w[0] + 8]).all())   # ... while the encoder's gradients do not exist yet
+                ex.begin(flat[lo:])
+                sim_run(plan, PHASE_BWD, ar, op + 1, plan.num_ops(PHASE_BWD))
+                ex.begin(flat[:lo])
+                ex.finish(flat)
+            res[nb] = flat.clone()
+        q.put((rank, bool(torch.equal(res[1], res[2])), float(res[2].abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_bucketed_exchange_equals_flat_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(world)]
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][2] > 0               # both ranks hold the same summed gradient
