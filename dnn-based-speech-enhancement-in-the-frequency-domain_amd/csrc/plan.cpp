@@ -446,9 +446,11 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   const int Cl = ch[n];                      // channels entering the LSTM
   for (int i = 1; i <= n; ++i)
     if (ch[i] % 8 != 0 && !(i == 0)) { P->error = "channel counts must be multiples of 8"; return P; }
-  // H <= 128: persistent recurrence kernels (W_hh resident in VGPRs).  Larger H (DCCRN-large: rnn_units 512) does not fit
-  // the register file of one CU: the recurrence becomes one GEMM + one cell launch per time step on the same buffers.
-  const bool stepped = H > 128 || getenv("SEFD_LSTM_STEPPED") != nullptr;
+  // H <= 128: persistent recurrence kernels (W_hh resident in the VGPRs of one CU).  Larger H (DCCRN-large: rnn_units 512):
+  // bf16 mode runs the cluster kernels of lstm_cluster.hip (W_hh spread over H/64 CUs, h handed over in memory every step);
+  // fp32 mode and odd sizes fall back to one GEMM + one cell launch per time step on the same buffers.
+  const bool cluster_ok = adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0;
+  const bool stepped = (H > 128 && !cluster_ok) || getenv("SEFD_LSTM_STEPPED") != nullptr;
   // all weight gradients ride the second stream (after the fork they run next to the encoder's dgrad / BatchNorm chain and
   // fill the tails of its kernels: 14.42 -> 14.30 ms/step); SEFD_LANE_ALL=0 keeps only the decoder's there
   const bool lane_all = !(getenv("SEFD_LANE_ALL") != nullptr && atoi(getenv("SEFD_LANE_ALL")) == 0);

@@ -36,7 +36,10 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 3, 4000, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),
                                                         ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("DCCRN", 1, 2401, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L odd: marks the case that lowers SEFD_CG256_MINM -> wide-tile kernel on every N % 256 == 0 layer
-                                                        ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM: per-step path
+                                                        ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM (H = 256): cluster kernels, one partial row block
+                                                        ("DCCRN", 18, 7000, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),    # the same, two row blocks, T = 71: chunked forward
+                                                        ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 1024, "bf16"),    # H = 512: 8 workgroups per cluster
+                                                        ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "fp32"),     # wide LSTM in fp32: per-step path
                                                         ("DCCRN", 2, 7000, "C", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # T = 71: chunked two-lane LSTM forward
                                                         ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
                                                         ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),

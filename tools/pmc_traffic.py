@@ -29,7 +29,7 @@ def main():
             launches[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
     res = {}
     for k, c in acc.items():
-        if not (k.startswith("rungemm") or k.startswith("wgrad") or k.startswith("lstm") or k.startswith("bn_") or k.startswith("stft") or k.startswith("istft")):
+        if not (k.startswith("cgemm") or k.startswith("rungemm") or k.startswith("wgrad") or k.startswith("lstm") or k.startswith("bn_") or k.startswith("stft") or k.startswith("istft")):
             continue
         e = {}
         for name, tot in c.items():
