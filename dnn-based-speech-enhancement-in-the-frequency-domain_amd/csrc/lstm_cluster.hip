@@ -18,6 +18,7 @@
 // are next in the dispatch queue; every spin is bounded (a latched budget) so a lost block cannot hang the device.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -68,23 +69,36 @@ __device__ __forceinline__ void gather(__amdgpu_buffer_rsrc_t r, uint32_t off0, 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- forward
-template <int H>
-__global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab) {
+// Work of one wave = the linear sequence of tiles (t, mt): frame t, row tile mt (16 sequences) of the workgroup's 16 * MT rows.
+// MT = 1 is the latency-bound case (few sequences, e.g. DCCRN: B <= a few hundred); with thousands of sequences (FullSubNet's
+// sub-band model: B * 257 rows) a workgroup walks MT row tiles per frame, so the hand-off latency of one tile hides behind the
+// work on the others (the gather of the next tile is issued before the MFMAs of this one, template flag PF).
+// Buffers may be batch-major [row][T][..] (DCCRN / CRN) or time-major [T][row][..] (FullSubNet, d.tmajor).
+constexpr int kMaxMT = 8;
+
+template <int H, bool PF>
+__global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT) {
   constexpr int KS = H / 32;
   __shared__ __attribute__((aligned(16))) uint16_t stage[4][16 * 16];
+  __shared__ __attribute__((aligned(16))) float4 cst[4][kMaxMT][64];
   const int T = d.T;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x, b0 = blockIdx.y * 16, g = blockIdx.z;
+  const int j = blockIdx.x, b0 = blockIdx.y * 16 * MT, g = blockIdx.z;
+  const int64_t rstr = d.tmajor ? 1 : T, tstr = d.tmajor ? d.B : 1;       // row / frame strides, in rows
   const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
   const float* gx = reinterpret_cast<const float*>(rp(ab, d.gx)) + d.gx_goff[g];
   const int64_t GBT = (int64_t)d.B * T;
-  uint16_t* hgrp = reinterpret_cast<uint16_t*>(rp(ab, d.h)) + (int64_t)g * GBT * H;       // this group's [B][T][H]
-  float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
-  float* cs = reinterpret_cast<float*>(rp(ab, d.c));
+  uint16_t* hgrp = reinterpret_cast<uint16_t*>(rp(ab, d.h)) + (int64_t)g * GBT * H;
+  float* gates = reinterpret_cast<float*>(rp(ab, d.gates)) + (int64_t)g * GBT * H * 4;
+  float* cs = reinterpret_cast<float*>(rp(ab, d.c)) + (int64_t)g * GBT * H;
   const int ubase = 64 * j + 16 * w;
   const int unit = ubase + (lane & 15);
   const int kq = lane >> 4;
-  const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(hgrp, 0, (uint32_t)(GBT * H * 2), 0x00020000);
+  const int64_t gx_ld = d.gx_ld;
+  const uint32_t hbytes = (uint32_t)((((int64_t)d.B - 1) * rstr + 1) * H * 2);
+  auto hres = [&](int frame) {                   // frame `frame` of every row: row b at byte offset b * rstr * H * 2
+    return __builtin_amdgcn_make_buffer_rsrc(hgrp + (int64_t)frame * tstr * H, 0, hbytes, 0x00020000);
+  };
 
   uint4 wreg[4][KS];
 #pragma unroll
@@ -96,55 +110,85 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
       wreg[q][ks] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
     }
   const int tb = d.t0, te = d.t1 > 0 ? d.t1 : T;
+  const int ntile = (te - tb) * MT;
 
-  bool rvalid[4];
-  int64_t rowbt[4];
+  // cell (r = 0..3) of tile mt: row b0 + 16 mt + 4 kq + r, this lane's unit
+  auto cell_row = [&](int mt, int r, bool& valid) -> int64_t {
+    const int b = b0 + 16 * mt + 4 * kq + r;
+    valid = b < d.B;
+    return valid ? b : 0;                        // rows beyond the batch alias row 0 and are never stored
+  };
+  for (int mt = 0; mt < MT; ++mt) {              // cell state of frame tb - 1
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tb > 0) {
+      float cc[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * kq + r;
-    rvalid[r] = b < d.B;
-    rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
+      for (int r = 0; r < 4; ++r) { bool v; const int64_t b = cell_row(mt, r, v); cc[r] = cs[(b * rstr + (int64_t)(tb - 1) * tstr) * H + unit]; }
+      c0 = make_float4(cc[0], cc[1], cc[2], cc[3]);
+    }
+    cst[w][mt][lane] = c0;
   }
-  float c[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* gxp[4];
-  int64_t so[4];                                 // (g*GBT + row*T + t) * H + unit
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    gxp[r] = gx + (rowbt[r] + tb) * d.gx_ld + gate_col(0, unit);
-    so[r] = ((int64_t)g * GBT + rowbt[r] + tb) * H + unit;
-    if (tb > 0) c[r] = cs[so[r] - H];
-  }
-  // A fragment source: sequence (lane & 15) of the block, inputs 32 ks + 8 kq .. +8 of frame t-1 (rows beyond the batch alias row 0)
-  const int arow = b0 + (lane & 15) < d.B ? b0 + (lane & 15) : 0;
-  uint32_t aoff = (uint32_t)((((int64_t)arow * T + (tb - 1)) * H + 8 * kq) * 2);
-  // h store: the wave's 16 x 16 tile leaves as 32 chunks of 16 bytes (lanes 0..31: sequence lane >> 1, half lane & 1)
   const int srow = lane >> 1, shalf = lane & 1;
-  const bool svalid = lane < 32 && b0 + srow < d.B;
-  uint32_t soff = (uint32_t)((((int64_t)(b0 + srow) * T + tb) * H + ubase + 8 * shalf) * 2);
   uint16_t* stg = &stage[w][0];
   int budget = kSpinBudget;
 
-  const int64_t gx_ld = d.gx_ld;
-  auto load_gx = [&](int t, float4 (&dst)[4]) {
-    const int64_t inc = t < T - 1 ? gx_ld : 0;
+  int pt = tb, pmt = 0;                          // prefetch cursor of the gate pre-activations (two tiles ahead)
+  auto load_gx = [&](float4 (&dst)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { dst[r] = *reinterpret_cast<const float4*>(gxp[r]); gxp[r] += inc; }
+    for (int r = 0; r < 4; ++r) {
+      bool v;
+      const int64_t b = cell_row(pmt, r, v);
+      dst[r] = *reinterpret_cast<const float4*>(gx + (b * rstr + (int64_t)pt * tstr) * gx_ld + gate_col(0, unit));
+    }
+    if (pt < te - 1 || pmt < MT - 1) { if (++pmt == MT) { pmt = 0; ++pt; } }      // the last prefetches re-read the last tile
   };
-  auto step = [&](int t, const float4 (&cur)[4], float4 (&pre)[4]) {
+  auto a_off = [&](int mt) -> uint32_t {         // A fragment of tile mt: sequence lane & 15 of the tile, inputs 8 kq .. (+ 32 ks)
+    const int b = b0 + 16 * mt + (lane & 15);
+    return (uint32_t)(((int64_t)(b < d.B ? b : 0) * rstr * H + 8 * kq) * 2);
+  };
+  u32x4 an[PF ? KS : 1];
+  auto issue_next = [&](int t, int mt) {         // start the gather of the tile after (t, mt), if it has a recurrent term
+    if constexpr (PF) {
+      int nt = t, nmt = mt + 1;
+      if (nmt == MT) { nmt = 0; ++nt; }
+      if (nt < te && nt > 0) {
+        const auto r = hres(nt - 1);
+        const uint32_t o = a_off(nmt);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) an[i] = __builtin_amdgcn_raw_buffer_load_b128(r, o + 64u * i, 0, kSc1);
+      }
+    }
+  };
+  int t = tb, mt = 0;
+  auto tile = [&](const float4 (&cur)[4], float4 (&pre)[4]) {
     f32x4 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { acc[0][r] = cur[r].x; acc[1][r] = cur[r].y; acc[2][r] = cur[r].z; acc[3][r] = cur[r].w; }
-    load_gx(t + 2, pre);
+    load_gx(pre);
     if (t > 0) {
       u32x4 a[KS];
-      gather<KS>(hres, aoff, 64u, a, budget);
+      bool have = false;
+      if constexpr (PF) {
+        if (t > tb || mt > 0) {                  // prefetched by the previous tile: usable if complete
+          uint32_t bad = 0;
+#pragma unroll
+          for (int i = 0; i < KS; ++i) { a[i] = an[i]; bad = unset4(bad, a[i]); }
+          have = !__any((bad & 0x80008000u) != 0);
+        }
+      }
+      if (!have) gather<KS>(hres(t - 1), a_off(mt), 64u, a, budget);
+      issue_next(t, mt);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[ks]), __builtin_bit_cast(bf16x8, wreg[q][ks]), acc[q], 0, 0, 0);
+    } else {
+      issue_next(t, mt);
     }
-    aoff += (uint32_t)(H * 2);
+    const float4 cv = cst[w][mt][lane];
+    const float c[4] = {cv.x, cv.y, cv.z, cv.w};
+    float cnew[4];
 #pragma unroll
     for (int rp2 = 0; rp2 < 4; rp2 += 2) {
       const f32x2 ig = sigmoid2(f32x2{acc[0][rp2], acc[0][rp2 + 1]}), fg = sigmoid2(f32x2{acc[1][rp2], acc[1][rp2 + 1]});
@@ -154,61 +198,72 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int r = rp2 + k;
-        c[r] = cn[k];
+        cnew[r] = cn[k];
         uint16_t hb = f2bf(hv[k]);
         if (hb == 0xffffu) hb = 0x7fc0u;
         stg[(4 * kq + r) * 16 + (lane & 15)] = hb;
-        if (rvalid[r]) {
-          *reinterpret_cast<float4*>(gates + so[r] * 4) = make_float4(ig[k], fg[k], gg[k], og[k]);
-          cs[so[r]] = cn[k];
+        bool v;
+        const int64_t b = cell_row(mt, r, v);
+        if (v) {
+          const int64_t so = (b * rstr + (int64_t)t * tstr) * H + unit;
+          *reinterpret_cast<float4*>(gates + so * 4) = make_float4(ig[k], fg[k], gg[k], og[k]);
+          cs[so] = cn[k];
         }
-        so[r] += H;
       }
     }
-    // wave-local transpose through LDS (DS operations of one wave execute in order; the fence only stops the compiler)
+    cst[w][mt][lane] = make_float4(cnew[0], cnew[1], cnew[2], cnew[3]);
+    // wave-local transpose through LDS (DS operations of one wave execute in order; the fences only stop the compiler)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < 32) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(stg + srow * 16 + 8 * shalf);
-      if (svalid) __builtin_amdgcn_raw_buffer_store_b128(v, hres, soff, 0, kSc1);
+      const int b = b0 + 16 * mt + srow;
+      if (b < d.B) __builtin_amdgcn_raw_buffer_store_b128(v, hres(t), (uint32_t)(((int64_t)b * rstr * H + ubase + 8 * shalf) * 2), 0, kSc1);
     }
-    soff += (uint32_t)(H * 2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (++mt == MT) { mt = 0; ++t; }
   };
   float4 b0v[4], b1v[4], b2v[4];
-  load_gx(tb, b0v);
-  load_gx(tb + 1, b1v);
-  int t = tb;
-  for (; t + 3 <= te; t += 3) {
-    step(t, b0v, b2v);
-    step(t + 1, b1v, b0v);
-    step(t + 2, b2v, b1v);
+  load_gx(b0v);
+  load_gx(b1v);
+  int n = 0;
+  for (; n + 3 <= ntile; n += 3) {
+    tile(b0v, b2v);
+    tile(b1v, b0v);
+    tile(b2v, b1v);
   }
-  if (t < te) { step(t, b0v, b2v); ++t; }
-  if (t < te) { step(t, b1v, b0v); ++t; }
+  if (n < ntile) { tile(b0v, b2v); ++n; }
+  if (n < ntile) { tile(b1v, b0v); ++n; }
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
+// Tile (t, mt), frames last to first: dh_rec = dgates_{t+1}[tile] . W_hh (gathered first: the peers stored it MT tiles ago),
+// then the cell backward of frame t, whose dgates_t leave write-through for the peers' (and this wave's) tile (t-1, mt).
 template <int H>
-__global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab) {
-  constexpr int KS = 4 * H / 32;                 // k16x2 steps over the 4H gate columns
-  constexpr int GK = KS % 16 == 0 ? 16 : 8;      // fragments gathered at a time (KS = H/8 is a multiple of 8)
+__global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT) {
+  constexpr int KS = 4 * H / 32;                 // k32 steps over the 4H gate columns
+  constexpr int GK = (KS % 16 == 0 && H < 512) ? 16 : 8;   // fragments gathered at a time (KS = H/8 is a multiple of 8; 8 at H = 512: registers)
   __shared__ __attribute__((aligned(16))) uint16_t stage[4][16 * 64];
+  __shared__ __attribute__((aligned(16))) float4 dcs[4][kMaxMT][64];
   const int T = d.T;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x, b0 = blockIdx.y * 16, g = blockIdx.z;
+  const int j = blockIdx.x, b0 = blockIdx.y * 16 * MT, g = blockIdx.z;
+  const int64_t rstr = d.tmajor ? 1 : T, tstr = d.tmajor ? d.B : 1;
+  const int64_t GBT = (int64_t)d.B * T;
   const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
-  const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates));
-  const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
-  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
+  const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates)) + (int64_t)g * GBT * H * 4;
+  const float* cs = reinterpret_cast<const float*>(rp(ab, d.c)) + (int64_t)g * GBT * H;
+  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh)) + (int64_t)g * GBT * H;
   uint16_t* dgrp = reinterpret_cast<uint16_t*>(rp(ab, d.dgates)) + d.gx_goff[g];          // this group's rows, ld gx_ld
   const int ubase = 64 * j + 16 * w;
   const int unit = ubase + (lane & 15);
   const int kq = lane >> 4;
   const int64_t gx_ld = d.gx_ld;
-  const int64_t GBT = (int64_t)d.B * T;
-  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(dgrp, 0, (uint32_t)(((GBT - 1) * gx_ld + 4 * H) * 2), 0x00020000);
+  const uint32_t gbytes = (uint32_t)(((((int64_t)d.B - 1) * rstr) * gx_ld + 4 * H) * 2);
+  auto gres = [&](int frame) {
+    return __builtin_amdgcn_make_buffer_rsrc(dgrp + (int64_t)frame * tstr * gx_ld, 0, gbytes, 0x00020000);
+  };
 
   // B[k = gate column][n = unit] = W_hh[torch row of that column][unit]
   uint4 wreg[KS];
@@ -219,55 +274,60 @@ __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, 
     for (int e = 0; e < 8; ++e) f[e] = whh[(int64_t)gate_torch_row(32 * ks + 8 * kq + e, H) * H + unit];
     wreg[ks] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
   }
-  bool rvalid[4];
-  int64_t fo[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * kq + r;
-    rvalid[r] = b < d.B;
-    fo[r] = ((int64_t)g * GBT + (int64_t)(rvalid[r] ? b : 0) * T + (T - 1)) * H + unit;
-  }
-  // dgates_t of this wave: 16 sequences x (16 units x 4 gates) = 16 x 128 bytes = 128 chunks, two per lane
-  uint32_t soff[2];
-  bool svalid[2];
-  int srow[2], spiece[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int cidx = lane + 64 * i;
-    srow[i] = cidx >> 3; spiece[i] = cidx & 7;
-    svalid[i] = b0 + srow[i] < d.B;
-    soff[i] = (uint32_t)((((int64_t)(b0 + srow[i]) * T + (T - 1)) * gx_ld + 4 * ubase + 8 * spiece[i]) * 2);
-  }
-  const int arow = b0 + (lane & 15) < d.B ? b0 + (lane & 15) : 0;
-  uint32_t aoff = (uint32_t)((((int64_t)arow * T + (T - 1)) * gx_ld + 8 * kq) * 2);
-  const uint32_t back = (uint32_t)(gx_ld * 2);
+  auto cell_row = [&](int mt, int r, bool& valid) -> int64_t {
+    const int b = b0 + 16 * mt + 4 * kq + r;
+    valid = b < d.B;
+    return valid ? b : 0;
+  };
+  for (int mt = 0; mt < MT; ++mt) dcs[w][mt][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   uint16_t* stg = &stage[w][0];
   int budget = kSpinBudget;
+  const int ntile = T * MT;
 
-  float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
-  f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
-  struct Sav { float4 g[4]; float cp[4], dh[4]; };
-  auto fetch = [&](int t_, Sav& s) {
-    const int64_t bk = t_ > 0 ? H : 0;
+  struct Sav { float4 g[4]; float cp[4], ct[4], dh[4]; };
+  int pt = T - 1, pmt = 0;
+  auto fetch = [&](Sav& s) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      s.g[r] = *reinterpret_cast<const float4*>(gates + fo[r] * 4);
-      s.cp[r] = cs[fo[r] - bk];
-      s.dh[r] = dh[fo[r]];
-      fo[r] -= bk;
+      bool v;
+      const int64_t b = cell_row(pmt, r, v);
+      const int64_t o = (b * rstr + (int64_t)pt * tstr) * H + unit;
+      s.g[r] = *reinterpret_cast<const float4*>(gates + o * 4);
+      s.ct[r] = cs[o];
+      s.cp[r] = pt > 0 ? cs[o - tstr * H] : 0.f;
+      s.dh[r] = dh[o];
     }
+    if (pt > 0 || pmt < MT - 1) { if (++pmt == MT) { pmt = 0; --pt; } }
   };
-  float pct[4];
+  int t = T - 1, mt = 0;
+  auto tile = [&](const Sav& cur, Sav& pre) {
+    fetch(pre);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (t < T - 1) {
+      const auto r = gres(t + 1);
+      const int b = b0 + 16 * mt + (lane & 15);
+      const uint32_t o = (uint32_t)(((int64_t)(b < d.B ? b : 0) * rstr * gx_ld + 8 * kq) * 2);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pct[r] = cs[fo[r]];
-  auto step = [&](int t, const Sav& cur, Sav& pre) {
-    fetch(t - 2, pre);
+      for (int k0 = 0; k0 < KS; k0 += GK) {
+        u32x4 a[GK];
+        gather<GK>(r, o + 64u * k0, 64u, a, budget);
+#pragma unroll
+        for (int i = 0; i < GK; i += 2) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, wreg[k0 + i]), a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i + 1]), __builtin_bit_cast(bf16x8, wreg[k0 + i + 1]), a1, 0, 0, 0);
+        }
+      }
+    }
+    const f32x4 dhrec = a0 + a1;
+    const float4 dcv = dcs[w][mt][lane];
+    const float dcarry[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+    float dcn4[4];
 #pragma unroll
     for (int rp2 = 0; rp2 < 4; rp2 += 2) {
       const f32x2 ig = {cur.g[rp2].x, cur.g[rp2 + 1].x}, fg = {cur.g[rp2].y, cur.g[rp2 + 1].y};
       const f32x2 gg = {cur.g[rp2].z, cur.g[rp2 + 1].z}, og = {cur.g[rp2].w, cur.g[rp2 + 1].w};
-      const f32x2 ct = {pct[rp2], pct[rp2 + 1]};
-      const f32x2 cp = t > 0 ? f32x2{cur.cp[rp2], cur.cp[rp2 + 1]} : f32x2{0.f, 0.f};
+      const f32x2 ct = {cur.ct[rp2], cur.ct[rp2 + 1]};
+      const f32x2 cp = {cur.cp[rp2], cur.cp[rp2 + 1]};
       const f32x2 dht = f32x2{cur.dh[rp2], cur.dh[rp2 + 1]} + f32x2{dhrec[rp2], dhrec[rp2 + 1]};
       const f32x2 tc = tanh2(ct);
       const f32x2 dog = dht * tc * og * (1.f - og);
@@ -279,67 +339,84 @@ __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, 
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int r = rp2 + k;
-        dcarry[r] = rvalid[r] ? dcn[k] : 0.f;
-        pct[r] = cur.cp[r];
+        bool v;
+        (void)cell_row(mt, r, v);
+        dcn4[r] = v ? dcn[k] : 0.f;
         *reinterpret_cast<uint2*>(stg + (4 * kq + r) * 64 + 4 * (lane & 15)) =
             make_uint2(clean2(pack_bf16x2(di[k], df[k])), clean2(pack_bf16x2(dg[k], dog[k])));
       }
     }
+    dcs[w][mt][lane] = make_float4(dcn4[0], dcn4[1], dcn4[2], dcn4[3]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    {
+      // dgates_t of this wave: 16 sequences x (16 units x 4 gates) = 16 x 128 bytes = 128 chunks of 16 bytes, two per lane
+      const auto r = gres(t);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + srow[i] * 64 + 8 * spiece[i]);
-      if (svalid[i]) __builtin_amdgcn_raw_buffer_store_b128(v, gres, soff[i], 0, kSc1);
-      soff[i] -= back;
+      for (int i = 0; i < 2; ++i) {
+        const int cidx = lane + 64 * i, row = cidx >> 3, piece = cidx & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 64 + 8 * piece);
+        const int b = b0 + 16 * mt + row;
+        if (b < d.B) __builtin_amdgcn_raw_buffer_store_b128(v, r, (uint32_t)(((int64_t)b * rstr * gx_ld + 4 * ubase + 8 * piece) * 2), 0, kSc1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-    if (t > 0) {
-#pragma unroll
-      for (int k0 = 0; k0 < KS; k0 += GK) {
-        u32x4 a[GK];
-        gather<GK>(gres, aoff + 64u * k0, 64u, a, budget);
-#pragma unroll
-        for (int i = 0; i < GK; i += 2) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, wreg[k0 + i]), a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i + 1]), __builtin_bit_cast(bf16x8, wreg[k0 + i + 1]), a1, 0, 0, 0);
-        }
-      }
-    }
-    aoff -= back;
-    dhrec = a0 + a1;
+    if (++mt == MT) { mt = 0; --t; }
   };
   Sav s0, s1, s2;
-  fetch(T - 1, s0);
-  fetch(T - 2, s1);
-  int t = T - 1;
-  for (; t >= 2; t -= 3) {
-    step(t, s0, s2);
-    step(t - 1, s1, s0);
-    step(t - 2, s2, s1);
+  fetch(s0);
+  fetch(s1);
+  int n = 0;
+  for (; n + 3 <= ntile; n += 3) {
+    tile(s0, s2);
+    tile(s1, s0);
+    tile(s2, s1);
   }
-  if (t >= 0) { step(t, s0, s2); --t; }
-  if (t >= 0) { step(t, s1, s0); --t; }
+  if (n < ntile) { tile(s0, s2); ++n; }
+  if (n < ntile) { tile(s1, s0); ++n; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ launch
-bool lstm_cluster_supported(int H) { return H == 192 || H == 256 || H == 320 || H == 384 || H == 448 || H == 512; }
+bool lstm_cluster_supported(int H) { return H > 128 && H <= 512 && H % 64 == 0; }
 
-template <int H>
-static void launch_c(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
-  const dim3 grid(H / 64, (d.B + 15) / 16, d.G);
-  if (fwd) hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab);
-  else hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab);
-}
-
-// "unwritten" marks: frames [t0, t1) of every sequence of h [rows][T][H] (16-byte chunks)
-__global__ void lstm_mark_kernel(uint4* h, int64_t rows, int T, int H8, int t0, int t1) {
+// "unwritten" marks: frames [t0, t1) of every sequence of h (16-byte chunks; rows x T batch-major or T x rows time-major)
+__global__ void lstm_mark_kernel(uint4* h, int64_t rows, int T, int H8, int t0, int t1, int tmajor) {
   const int64_t per = (int64_t)(t1 - t0) * H8, n = rows * per;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / per, rem = i - row * per;
-    h[(row * T + t0) * H8 + rem] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    const int64_t tt = rem / H8, c = rem - tt * H8;
+    const int64_t o = tmajor ? ((t0 + tt) * rows + row) * H8 + c : (row * T + t0 + tt) * H8 + c;
+    h[o] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  }
+}
+
+// rows per workgroup = 16 * MT: the fewest dispatch rounds over the chip's CUs (one workgroup per CU: the weights fill its registers)
+static int pick_mt(const LstmRec& d, int nc) {
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&p, dev); ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+  if (const char* e = getenv("SEFD_LSTM_MT")) { const int v = atoi(e); if (v >= 1 && v <= kMaxMT) return v; }   // tuning / test override
+  const int64_t nb16 = (d.B + 15) / 16;
+  if (nb16 * nc * d.G <= ncu) return 1;
+  // measured on FullSubNet's sub-band model (16448 rows, H = 384; ms per training step): MT 1: 187, 2: 156, 3: 158, 8: 183 - two
+  // tiles overlap one hand-off with the other tile's work, more only lengthen a workgroup's frame; ties go to the larger of 1 / 2
+  int best = 1; int64_t cost = -1;
+  for (int mt = 2; mt >= 1; --mt) {
+    const int64_t wgs = ((nb16 + mt - 1) / mt) * nc * d.G, c = ((wgs + ncu - 1) / ncu) * mt;
+    if (cost < 0 || c < cost) { cost = c; best = mt; }
+  }
+  return best;
+}
+
+template <int H>
+static void launch_c(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  const int mt = pick_mt(d, H / 64);
+  const dim3 grid(H / 64, (d.B + 16 * mt - 1) / (16 * mt), d.G);
+  if (fwd) {
+    if constexpr (H <= 384) { if (mt > 1) { hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, true>), grid, dim3(256), 0, st, d, ab, mt); return; } }
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, false>), grid, dim3(256), 0, st, d, ab, mt);
+  } else {
+    hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab, mt);
   }
 }
 
@@ -348,8 +425,9 @@ void launch_lstm_cluster(const LstmRec& d, const ArenaBases& ab, hipStream_t st,
   if (fwd) {
     const int t0 = d.t0, t1 = d.t1 > 0 ? d.t1 : d.T;
     const int64_t n = (int64_t)d.G * d.B * (t1 - t0) * (d.H / 8);
-    hipLaunchKernelGGL(lstm_mark_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st,
-                       reinterpret_cast<uint4*>(rp(ab, d.h)), (int64_t)d.G * d.B, d.T, d.H / 8, t0, t1);
+    for (int g = 0; g < d.G; ++g)
+      hipLaunchKernelGGL(lstm_mark_kernel, dim3((unsigned)std::min<int64_t>((n / d.G + 255) / 256, 2048)), dim3(256), 0, st,
+                         reinterpret_cast<uint4*>(rp(ab, d.h)) + (int64_t)g * d.B * d.T * (d.H / 8), (int64_t)d.B, d.T, d.H / 8, t0, t1, d.tmajor);
   } else {
     int64_t hi = 0;
     for (int g = 0; g < d.G; ++g) hi = d.gx_goff[g] > hi ? d.gx_goff[g] : hi;

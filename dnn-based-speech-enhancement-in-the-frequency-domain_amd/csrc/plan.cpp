@@ -2124,7 +2124,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2137,13 +2137,27 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     L.gates = b.ws(L.nm + ".gates", (int64_t)TP * rows * 4 * H, DT_F32);
     L.c = b.ws(L.nm + ".c", (int64_t)TP * rows * H, DT_F32);
     L.h = b.ws(L.nm + ".h", (int64_t)TP * rows * H, adt);
+    // bf16 mode, 128 < H <= 512: the whole recurrence is ONE launch of the cluster kernels (lstm_cluster.hip) on the time-major
+    // slabs, gate columns unit-major (sefd_desc.h gate_col); otherwise one GEMM + one cell launch per frame, gate-major columns
+    L.cluster = adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && getenv("SEFD_LSTM_STEPPED") == nullptr;
+    const bool um = L.cluster;
     RunGemm g = seq_gemm(x, adt, rows, xfeat, 0, xlen, 4 * H, DT_F32);
-    L.cgx = [=](int nn, int s, int j) -> int32_t { return j < I ? pe(Wih, (int64_t)nn * I + j, 1) : 0; };
-    L.bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, nn, 1); o[1] = pe(bhh, nn, 1); };
+    L.cgx = [=](int nn, int s, int j) -> int32_t { return j < I ? pe(Wih, (int64_t)(um ? gate_torch_row(nn, H) : nn) * I + j, 1) : 0; };
+    L.bgx = [=](int nn, int32_t* o) { const int q = um ? gate_torch_row(nn, H) : nn; o[0] = pe(bih, q, 1); o[1] = pe(bhh, q, 1); };
     b.pack_weights(Fw, g, L.cgx, L.nm + ".ih", tag, &L.bgx);
     set_y(g, L.gates, rows, 4 * H, 0);
     b.push(Fw, OP_RUNGEMM, tag).g = g;
     L.gx = g;
+    if (L.cluster) {
+      LstmRec r;
+      std::memset(&r, 0, sizeof(r));
+      r.gx = L.gates; r.gates = L.gates;                   // pre-activations are overwritten in place by i, f, g, o
+      r.whh[0] = r.whh[1] = b.pptr(pp + "weight_hh_l" + std::to_string(l));
+      r.h = L.h; r.c = L.c; r.dh = r.dgates = b.none();
+      r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = (int)rows; r.T = TP; r.H = H; r.hdt = adt; r.gdt = DT_F32; r.tmajor = 1;
+      b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
+      L.rec = Builder::gemm0();
+    } else {
     // recurrent weights, packed once per step list
     RunGemm rec0 = step_gemm(L.h, adt, rows, H, 0, 4 * H, L.gates, 4 * H, 0, DT_F32, kRunAccum);
     Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(Whh, (int64_t)nn * H + j, 1); };
@@ -2163,6 +2177,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       cl.h = b.mk(A_WS, L.h.off + (int64_t)t * rows * H * esize(adt));
       cl.dh = cl.dc = cl.dgates = b.none();
       cl.rows = rows; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == 0;
+    }
     }
     L.hd = L.h;
     if (l == 0) {               // inter-layer dropout (nn.LSTM(dropout=0.8)): only after the first of the two layers
@@ -2216,10 +2231,19 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       const int H = L.H;
       const int64_t rows = L.rows;
       Ptr dgates = b.ws(L.nm + ".dgates", (int64_t)TP * rows * 4 * H, adt);
+      const ParamInfo* Whh = L.Whh;
+      const bool um = L.cluster;
+      if (L.cluster) {
+        LstmRec r;
+        std::memset(&r, 0, sizeof(r));
+        r.gx = L.gates; r.gates = L.gates; r.h = L.h; r.c = L.c; r.dh = dh; r.dgates = dgates;
+        r.whh[0] = r.whh[1] = b.mk(A_PARAM, Whh->off * 4);
+        r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = (int)rows; r.T = TP; r.H = H; r.hdt = adt; r.gdt = adt; r.tmajor = 1;
+        b.push(R, OP_LSTM_BWD, tag).lstm = r;
+      } else {
       Ptr dc = b.ws(L.nm + ".dc", rows * H, DT_F32);
       // dh_{t-1} += dgates_t . W_hh : packed transposed recurrent weights
       RunGemm rb0 = step_gemm(dgates, adt, rows, 4 * H, 0, H, dh, H, 0, DT_F32, kRunAccum);
-      const ParamInfo* Whh = L.Whh;
       Builder::Coef cT = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)j * H + nn, 1); };
       b.pack_weights(R, rb0, cT, L.nm + ".hhT", tag);
       for (int t = TP - 1; t >= 0; --t) {
@@ -2239,6 +2263,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
           b.push(R, OP_RUNGEMM, tag).g = r;
         }
       }
+      }
       // weight gradients over all steps
       RunGemm fw = L.gx;
       fw.ydt = adt;
@@ -2246,7 +2271,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       RunGemm fh = seq_gemm(L.h, adt, rows, H, 0, H, 4 * H, adt);
       fh.seg[0].dt = -1;                                   // h_{t-1}
       set_y(fh, dgates, rows, 4 * H, 0);
-      Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)nn * H + j, 1); };
+      Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)(um ? gate_torch_row(nn, H) : nn) * H + j, 1); };
       b.wgrad(R, fh, dgates, chh, tag, nullptr);
       if (need_dx) {
         RunGemm g = seq_gemm(dgates, adt, rows, 4 * H, 0, 4 * H, dx_N, dx_dt);

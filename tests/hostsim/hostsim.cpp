@@ -547,12 +547,13 @@ void run_op(const Op& op, const AB& ab) {
           std::vector<double> h(H, 0.0), c(H, 0.0), hn(H);
           const int tb = d.t0, te = d.t1 > 0 ? d.t1 : T;
           if (tb > 0) {                                   // resume from the saved state of frame tb - 1
-            const int64_t rp_ = ((int64_t)g * d.B + b) * T + tb - 1;
+            const int64_t rp_ = (int64_t)g * d.B * T + (d.tmajor ? (int64_t)(tb - 1) * d.B + b : (int64_t)b * T + tb - 1);
             for (int j = 0; j < H; ++j) { h[j] = ld(rp(ab, d.h), d.hdt, rp_ * H + j); c[j] = cs[rp_ * H + j]; }
           }
           for (int t = tb; t < te; ++t) {
-            const float* gx = gxb + d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld;
-            const int64_t row = ((int64_t)g * d.B + b) * T + t;
+            const int64_t rt = d.tmajor ? (int64_t)t * d.B + b : (int64_t)b * T + t;      // (sequence, frame) -> row of the buffers
+            const float* gx = gxb + d.gx_goff[g] + rt * d.gx_ld;
+            const int64_t row = (int64_t)g * d.B * T + rt;
             for (int j = 0; j < H; ++j) {
               double pre[4];
               for (int q = 0; q < 4; ++q) {
@@ -590,11 +591,12 @@ void run_op(const Op& op, const AB& ab) {
         for (int b = 0; b < d.B; ++b) {
           std::vector<double> dhrec(H, 0.0), dc(H, 0.0), dg(4 * H);
           for (int t = T - 1; t >= 0; --t) {
-            const int64_t row = ((int64_t)g * d.B + b) * T + t;
+            const int64_t rt = d.tmajor ? (int64_t)t * d.B + b : (int64_t)b * T + t;
+            const int64_t row = (int64_t)g * d.B * T + rt, rowp = row - (d.tmajor ? d.B : 1);
             for (int j = 0; j < H; ++j) {
               const float* gq = gates + (row * H + j) * 4;
               const double ig = gq[0], fg = gq[1], gg = gq[2], og = gq[3];
-              const double ct = cs[row * H + j], cp = t > 0 ? cs[(row - 1) * H + j] : 0.0;
+              const double ct = cs[row * H + j], cp = t > 0 ? cs[rowp * H + j] : 0.0;
               const double dht = dh[row * H + j] + dhrec[j];
               const double tc = std::tanh(ct);
               const double dcv = dht * og * (1 - tc * tc) + dc[j];
@@ -604,7 +606,7 @@ void run_op(const Op& op, const AB& ab) {
               dg[3 * H + j] = dht * tc * og * (1 - og);
               dc[j] = dcv * fg;
             }
-            const int64_t o = d.gx_goff[g] + ((int64_t)b * T + t) * d.gx_ld;
+            const int64_t o = d.gx_goff[g] + rt * d.gx_ld;
             for (int k = 0; k < 4 * H; ++k) st(rp(ab, d.dgates), d.gdt, o + gate_col(k / H, k % H), (float)dg[k]);
             for (int j = 0; j < H; ++j) {
               double s = 0;

@@ -44,7 +44,9 @@ def _typed(t_u8, dt):
                                                         ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
                                                         ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("FullSubNet", 2, 13, "E", (128, 64), 0, "fp32"),
-                                                        ("FullSubNet", 2, 9, "E", (64, 32), 0, "bf16")])
+                                                        ("FullSubNet", 2, 9, "E", (64, 32), 0, "bf16"),
+                                                        ("FullSubNet", 2, 9, "E", (256, 192), 0, "bf16"),      # cluster LSTM kernels on the time-major slabs
+                                                        ("FullSubNet", 2, 10, "E", (512, 384), 0, "bf16")])    # reference sizes; T = 10 marks the case that walks 3 row tiles per workgroup
 def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     """Tolerances: fp32 buffers 1e-3 (observed <= 3e-6); bf16 buffers 1.6e-2 = two bf16 ulps of the largest element
     (simulator and kernel round slightly different fp32 accumulations of the SAME bf16 operands)."""
@@ -54,6 +56,9 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         os.environ["SEFD_CG256_MINM"] = "64"
     else:
         os.environ.pop("SEFD_CG256_MINM", None)
+    os.environ.pop("SEFD_LSTM_MT", None)
+    if model == "FullSubNet" and L == 10:
+        os.environ["SEFD_LSTM_MT"] = "3"
     if model == "FullSubNet":              # L = STFT frames, kn = (fb_hidden, sb_hidden); dropout keep 0.2 exercises the mask hash
         from oracle.fullsubnet import FSNConfig, fsn_state_shapes
         P = formula_state_dict(fsn_state_shapes(FSNConfig(fb_hidden=kn[0], sb_hidden=kn[1])))
@@ -141,7 +146,8 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
                          f"err/tol {worst:.3e} stray {stray} {where}")
             if not (worst < 1.0) or stray:
                 bad.append(lines[-1])
-    with open(_report_path(f"ops_report_{model}_B{B}_{mode}_{dtype}.txt"), "w") as f:
+    os.environ.pop("SEFD_LSTM_MT", None)
+    with open(_report_path(f"ops_report_{model}_B{B}_{mode}_{dtype}_{L}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])
 

@@ -57,6 +57,51 @@ def test_hostsim_wide_lstm_takes_the_per_step_path():
     _check_plan_vs_oracle("C", "SDR", kw, 1, 2000)
 
 
+def _grads_close(g1, g2, tol):
+    """Per-tensor relative L2 error; tensors whose true gradient is zero (a conv bias in front of BatchNorm) hold rounding noise
+    only and are measured against the largest gradient norm of the model instead of their own."""
+    floor = 1e-2 * max(float(v.double().norm()) for v in g2.values())
+    for k in g1:
+        d = float((g1[k].double() - g2[k].double()).norm())
+        assert d / max(float(g2[k].double().norm()), floor) < tol, k
+
+
+def _run_plan(plan, P, x, gw):
+    ar = plan.alloc_arenas("cpu")
+    fill_params(plan, ar, P)
+    B, L = x.shape
+    plan.io(ar, "wav", (B, L)).copy_(x)
+    sim_run(plan, PHASE_FWD, ar)
+    plan.io(ar, "grad_wav", (B, L)).copy_(gw)
+    sim_run(plan, PHASE_BWD, ar)
+    return plan.io(ar, "out_wav", (B, L)).clone(), read_params(plan, ar, ARENA_GRAD)
+
+
+def test_bf16_wide_lstm_is_one_recurrence_op_per_layer_and_equals_the_per_step_plan(monkeypatch):
+    """bf16, rnn_units 512 (H = 256 per part): the planner emits LSTM_FWD / LSTM_BWD (cluster kernels on the GPU, lstm_cluster.hip)
+    instead of per-frame GEMM + cell ops.  Same arithmetic contract (bf16 h / W_hh / dgates, fp32 gates and cell state), so on
+    the host simulator the two plans agree to bf16 rounding noise, and both sit within the bf16 budget of the fp32 oracle."""
+    kw = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=512)
+    B, L = 2, 2000
+    P = oracle_params(DCCRNConfig(masking_mode="C", **kw))
+    x, y = make_signals(B, L)
+    torch.manual_seed(2)
+    gw = torch.randn(B, L) * 1e-3
+    plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
+    kinds = [plan.op_info(PHASE_FWD, i)["kind"] for i in range(plan.num_ops(PHASE_FWD))]
+    assert kinds.count(1) < 40                                  # no per-frame GEMMs
+    monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+    ref = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
+    monkeypatch.delenv("SEFD_LSTM_STEPPED")
+    assert plan.num_ops(PHASE_FWD) < ref.num_ops(PHASE_FWD) - 2 * (plan.T - 1)
+    o1, g1 = _run_plan(plan, P, x, gw)
+    o2, g2 = _run_plan(ref, P, x, gw)
+    assert rel_err(o1, o2) < 5e-3
+    _grads_close(g1, g2, 3e-2)
+    outs, _ = dccrn_forward({k: v.clone() for k, v in P.items()}, x, DCCRNConfig(masking_mode="C", **kw), targets=y, train=True)
+    assert rel_err(o1, outs[2]) < 3e-2
+
+
 def test_hostsim_without_skip_connections():
     """cfg.skip_type = False (models.py:107-137, 222-223): decoder layers take only the previous layer's output."""
     _check_plan_vs_oracle("E", "SI-SNR", dict(SMALL, skip_type=False), 2, 3000)
@@ -320,6 +365,37 @@ def test_fsn_hostsim_forward_backward_vs_oracle():
     got = read_params(plan, ar, ARENA_GRAD)
     for k in names:
         assert rel_err(got[k], grads[k]) < 2e-4, k
+
+
+def test_fsn_bf16_cluster_lstm_plan_equals_the_per_step_plan(monkeypatch):
+    """bf16 with 128 < hidden <= 512 (the reference sizes 512 / 384 included): each LSTM layer is ONE recurrence op on the
+    time-major slabs with unit-major gate columns; must agree with the per-frame GEMM + cell plan on the host simulator."""
+    from oracle.fullsubnet import FSNConfig, fsn_forward, fsn_state_shapes
+    hid = (256, 192)
+    cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])
+    P = formula_state_dict(fsn_state_shapes(cfg))
+    B, T = 1, 7
+    torch.manual_seed(4)
+    mag = torch.rand(B, 257, T) * 2
+    gc = torch.randn(B, 257, T, 2) * 1e-3
+    outs = []
+    for stepped in (False, True):
+        if stepped:
+            monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+        plan = Plan(B, T, model="FullSubNet", act_dtype="bf16", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=1.0))
+        kinds = [plan.op_info(PHASE_FWD, i)["kind"] for i in range(plan.num_ops(PHASE_FWD))]
+        assert (kinds.count(1) < 12) == (not stepped)
+        ar = plan.alloc_arenas("cpu")
+        fill_params(plan, ar, P)
+        plan.io(ar, "mag", (B, 257, T)).copy_(mag)
+        sim_run(plan, PHASE_FWD, ar)
+        plan.io(ar, "grad_crm", (B, 257, T, 2)).copy_(gc)
+        sim_run(plan, PHASE_BWD, ar)
+        outs.append((plan.io(ar, "crm", (B, 257, T, 2)).clone(), read_params(plan, ar, ARENA_GRAD)))
+    monkeypatch.delenv("SEFD_LSTM_STEPPED")
+    assert rel_err(outs[0][0], outs[1][0]) < 5e-3
+    _grads_close(outs[0][1], outs[1][1], 3e-2)
+    assert rel_err(outs[0][0], fsn_forward(P, mag, cfg)) < 3e-2
 
 
 def test_fsn_dropout_mask_statistics_and_backward_consistency():
