@@ -22,6 +22,24 @@ namespace {
 constexpr double kPi = 3.14159265358979323846;
 inline int64_t rup(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// Runs of a RUNGEMM / WGRAD are whole, 16-byte aligned chunks (then the kernels use the LDS-DMA loaders).  Arena buffers are
+// 256-byte aligned, so only element offsets matter.  WGRAD: the upstream-gradient operand must be chunk aligned as well.
+static bool runs_aligned(const RunGemm& g, bool is_wgrad) {
+  const int vec = 16 / esize(g.xdt);
+  bool ok = true;
+  for (int s = 0; s < g.nseg && ok; ++s) {
+    const Seg& sg = g.seg[s];
+    if (sg.src < 0) { ok = is_wgrad; continue; }          // the ones run exists only in WGRAD
+    const int q = sg.src;
+    ok = sg.off % vec == 0 && sg.len % vec == 0 && g.fstride[q] % vec == 0 && g.base[q] % vec == 0 && g.rowlen[q] % vec == 0 &&
+         g.tstride[q] % vec == 0 && g.bstride[q] % vec == 0 && (g.x[q].off % 16) == 0;
+  }
+  if (is_wgrad)
+    ok = ok && g.xdt == DT_BF16 && g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&
+         g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
+  return ok;
+}
+
 struct Builder {
   Plan* P;
   ModelConfig c;
@@ -215,9 +233,17 @@ struct Builder {
     // co-resident slots of the 256 CUs in ONE wave of workgroups and never spill a few stragglers into a second one
     // (sized for the 4-stage ring: 64 KiB (128-wide n tile) or 48 KiB (64-wide) of LDS, 2 or 3 workgroups per CU; the shipped
     //  3-stage ring needs 48 / 36 KiB, so the same grids still fit in one wave with room for the other stream's kernels).
-    const int tn = (g.xdt == DT_BF16 && g.Npad >= 128) ? 128 : kWgTN;
-    const int slots = g.xdt == DT_BF16 ? (tn == 128 ? 512 : 768) : 768;
-    const int tiles = (int)(rup(g.Npad, tn) / tn * rup(g.ldw, kWgTK) / kWgTK);
+    const bool narrow = runs_aligned(g, true);       // thin layers: 32 / 16 wide n tiles (aligned bf16 kernel only)
+    int tn = narrow ? wgrad_tn(g.xdt, g.N, g.Npad) : (g.xdt == DT_BF16 && g.Npad >= 128) ? 128 : kWgTN;
+    // the layers that carry the FLOPs: 256 x 256 tile of the 8-wave kernel.  SEFD_WG256=0 keeps the 128 x 128 tile; SEFD_WG256_MINM
+    // lowers the row threshold (tests run the wide kernel on small cases)
+    const bool wide_on = !(getenv("SEFD_WG256") && atoi(getenv("SEFD_WG256")) == 0);
+    const int64_t wide_minm = getenv("SEFD_WG256_MINM") ? atoll(getenv("SEFD_WG256_MINM")) : 32768;
+    int tk = kWgTK;
+    if (narrow && wide_on && g.Npad % 256 == 0 && g.ldw >= 512 && g.M >= wide_minm) { tn = 256; tk = 256; g.flags |= kRunWgWide; }
+    else if (narrow && wide_on && g.Npad == 128 && g.ldw >= 1024 && g.M >= wide_minm) { tn = 128; tk = 512; g.flags |= kRunWgWide; }
+    const int slots = g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768;
+    const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
     ns = std::max(1, std::min(ns, std::max(1, steps / 4)));
@@ -308,18 +334,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
       g.zero = z;
       fastdiv_make((uint32_t)(g.Tout * g.Fo), &g.div_tf_m, &g.div_tf_s);
       fastdiv_make((uint32_t)g.Fo, &g.div_fo_m, &g.div_fo_s);
-      const int vec = 16 / esize(g.xdt);
-      bool ok = true;
-      for (int s = 0; s < g.nseg && ok; ++s) {
-        const Seg& sg = g.seg[s];
-        if (sg.src < 0) { ok = op.kind == OP_WGRAD; continue; }          // the ones run exists only in WGRAD
-        const int q = sg.src;
-        ok = sg.off % vec == 0 && sg.len % vec == 0 && g.fstride[q] % vec == 0 && g.base[q] % vec == 0 && g.rowlen[q] % vec == 0 &&
-             g.tstride[q] % vec == 0 && g.bstride[q] % vec == 0 && (g.x[q].off % 16) == 0;
-      }
-      if (op.kind == OP_WGRAD)      // the upstream-gradient operand must be chunk aligned as well
-        ok = ok && g.xdt == DT_BF16 && g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&
-             g.y_bstride % 8 == 0 && (g.y.off % 16) == 0;
+      const bool ok = runs_aligned(g, op.kind == OP_WGRAD);
       g.flags = (g.flags & ~kRunAligned) | (ok ? kRunAligned : 0);
       if (op.kind == OP_RUNGEMM) {
         const bool ya = g.ydt == DT_BF16 && g.N % 8 == 0 && g.y_off % 8 == 0 && g.y_fstride % 8 == 0 && g.y_tstride % 8 == 0 &&

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const RunGemm d, const 
 // Padding / out-of-range rows come from a zero page, the bias "ones" run from a ones page (1.0, 0, 0, ...).
 template <int TN>
 __device__ __forceinline__ bf16x8 tr_frag_swz(const uint16_t* tile, int col0, int lane) {
-  constexpr int MASK = TN == 64 ? 3 : 7;           // 32-byte pieces per row: 4 (128-byte rows) or 8 (256-byte rows)
+  constexpr int MASK = TN >= 128 ? 7 : TN == 64 ? 3 : 0;   // 32-byte pieces per row: 8 (256-byte rows) or 4 (128-byte rows); narrow tiles are not swizzled
   const int g = lane >> 4, i = lane & 15;
   const int r = 4 * g + (i >> 2);
   const int piece = ((col0 >> 4) + 0);             // col0 is a multiple of 16 elements = one 32-byte piece
@@ -748,11 +748,17 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const uint16_t* tile, int col0, in
   return __builtin_bit_cast(bf16x8, f);
 }
 
-template <int TN, int S>
-__global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, const ArenaBases ab) {
-  constexpr int TK = kWgTK, RS = kWgRows;
-  constexpr int NT = TN / 32;
-  constexpr int DMASK = TN == 64 ? 3 : 7;
+// TK x NTHR: 128 x 256 threads (tiles up to 128 x 128) or 256 x 512 threads (the 256 x 256 tile of the wide layers: half the operand
+// bytes through L2 -> LDS per MFMA, which is what bounds the 128 x 128 tile - 64 B/clk/CU at the MFMA rate, the DMA stream's ceiling)
+template <int TN, int S, int TK = kWgTK, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, const ArenaBases ab) {
+  constexpr int RS = kWgRows, NW = NTHR / 64;
+  // wave grid: 2 (n) x 2 (k) for the 128 / 64 / 32 wide n tiles, 1 x 4 for the 16 wide one (thin layers: N <= 16, e.g. the mask
+  // layer's 2 -> 8 channels - a 64-wide tile there is 7/8 padding and the launch is bound by the activation stream instead)
+  constexpr int WK = (TN >= 32 ? 2 : 4) * (NW / 4);
+  constexpr int PWN = TN / (NW / WK), PWK = TK / WK;
+  constexpr int NT = PWN / 16, KB = PWK / 16;
+  constexpr int DMASK = TN >= 128 ? 7 : TN == 64 ? 3 : 0;
   __shared__ __attribute__((aligned(16))) uint16_t dys[S][RS * TN];
   __shared__ __attribute__((aligned(16))) uint16_t as[S][RS * TK];
 
@@ -765,6 +771,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
   const uint16_t* zp = reinterpret_cast<const uint16_t*>(rp(ab, d.zero));
   const uint16_t* onep = zp + 128;                 // second 256-byte page: bf16 (1, 0, 0, ...)
   float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)split * d.Npad * d.ldw;
+  if (ntile * TN >= d.N) {                         // n tile made of padding rows only (N = 8 in a 32-row packed matrix): zeros
+    for (int i = tid; i < TN * TK; i += NTHR) {
+      const int n = ntile * TN + i / TK, k = ktile * TK + i % TK;
+      if (n < d.Npad && k < d.ldw) part[(int64_t)n * d.ldw + k] = 0.f;
+    }
+    return;
+  }
 
   // Reduction rows are walked per batch item in steps of RS rows: step (b, s) covers rows q = RS*s .. RS*s+RS-1 of item b
   // (q >= Tout*Fo reads the zero page).  With Fo a power of two the (frame, bin) of a row is then a per-thread constant plus
@@ -780,7 +793,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
   const int fsh = (Fo & (Fo - 1)) == 0 ? __ffs(Fo) - 1 : -1;
 
   // A tile: 16 chunks per row, thread -> (row ra + 16p, LDS position pa); it fetches source chunk qa = pa ^ ((row & 7) << 1)
-  const int pa = tid & 15, ra = tid >> 4;
+  constexpr int ACH = TK / 8;                      // 16-byte chunks per row of the A tile; NTHR / ACH = 16 rows per pass
+  constexpr int AROWS = NTHR / ACH, APASS = RS / AROWS;   // rows per pass (16 or 8), passes (2 or 4)
+  const int pa = tid % ACH, ra = tid / ACH;
   const int qa = pa ^ ((ra & 7) << 1);
   const int kcol = ktile * TK + qa * 8;
   int sgi = -1, j0 = 0;
@@ -816,9 +831,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
   const bool a_any = a_real && fhi >= flo;
   // dy tile: TN/8 chunks per row
   constexpr int DCH = TN / 8;
-  constexpr int DROWS = 256 / DCH;                 // rows per pass (16 or 32)
-  constexpr int DPASS = RS / DROWS;
-  constexpr int NL = 2 + DPASS;                    // DMAs per thread per stage
+  constexpr int DROWS = NTHR / DCH;                 // rows per pass (16 or 32; the narrow tiles need only the first 128 / 64 threads)
+  constexpr int DPASS = RS >= DROWS ? RS / DROWS : 1;
+  constexpr int DWAVES = RS >= DROWS ? NW : RS * DCH / 64;   // waves that move the dy tile
+  constexpr int NL = APASS + DPASS;                    // DMAs per thread per stage (waves >= DWAVES: 2)
+  const bool dwave = __builtin_amdgcn_readfirstlane(wid) < DWAVES;
   const int pd = tid % DCH, rd = tid / DCH;
   const int qd = pd ^ ((rd & DMASK) << 1);
   const int ncol = ntile * TN + qd * 8;
@@ -827,12 +844,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
   const uint16_t* dy_base = dy + d.y_off + ncol;
 
   // per-thread constant part of each row (pow-2 Fo): row r of a step sits at frame u0 + ur, bin f0 + fr
-  int a_r[2], a_ur[2], a_fr[2], y_r[DPASS];
-  const uint16_t* a_tc[2];
+  int a_r[APASS], a_ur[APASS], a_fr[APASS], y_r[DPASS];
+  const uint16_t* a_tc[APASS];
   const uint16_t* y_tc[DPASS];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int r = ra + 16 * p;
+  for (int p = 0; p < APASS; ++p) {
+    const int r = ra + AROWS * p;
     a_r[p] = r;
     a_ur[p] = (fsh >= 0 && Fo < RS) ? (r >> fsh) : 0;
     a_fr[p] = (fsh >= 0 && Fo < RS) ? (r & (Fo - 1)) : r;
@@ -858,46 +875,50 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
       const int64_t oy = (int64_t)ib * y_bstride + (int64_t)u0 * y_tstride + (int64_t)f0 * y_fstride;
       const int64_t oa = asrc ? o1 : o0;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < APASS; ++p) {
         const bool rowv = q0 + a_r[p] < TF;
         const bool v = a_any && rowv && (unsigned)(u0 + a_ur[p] + a_dt) < (unsigned)a_Tin &&
                        (unsigned)(f0 + a_fr[p] - flo) <= fspan;
         const uint16_t* src = v ? a_tc[p] + oa : ((a_ones && rowv) ? onep : zp);
-        dma16(src, as_l + stage * (RS * TK * 2) + p * 4096);
+        dma16(src, as_l + stage * (RS * TK * 2) + p * (NTHR * 16));
       }
+      if (dwave) {
 #pragma unroll
-      for (int p = 0; p < DPASS; ++p) {
-        const uint16_t* src = (d_ok && q0 + y_r[p] < TF) ? y_tc[p] + oy : zp;
-        dma16(src, dys_l + stage * (RS * TN * 2) + p * 4096);
+        for (int p = 0; p < DPASS; ++p) {
+          const uint16_t* src = (d_ok && q0 + y_r[p] < TF) ? y_tc[p] + oy : zp;
+          dma16(src, dys_l + stage * (RS * TN * 2) + p * (NTHR * 16));
+        }
       }
     } else {                                         // general Fo: one division per row
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < APASS; ++p) {
         const int q = q0 + a_r[p];
         const int u = q / Fo, fo = q - u * Fo;
         const bool rowv = q < TF;
         const bool v = a_any && rowv && (unsigned)(u + a_dt) < (unsigned)a_Tin && (unsigned)(fo - flo) <= fspan;
         const uint16_t* src = v ? xs_base + (int64_t)ib * (asrc ? bs1 : bs0) + (int64_t)(u + a_dt) * a_tstride + (int64_t)fo * a_fstride
                                 : ((a_ones && rowv) ? onep : zp);
-        dma16(src, as_l + stage * (RS * TK * 2) + p * 4096);
+        dma16(src, as_l + stage * (RS * TK * 2) + p * (NTHR * 16));
       }
+      if (dwave) {
 #pragma unroll
-      for (int p = 0; p < DPASS; ++p) {
-        const int q = q0 + y_r[p];
-        const int u = q / Fo, fo = q - u * Fo;
-        const uint16_t* src = (d_ok && q < TF) ? dy_base + (int64_t)ib * y_bstride + (int64_t)u * y_tstride + (int64_t)fo * y_fstride : zp;
-        dma16(src, dys_l + stage * (RS * TN * 2) + p * 4096);
+        for (int p = 0; p < DPASS; ++p) {
+          const int q = q0 + y_r[p];
+          const int u = q / Fo, fo = q - u * Fo;
+          const uint16_t* src = (d_ok && q < TF) ? dy_base + (int64_t)ib * y_bstride + (int64_t)u * y_tstride + (int64_t)fo * y_fstride : zp;
+          dma16(src, dys_l + stage * (RS * TN * 2) + p * (NTHR * 16));
+        }
       }
     }
     if (++is == spb) { is = 0; ++ib; }
   };
 
-  f32x4 acc[NT][4];
+  f32x4 acc[NT][KB];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int wn = (wid >> 1) * (TN / 2), wk = (wid & 1) * 64;
+    for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wn = (wid / WK) * PWN, wk = (wid % WK) * PWK;
 
   // S-stage ring: DMA runs S-1 row steps ahead of the MFMAs; per step one vmcnt wait for the oldest stage + one LDS barrier
   const int nst = step1 - step0;
@@ -906,24 +927,24 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const RunGemm d, co
     if (issued < nst) { dma(istage); istage = istage + 1 == S ? 0 : istage + 1; ++issued; }
   int cstage = 0;
   for (int i = 0; i < nst; ++i) {
-    wait_stage<NL, S>(nst - 1 - i);
+    if (dwave) wait_stage<NL, S>(nst - 1 - i); else wait_stage<APASS, S>(nst - 1 - i);
     lds_barrier();
     if (issued < nst) { dma(istage); istage = istage + 1 == S ? 0 : istage + 1; ++issued; }
-    bf16x8 af[NT], bfr[4];
+    bf16x8 af[NT], bfr[KB];
 #pragma unroll
     for (int a = 0; a < NT; ++a) af[a] = tr_frag_swz<TN>(&dys[cstage][0], wn + a * 16, lane);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bfr[b] = tr_frag_swz<TK>(&as[cstage][0], wk + b * 16, lane);
+    for (int b = 0; b < KB; ++b) bfr[b] = tr_frag_swz<TK>(&as[cstage][0], wk + b * 16, lane);
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < KB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     cstage = cstage + 1 == S ? 0 : cstage + 1;
   }
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < KB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = ntile * TN + wn + a * 16 + 4 * (lane >> 4) + r;
@@ -975,6 +996,21 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   else launch_rungemm_t<float>(d, ab, st);
 }
 
+// 256 x 256 tile, 8 waves, 4-stage ring of 32 KB = 128 KB: one workgroup per CU (wgrad_tn == 256)
+static void launch_wgrad_wide(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  static const int stages = env_stages("SEFD_WG256_STAGES", 2);   // 2, 3 and 4 stages measure the same (+-1 %): 2 x 32 KB leaves LDS to the other stream's kernels
+  dim3 grid(((d.Npad + 255) / 256) * ((d.ldw + 255) / 256) * d.nsplit);
+  if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 2, 256, 512>), grid, dim3(512), 0, st, d, ab);
+  else if (stages == 3) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 3, 256, 512>), grid, dim3(512), 0, st, d, ab);
+  else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 4, 256, 512>), grid, dim3(512), 0, st, d, ab);
+}
+
+// 128 x 512 tile for the N = 128 layers (kRunWgWide with Npad == 128): same bytes per MFMA as 256 x 256 would need at N = 256
+static void launch_wgrad_wide128(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + 511) / 512) * d.nsplit);
+  hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 2, 512, 512>), grid, dim3(512), 0, st, d, ab);
+}
+
 template <int TN>
 static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int stages = env_stages("SEFD_WG_STAGES", 3);   // 3 stages = 48 KiB (128-wide) / 36 KiB: co-resides better with the other stream (13.63 -> 13.24 ms per step vs 4)
@@ -986,8 +1022,13 @@ static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t
 
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (d.xdt == DT_BF16 && (d.flags & kRunAligned)) {
-    if (d.Npad >= 128) launch_wgrad_dma<128>(d, ab, st);
-    else launch_wgrad_dma<64>(d, ab, st);
+    if (d.flags & kRunWgWide) { if (d.Npad % 256 == 0) launch_wgrad_wide(d, ab, st); else launch_wgrad_wide128(d, ab, st); return; }
+    switch (wgrad_tn(d.xdt, d.N, d.Npad)) {        // sefd_desc.h: the planner sized nsplit for the same tile
+      case 128: launch_wgrad_dma<128>(d, ab, st); break;
+      case 64: launch_wgrad_dma<64>(d, ab, st); break;
+      case 32: launch_wgrad_dma<32>(d, ab, st); break;
+      default: launch_wgrad_dma<16>(d, ab, st); break;
+    }
     return;
   }
   if (d.xdt == DT_BF16) {

@@ -5,6 +5,7 @@
 // kernel per Op; the test-only host simulator (tests/hostsim) interprets the same list on the CPU
 // so that the planner's index arithmetic can be checked without a GPU.  All structs are PODs.
 #pragma once
+#include <cstdlib>
 #include <cstdint>
 
 namespace sefd {
@@ -80,6 +81,7 @@ constexpr int kRunRelu = 4;      // y = max(result, 0)
 constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chunks: the tile is staged through LDS and stored wide
 constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw / 32][Npad][32]: the B operand of one 32-deep K tile is ONE
                                  // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
+constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`
 static inline int64_t w_index(int flags, int ldw, int Npad, int n, int k) {
   return (flags & kRunWTile32) ? ((int64_t)(k >> 5) * Npad + n) * 32 + (k & 31) : (int64_t)n * ldw + k;
@@ -343,6 +345,13 @@ constexpr int kBM = 128;                                   // rows per RUNGEMM b
 inline int bk_of(int dt) { return dt == DT_BF16 ? 64 : 32; }   // K-tile in elements: 128 bytes of either dtype
 inline int bn_of(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 constexpr int kWgTN = 64, kWgTK = 128, kWgRows = 32;       // WGRAD block tile (n x k) and reduction rows per step
+// n extent of the WGRAD tile of the aligned bf16 kernel: 128 for wide layers, 32 for the thin ones (shared by the planner, which
+// sizes the row splits for it, and the launcher).  Measured (MI355X, DCCRN B = 32): N = 32 layers 228 -> 210 us and 164 -> 149 us
+// with the 32-wide tile; a 16-wide one made the mask layer (N = 8, M = 2 M rows) slower (318 -> 457 us: twice the workgroups, each
+// bound by the same activation stream) and is not used.
+static inline constexpr int wgrad_tn(int xdt, int N, int Npad) {
+  return xdt != DT_BF16 ? kWgTN : Npad >= 128 ? 128 : N > 32 ? 64 : 32;
+}
 inline int esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
 
 }  // namespace sefd

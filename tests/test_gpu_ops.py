@@ -54,8 +54,10 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     if L == 2401:                          # the wide-tile kernel needs M >= 4096 by default: lower the bar so that this small case runs it
         L = 2400
         os.environ["SEFD_CG256_MINM"] = "64"
+        os.environ["SEFD_WG256_MINM"] = "64"
     else:
         os.environ.pop("SEFD_CG256_MINM", None)
+        os.environ.pop("SEFD_WG256_MINM", None)
     os.environ.pop("SEFD_LSTM_MT", None)
     if model == "FullSubNet" and L == 10:
         os.environ["SEFD_LSTM_MT"] = "3"
@@ -70,7 +72,8 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)))
     if model != "FullSubNet":
         plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
-    os.environ.pop("SEFD_CG256_MINM", None)        # the plan is built: later tests get the default threshold again
+    os.environ.pop("SEFD_CG256_MINM", None)        # the plan is built: later tests get the default thresholds again
+    os.environ.pop("SEFD_WG256_MINM", None)
     dev = plan.alloc_arenas("cuda")
     host = plan.alloc_arenas("cpu")
     fill_params(plan, dev, P)

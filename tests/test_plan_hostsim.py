@@ -140,6 +140,26 @@ def test_chunked_lstm_pipeline_plan_equals_unchunked(monkeypatch):
         assert torch.equal(a, b_)
 
 
+def test_wide_wgrad_tile_only_changes_the_row_splits(monkeypatch):
+    """The 256 x 256 WGRAD tile (rungemm.hip launch_wgrad_wide, descriptor flag kRunWgWide) is a launch geometry: the planner sizes
+    the row splits for it, the sums are the same.  Same gradients as the 128 x 128 plan up to fp32 summation order."""
+    B, L = 1, 2400
+    kw = dict(kernel_num=(32, 64, 128, 256, 256, 256), rnn_units=256)
+    P = oracle_params(DCCRNConfig(masking_mode="C", **kw))
+    x, _ = make_signals(B, L)
+    torch.manual_seed(6)
+    gw = torch.randn(B, L) * 1e-3
+    res, nwide = [], []
+    for on in ("0", "1"):
+        monkeypatch.setenv("SEFD_WG256", on)
+        monkeypatch.setenv("SEFD_WG256_MINM", "64")
+        plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
+        nwide.append(sum(1 for i in range(plan.num_ops(PHASE_BWD)) if plan.op_info(PHASE_BWD, i)["kind"] == 2 and plan.op_info(PHASE_BWD, i)["flags"] & 32))
+        res.append(_run_plan(plan, P, x, gw)[1])
+    assert nwide[0] == 0 and nwide[1] >= 7, nwide            # enc3-5 and the two sub-pixel phases of dec0, dec1
+    _grads_close(res[1], res[0], 1e-4)
+
+
 def test_tiled_weight_layout_is_a_pure_relayout(monkeypatch):
     """Wide-tile GEMMs (cgemm256.hip) read their weights K-tile major (kRunWTile32): same numbers, different addresses.  The
     plan with every N % 256 == 0 bf16 layer switched to that layout must give bit-identical results on the host simulator."""
