@@ -90,48 +90,47 @@ def si_sdr(reference, estimation, eps=1e-8):
 MEL_SCALES = [16, 32, 64]        # cfg.perceptual == 'LMS' (tools_for_loss.py:114-115)
 
 
-def freqToMel(freq):
-    return 1127.01048 * math.log(1 + freq / 700.0)
+_MEL_K = 1127.01048
 
 
-def melToFreq(mel):
-    return 700 * (math.exp(mel / 1127.01048) - 1)
+def _mel_edges(nb, nbins):
+    """FFT-bin edges of nb triangular mel bands over [0, fs/2].  Parity detail (reference tools_for_loss.py:140-165, pinned by
+    tests/golden/*lms*): the nb + 2 band centres live in a float32 array, are mapped mel -> Hz one element at a time and floored
+    to a bin index through that float32 array, so the edges are what float32 rounding makes them, not the exact ones."""
+    top = _MEL_K * math.log(1 + (cfg.fs / 2) / 700.0)
+    pts = np.arange(nb + 2).astype(np.float32) * top / (nb + 1) + 0.0
+    for i in range(nb + 2):
+        pts[i] = 700 * (math.exp(pts[i] / _MEL_K) - 1)
+        pts[i] = math.floor(nbins * pts[i] / (cfg.fs / 2))
+    return pts.astype(np.int64)
 
 
-def melFilterBank(numCoeffs, fftSize=None):
-    """Host-side constant, same construction as the reference (float32 centre array, floor-binned edges; :140-184)."""
-    maxHz = cfg.fs / 2
-    numFFTBins = cfg.win_len if fftSize is None else int(fftSize / 2) + 1
-    maxMel, minMel = freqToMel(maxHz), freqToMel(0)
-    centers = np.array(range(numCoeffs + 2)).astype(np.float32) * (maxMel - minMel) / (numCoeffs + 1) + minMel
-    for i in range(numCoeffs + 2):
-        centers[i] = melToFreq(centers[i])
-        centers[i] = math.floor(numFFTBins * centers[i] / maxHz)
-    mat = np.zeros((numCoeffs, numFFTBins))
-    for i in range(1, numCoeffs + 1):
-        s, m, e = int(centers[i - 1]), int(centers[i]), int(centers[i + 1])
-        for j in range(s, m):
-            mat[i - 1][j] = (float(j) - s) / (m - s)
-        for j in range(m, e):
-            mat[i - 1][j] = 1 - ((float(j) - m) / (e - m))
-    return mat
+def _band_table(nfft):
+    """Sparse form of the three mel banks (MEL_SCALES): one row (first bin, taps, offset into the tap array, scale index) per band
+    and the tap weights: rising edge (j - s) / (m - s) on [s, m), falling edge 1 - (j - m) / (e - m) on [m, e)."""
+    nbins = cfg.win_len if nfft is None else int(nfft / 2) + 1
+    rows, taps = [], []
+    for si, nb in enumerate(MEL_SCALES):
+        ed = _mel_edges(nb, nbins)
+        for s_, m_, e_ in zip(ed[:-2], ed[1:-1], ed[2:]):
+            up = (np.arange(s_, m_, dtype=np.float64) - s_) / max(m_ - s_, 1)
+            down = 1 - (np.arange(m_, e_, dtype=np.float64) - m_) / max(e_ - m_, 1)
+            w = np.concatenate([up, down]).astype(np.float32)
+            nz = np.nonzero(w)[0]                                    # the first rising tap is 0: bands start at their first non-zero bin
+            lo, n = (int(nz[0]), int(nz[-1] - nz[0] + 1)) if len(nz) else (0, 0)
+            rows.append([int(s_) + lo if n else 0, n, len(taps), si])
+            taps.extend(w[lo:lo + n].tolist())
+    return rows, taps
 
 
 _BANK_CACHE = {}
 
 
 def _banks(device, nfft):
-    """Sparse (start, taps, offset, scale) table + tap weights of the three mel banks on `device`."""
+    """(band rows, tap weights, number of bands, bands per scale) of the three mel banks on `device`."""
     key = (str(device), nfft)
     if key not in _BANK_CACHE:
-        bands, weights = [], []
-        for si, nb in enumerate(MEL_SCALES):
-            fb = melFilterBank(nb, nfft).astype(np.float32)          # [nb, NF]
-            for n in range(nb):
-                nz = np.nonzero(fb[n])[0]
-                st, ln = (int(nz[0]), int(nz[-1] - nz[0] + 1)) if len(nz) else (0, 0)
-                bands.append([st, ln, len(weights), si])
-                weights.extend(fb[n, st:st + ln].tolist())
+        bands, weights = _band_table(nfft)
         _BANK_CACHE[key] = (torch.tensor(bands, dtype=torch.int32, device=device).contiguous(),
                             torch.tensor(weights or [0.0], dtype=torch.float32, device=device), len(bands),
                             (C.c_int32 * len(MEL_SCALES))(*MEL_SCALES))

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Held-out evaluation of the fp32 and bf16 training paths (north_star criterion: PESQ / STOI of the bf16-trained model within
++-0.02 of the fp32-trained one).
+
+Two legs, because the reference's PESQ.so (its only PESQ implementation, x86 binary without source) cannot travel to the GPU box:
+
+  GPU box:    python tools/heldout_eval.py train --steps 400 --out gpurun_out/heldout
+      trains DCCRN (default sizes, mask E, SI-SNR) from the SAME initial weights on the SAME synthetic speech-like stream once
+      with fp32 activations and once with bf16 (config.act_dtype), enhances a held-out set with both models (eval mode) and
+      writes clean / noisy / enhanced_fp32 / enhanced_bf16 as int16 .npy plus the loss curves.
+  container:  python tools/heldout_eval.py score --dir gpurun_out/heldout --json profiles/r02_heldout_eval.json
+      scores every utterance with the reference's PESQ.so through its own ctypes contract (tools_for_estimate.py:68-84: float64
+      arrays, returns WB MOS-LQO) when /root/reference is present, and with this repo's C++ STOI (tools_for_estimate.cal_stoi).
+
+Synthetic data: there is no corpus in the image.  "Speech" = a harmonic source with a wandering pitch through three slowly moving
+formant resonances, syllable-rate amplitude envelope and pauses; noise = coloured noise + a hum, mixed at 0..15 dB SNR."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+from scipy.signal import lfilter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+FS, L = 16000, 48000
+
+
+def speechlike(rng, n=L):
+    t = np.arange(n) / FS
+    f0 = 110 + 60 * rng.random() + 25 * np.sin(2 * np.pi * (0.7 + rng.random()) * t + rng.random() * 6)
+    ph = 2 * np.pi * np.cumsum(f0) / FS
+    src = sum(np.sin(k * ph) / k for k in range(1, 30))
+    out = np.zeros(n)
+    for fc, bw in ((500 + 300 * rng.random(), 90), (1500 + 600 * rng.random(), 120), (2600 + 500 * rng.random(), 160)):
+        r = np.exp(-np.pi * bw / FS)
+        y = np.empty(n)
+        zi = np.zeros(2)
+        for i in range(0, n, 800):               # two-pole resonator whose centre moves every 50 ms
+            fm = fc * (1 + 0.15 * np.sin(2 * np.pi * 1.7 * t[i] + fc))
+            y[i:i + 800], zi = lfilter([1.0], [1.0, -2 * r * np.cos(2 * np.pi * fm / FS), r * r], src[i:i + 800], zi=zi)
+        out += y / (np.abs(y).max() + 1e-9)
+    env = np.clip(np.sin(2 * np.pi * (3.5 + rng.random()) * t + rng.random() * 6), 0, None) ** 0.7
+    gate = (np.sin(2 * np.pi * (0.45 + 0.2 * rng.random()) * t + rng.random() * 6) > -0.55).astype(float)
+    gate = np.convolve(gate, np.hanning(801) / np.hanning(801).sum(), mode="same")
+    s = out * env * gate
+    return 0.25 * s / (np.abs(s).max() + 1e-9)
+
+
+def noise(rng, n=L):
+    w = rng.standard_normal(n + 64)
+    k = np.exp(-np.arange(64) / (2 + 20 * rng.random()))
+    c = np.convolve(w, k, mode="valid")[:n]
+    c = c / (c.std() + 1e-9)
+    hum = 0.3 * np.sin(2 * np.pi * (50 + 900 * rng.random()) * np.arange(n) / FS)
+    return c + hum
+
+
+def make_set(seed, count):
+    rng = np.random.default_rng(seed)
+    clean, noisy = [], []
+    for _ in range(count):
+        s, v = speechlike(rng), noise(rng)
+        snr = 15 * rng.random()
+        v = v * np.sqrt((s ** 2).mean() / ((v ** 2).mean() * 10 ** (snr / 10)))
+        clean.append(s)
+        noisy.append(np.clip(s + v, -1, 1))
+    return np.stack(clean).astype(np.float32), np.stack(noisy).astype(np.float32)
+
+
+def train(args):
+    import torch
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.optim import Adam
+    os.makedirs(args.out, exist_ok=True)
+    pool_c, pool_n = make_set(1, args.pool)
+    held_c, held_n = make_set(2, args.heldout)
+    B = args.batch
+    res = {}
+    init = None
+    # third leg: fp32 again with another batch order - the run-to-run spread of the metric, against which the bf16 delta is read
+    for tag in ("fp32", "bf16", "fp32_rerun"):
+        dt = tag.split("_")[0]
+        cfg.masking_mode, cfg.loss, cfg.act_dtype = "E", "SI-SNR", dt
+        torch.manual_seed(0)
+        m = models.DCCRN(rnn_units=cfg.rnn_units, masking_mode="E").to("cuda").train()
+        if init is None:
+            init = {k: v.clone() for k, v in m.state_dict().items()}
+        else:
+            m.load_state_dict(init)
+        opt = Adam(m.parameters(), lr=args.lr)
+        order = np.random.default_rng(4 if tag.endswith("rerun") else 3)
+        losses = []
+        for step in range(args.steps):
+            idx = order.integers(0, args.pool, B)
+            x, y = torch.from_numpy(pool_n[idx]).cuda(), torch.from_numpy(pool_c[idx]).cuda()
+            loss = m.train_step(x, y, opt)
+            if step % 20 == 0 or step == args.steps - 1:
+                losses.append((step, float(loss)))
+        m.eval()
+        outs = []
+        with torch.no_grad():
+            for i in range(0, args.heldout, B):
+                o = m(torch.from_numpy(held_n[i:i + B]).cuda())
+                outs.append((o[2] if isinstance(o, (tuple, list)) else o).float().cpu().numpy())
+        enh = np.concatenate(outs)
+        np.save(os.path.join(args.out, f"enhanced_{tag}.npy"), np.round(np.clip(enh, -1, 1) * 32767).astype(np.int16))
+        res[tag] = losses
+        print(tag, "loss", losses[0], "->", losses[-1], flush=True)
+    np.save(os.path.join(args.out, "clean.npy"), np.round(held_c * 32767).astype(np.int16))
+    np.save(os.path.join(args.out, "noisy.npy"), np.round(held_n * 32767).astype(np.int16))
+    json.dump(dict(steps=args.steps, batch=B, lr=args.lr, pool=args.pool, heldout=args.heldout, losses=res), open(os.path.join(args.out, "train_log.json"), "w"))
+
+
+def score(args):
+    import ctypes
+    import sefd_amd  # noqa: F401
+    from sefd_amd import tools_for_estimate as est
+    ld = lambda n: np.load(os.path.join(args.dir, n)).astype(np.float64)
+    clean, noisy, e32, e16, e32b = ld("clean.npy"), ld("noisy.npy"), ld("enhanced_fp32.npy"), ld("enhanced_bf16.npy"), ld("enhanced_fp32_rerun.npy")
+    pesq = None
+    so = "/root/reference/PESQ.so"
+    if os.path.exists(so):
+        dll = ctypes.CDLL(so)
+        dll.pesq.restype = ctypes.c_double
+
+        def pesq(ref, deg):                      # the reference's own calling convention (tools_for_estimate.py:68-75)
+            ref, deg = np.ascontiguousarray(ref, np.double), np.ascontiguousarray(deg, np.double)
+            return float(dll.pesq(ctypes.c_void_p(ref.ctypes.data), ctypes.c_void_p(deg.ctypes.data), len(ref), len(deg)))
+    rows = []
+    for i in range(len(clean)):
+        r = dict(utt=i)
+        for name, sig in (("noisy", noisy), ("fp32", e32), ("bf16", e16), ("fp32_rerun", e32b)):
+            r["stoi_" + name] = float(est.cal_stoi([sig[i] / 32768.0], [clean[i] / 32768.0])[0])
+            if pesq:
+                r["pesq_" + name] = pesq(clean[i], sig[i])
+        rows.append(r)
+    mean = {k: float(np.mean([r[k] for r in rows])) for k in rows[0] if k != "utt"}
+    out = dict(scorer_pesq="reference PESQ.so (WB MOS-LQO), run in the build container" if pesq else None,
+               scorer_stoi="sefd_stoi_batch (C++ restatement of the published STOI, pystoi conventions; unpinned)",
+               n_utts=len(rows), mean=mean,
+               delta_bf16_minus_fp32={k: mean[k + "_bf16"] - mean[k + "_fp32"] for k in (("pesq", "stoi") if pesq else ("stoi",))},
+               delta_fp32_rerun_minus_fp32={k: mean[k + "_fp32_rerun"] - mean[k + "_fp32"] for k in (("pesq", "stoi") if pesq else ("stoi",))},
+               per_utt_abs_delta_max={k: float(max(abs(r[k + "_bf16"] - r[k + "_fp32"]) for r in rows)) for k in (("pesq", "stoi") if pesq else ("stoi",))},
+               train=json.load(open(os.path.join(args.dir, "train_log.json"))), rows=rows)
+    json.dump(out, open(args.json, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("mean", "delta_bf16_minus_fp32", "delta_fp32_rerun_minus_fp32", "per_utt_abs_delta_max")}, indent=1))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    t = sub.add_parser("train")
+    t.add_argument("--steps", type=int, default=400)
+    t.add_argument("--batch", type=int, default=16)
+    t.add_argument("--lr", type=float, default=1e-3)
+    t.add_argument("--pool", type=int, default=96)
+    t.add_argument("--heldout", type=int, default=16)
+    t.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "heldout"))
+    s = sub.add_parser("score")
+    s.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out", "heldout"))
+    s.add_argument("--json", default=os.path.join(ROOT, "profiles", "r02_heldout_eval.json"))
+    a = ap.parse_args()
+    train(a) if a.cmd == "train" else score(a)
