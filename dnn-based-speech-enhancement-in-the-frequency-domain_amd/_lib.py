@@ -10,7 +10,7 @@ class ModelConfig(C.Structure):
     """Mirror of `sefd_model_config` (include/sefd.h)."""
     _fields_ = [("model", C.c_int32), ("B", C.c_int32), ("L", C.c_int32),
                 ("win_len", C.c_int32), ("hop", C.c_int32), ("fft_len", C.c_int32),
-                ("n_layers", C.c_int32), ("kernel_num", C.c_int32 * 8),
+                ("n_layers", C.c_int32), ("kernel_num", C.c_int32 * 12),
                 ("rnn_layers", C.c_int32), ("rnn_units", C.c_int32), ("mask_mode", C.c_int32),
                 ("lstm_complex", C.c_int32), ("skip", C.c_int32), ("act_dtype", C.c_int32),
                 ("kernel_size", C.c_int32), ("training", C.c_int32), ("bn_world", C.c_int32), ("grad_buckets", C.c_int32)]

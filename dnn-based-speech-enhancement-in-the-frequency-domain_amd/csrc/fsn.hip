@@ -6,6 +6,8 @@
 
 namespace sefd {
 
+constexpr float kNormEps = 1.1920928955078125e-07f;    // EPSILON = np.finfo(np.float32).eps (tools_for_model.py: cumulative norms)
+
 static inline int gridn(int64_t n, int cap = 16384) { int64_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 #define GSL(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
@@ -45,6 +47,50 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const LstmCell d, const A
     gr[ci] = ig; gr[cf] = fg; gr[cg] = gg; gr[co] = og;
     c[a.o[1] + j] = cn;
     st_elem(h, d.hdt, a.o[2] + j, og * tanhf_(cn));
+  }
+}
+
+// GRU cell, one time step (LstmCell kind 1)
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const LstmCell d, const ArenaBases ab) {
+  float* g = reinterpret_cast<float*>(rp(ab, d.gates));
+  const float* gh = reinterpret_cast<const float*>(rp(ab, d.gh));
+  const char* hp = d.first ? nullptr : rp(ab, d.c_prev);
+  char* h = rp(ab, d.h);
+  const int H = d.H;
+  GSL(i, d.rows * H) {
+    const int64_t r = i / H;
+    const int j = (int)(i - r * H);
+    float* gr = g + r * 4 * H;
+    const float* hr = gh + r * 3 * H;
+    const float rg = sigmoidf_(gr[j] + hr[j]), zg = sigmoidf_(gr[H + j] + hr[H + j]);
+    const float hn = hr[2 * H + j];
+    const float ng = tanhf_(gr[2 * H + j] + rg * hn);
+    const float hprev = hp ? ld_elem(hp, d.hdt, r * H + j) : 0.f;
+    gr[j] = rg; gr[H + j] = zg; gr[2 * H + j] = ng; gr[3 * H + j] = hn;
+    st_elem(h, d.hdt, r * H + j, (1.f - zg) * ng + zg * hprev);
+  }
+}
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const LstmCell d, const ArenaBases ab) {
+  const float* g = reinterpret_cast<const float*>(rp(ab, d.gates));
+  const char* hp = d.c_prev.arena >= 0 ? rp(ab, d.c_prev) : nullptr;
+  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
+  float* dhp = d.dc.arena >= 0 ? reinterpret_cast<float*>(rp(ab, d.dc)) : nullptr;
+  char* dgi = rp(ab, d.dgates);
+  char* dgh = rp(ab, d.gh);
+  const int H = d.H;
+  GSL(i, d.rows * H) {
+    const int64_t r = i / H;
+    const int j = (int)(i - r * H);
+    const float* gr = g + r * 4 * H;
+    const float rg = gr[j], zg = gr[H + j], ng = gr[2 * H + j], hn = gr[3 * H + j];
+    const float hprev = hp ? ld_elem(hp, d.hdt, r * H + j) : 0.f;
+    const float dht = dh[r * H + j];
+    const float dn = dht * (1.f - zg) * (1.f - ng * ng);
+    const float dz = dht * (hprev - ng) * zg * (1.f - zg);
+    const float dr = dn * hn * rg * (1.f - rg);
+    st_elem(dgi, d.gdt, r * 3 * H + j, dr); st_elem(dgi, d.gdt, r * 3 * H + H + j, dz); st_elem(dgi, d.gdt, r * 3 * H + 2 * H + j, dn);
+    st_elem(dgh, d.gdt, r * 3 * H + j, dr); st_elem(dgh, d.gdt, r * 3 * H + H + j, dz); st_elem(dgh, d.gdt, r * 3 * H + 2 * H + j, dn * rg);
+    if (dhp) dhp[r * H + j] += dht * zg;
   }
 }
 
@@ -126,7 +172,18 @@ __global__ __launch_bounds__(256) void fsn_scale_kernel(const Fsn d, const Arena
     const int f = (int)(i % d.FP);
     const int64_t tb = i / d.FP;
     const int b = (int)(tb % d.B);
-    st_elem(out, d.dt, i, f < d.F ? mt[tb * d.F + f] / (mu[b] + 1e-5f) : 0.f);
+    float v = 0.f;
+    if (f < d.F) {
+      const float x = mt[tb * d.F + f];
+      if (d.mode == 0) v = x / (mu[b] + 1e-5f);
+      else {
+        const float* stt = reinterpret_cast<const float*>(rp(ab, d.stat));
+        if (d.mode == 2) v = (x - stt[b]) / (stt[d.B + b] + 1e-5f);
+        else if (d.mode == 1) v = x / (stt[tb * 2] + kNormEps);
+        else v = (x - stt[tb * 2]) / stt[tb * 2 + 1];
+      }
+    }
+    st_elem(out, d.dt, i, v);
   }
 }
 // means: sums [B][nper] -> aux2[B] = sum / count
@@ -170,7 +227,16 @@ __global__ __launch_bounds__(256) void fsn_sbbuild_kernel(const Fsn d, const Are
     const int f = (int)(r % d.F);
     const int64_t tb = r / d.F;
     const int b = (int)(tb % d.B), t = (int)(tb / d.B);
-    st_elem(out, d.dt, i, sb_raw(d, mt, fbo, t, b, f, k) / (mu[b] + 1e-5f));
+    const float x = sb_raw(d, mt, fbo, t, b, f, k);
+    float v;
+    if (d.mode == 0) v = x / (mu[b] + 1e-5f);
+    else {
+      const float* stt = reinterpret_cast<const float*>(rp(ab, d.stat));
+      if (d.mode == 2) v = (x - stt[b]) / (stt[d.B + b] + 1e-5f);
+      else if (d.mode == 1) v = x / (stt[r * 2] + kNormEps);
+      else v = (x - stt[r * 2]) / stt[r * 2 + 1];
+    }
+    st_elem(out, d.dt, i, v);
   }
 }
 __global__ __launch_bounds__(256) void fsn_out_kernel(const Fsn d, const ArenaBases ab) {      // crm [B][F][T][2] <- sbo [TP][B*F][2]
@@ -227,14 +293,153 @@ __global__ __launch_bounds__(256) void fsn_sbbwd_apply_kernel(const Fsn d, const
     const int b = (int)(tb % d.B);
     float v = 0.f;
     if (f < d.F) {
-      const float den = mu[b] + 1e-5f;
-      v = dsb[(tb * d.F + f) * W + d.NB] / den - Sm[b] / den;
+      if (d.mode == 0) {
+        const float den = mu[b] + 1e-5f;
+        v = dsb[(tb * d.F + f) * W + d.NB] / den - Sm[b] / den;
+      } else {
+        v = dsb[tb * d.F + f];                                   // FSN_NORMBWD already went through the normalisation
+      }
       const float y = fbo[i];
       if (d.act == 1) v = y > 0.f ? v : 0.f;                     // ReLU
       else if (d.act == 2) v *= (1.f - y * y);                   // Tanh
       else if (d.act == 3) v = (y > 0.f && y < 6.f) ? v : 0.f;   // ReLU6
     }
     st_elem(out, d.dt, i, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- other norm_type choices
+// block sum of doubles for 64- or 256-thread blocks (result valid in every thread)
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+// value j of frame t of row (b, f): src 0 -> mag_t[t][b][j] (f unused), src 1 -> the un-normalised sub-band input
+__device__ __forceinline__ float norm_val(const Fsn& d, const float* mt, const float* fbo, int t, int b, int f, int j) {
+  return d.src ? sb_raw(d, mt, fbo, t, b, f, j) : mt[((int64_t)t * d.B + b) * d.F + j];
+}
+// mode 2: one workgroup per utterance, (mean, unbiased std) over all its values (torch.mean / torch.std, tools_for_model.py:1047-1061)
+__global__ __launch_bounds__(256) void fsn_normstat_utt_kernel(const Fsn d, const ArenaBases ab) {
+  const float* mt = reinterpret_cast<const float*>(rp(ab, d.in));
+  const float* fbo = d.src ? reinterpret_cast<const float*>(rp(ab, d.aux)) : nullptr;
+  float* st = reinterpret_cast<float*>(rp(ab, d.stat));
+  __shared__ double sh[4];
+  const int b = blockIdx.x, W = d.src ? d.NB + 1 : d.F, nf = d.src ? d.F : 1;
+  const int64_t n = (int64_t)d.TP * nf * W;
+  double s = 0, q = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int j = (int)(i % W);
+    const int64_t r = i / W;
+    const float x = norm_val(d, mt, fbo, (int)(r / nf), b, (int)(r % nf), j);
+    s += x; q += (double)x * x;
+  }
+  s = block_sum(s, sh); q = block_sum(q, sh);
+  if (threadIdx.x == 0) {
+    const double mu = s / n, var = (q - n * mu * mu) / (n - 1);
+    st[b] = (float)mu;
+    st[d.B + b] = (float)sqrt(var > 0 ? var : 0.0);
+  }
+}
+// modes 1 / 3: one workgroup per row (grid (F or 1, B)), frames in order: running mean and sqrt(running variance + eps) (:1014-1044, 1064-1104)
+__global__ void fsn_normstat_cum_kernel(const Fsn d, const ArenaBases ab) {
+  const float* mt = reinterpret_cast<const float*>(rp(ab, d.in));
+  const float* fbo = d.src ? reinterpret_cast<const float*>(rp(ab, d.aux)) : nullptr;
+  float* st = reinterpret_cast<float*>(rp(ab, d.stat));
+  __shared__ double sh[4];
+  const int f = blockIdx.x, b = blockIdx.y, W = d.src ? d.NB + 1 : d.F;
+  const int64_t rows = d.src ? (int64_t)d.B * d.F : d.B, row = d.src ? (int64_t)b * d.F + f : b;
+  double cs = 0, cq = 0;
+  for (int t = 0; t < d.TP; ++t) {
+    double s = 0, q = 0;
+    for (int j = threadIdx.x; j < W; j += blockDim.x) { const float x = norm_val(d, mt, fbo, t, b, f, j); s += x; q += (double)x * x; }
+    cs += block_sum(s, sh); cq += block_sum(q, sh);
+    if (threadIdx.x == 0) {
+      const double n = (double)W * (t + 1), m = cs / n;
+      st[((int64_t)t * rows + row) * 2] = (float)m;
+      st[((int64_t)t * rows + row) * 2 + 1] = d.mode == 3 ? (float)sqrt((cq - 2 * m * cs) / n + m * m + (double)kNormEps) : 0.f;
+    }
+  }
+}
+// backward of the sub-band normalisation w.r.t. its full-band column k = NB.  in = d_sbin fp32 [TP][B*F][W], aux2 = sb_in (dtype dt),
+// aux = fbo (raw full-band output, fp32 [TP][B][FP]), stat as above, out = fp32 [TP][B][F].
+// modes 1 / 3, one wave per row, frames last to first (suffix sums of the statistics' gradients):
+//   cumulative_laplace : dx_t = g_t / (m_t + eps) - sum_{u >= t} S_u / ((m_u + eps) n_u)                          S_u = sum_k g y at frame u
+//   cumulative_layer   : dx_t = g_t / sd_t - sum_{u >= t} [ G_u / (n_u sd_u) + (x_t - m_u) S_u / (n_u sd_u^2) ]   G_u = sum_k g
+__global__ __launch_bounds__(64) void fsn_normbwd_cum_kernel(const Fsn d, const ArenaBases ab) {
+  const float* dsb = reinterpret_cast<const float*>(rp(ab, d.in));
+  const char* sb = rp(ab, d.aux2);
+  const float* fbo = reinterpret_cast<const float*>(rp(ab, d.aux));
+  const float* st = reinterpret_cast<const float*>(rp(ab, d.stat));
+  float* out = reinterpret_cast<float*>(rp(ab, d.out));
+  const int f = blockIdx.x, b = blockIdx.y, W = d.NB + 1, k = threadIdx.x;
+  const int64_t rows = (int64_t)d.B * d.F, row = (int64_t)b * d.F + f;
+  double accA = 0, accB = 0, accBM = 0;
+  for (int t = d.TP - 1; t >= 0; --t) {
+    const int64_t o = ((int64_t)t * rows + row) * W;
+    const float g = k < W ? dsb[o + k] : 0.f, y = k < W ? ld_elem(sb, d.dt, o + k) : 0.f;
+    double G = g, S = (double)g * y;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { G += __shfl_xor(G, sft); S += __shfl_xor(S, sft); }
+    if (k == 0) {
+      const double m = st[((int64_t)t * rows + row) * 2], sd = st[((int64_t)t * rows + row) * 2 + 1], n = (double)W * (t + 1);
+      const double gk = dsb[o + d.NB];
+      double v;
+      if (d.mode == 1) {
+        const double den = m + (double)kNormEps;
+        accA += S / (den * n);
+        v = gk / den - accA;
+      } else {
+        const double bb = S / (n * sd * sd);
+        accA += G / (n * sd); accB += bb; accBM += bb * m;
+        v = gk / sd - accA - (double)fbo[((int64_t)t * d.B + b) * d.FP + f] * accB + accBM;
+      }
+      out[((int64_t)t * d.B + b) * d.F + f] = (float)v;
+    }
+  }
+}
+// mode 2 (offline_gaussian_norm): dx = (g - G_b / N) / (sd_b + 1e-5) - y S_b / ((N - 1) sd_b);  sums[2][B][F] partial (S, G) per (b, f)
+__global__ __launch_bounds__(256) void fsn_normbwd_utt_part_kernel(const Fsn d, const ArenaBases ab) {
+  const float* dsb = reinterpret_cast<const float*>(rp(ab, d.in));
+  const char* sb = rp(ab, d.aux2);
+  float* part = reinterpret_cast<float*>(rp(ab, d.sums));
+  __shared__ double sh[4];
+  const int f = blockIdx.x, b = blockIdx.y, W = d.NB + 1;
+  double S = 0, G = 0;
+  for (int i = threadIdx.x; i < d.TP * W; i += 256) {
+    const int64_t o = (((int64_t)(i / W) * d.B + b) * d.F + f) * W + i % W;
+    const float g = dsb[o];
+    G += g; S += (double)g * ld_elem(sb, d.dt, o);
+  }
+  S = block_sum(S, sh); G = block_sum(G, sh);
+  if (threadIdx.x == 0) { part[b * d.F + f] = (float)S; part[(d.B + b) * d.F + f] = (float)G; }
+}
+__global__ __launch_bounds__(256) void fsn_normbwd_utt_kernel(const Fsn d, const ArenaBases ab) {
+  const float* dsb = reinterpret_cast<const float*>(rp(ab, d.in));
+  const char* sb = rp(ab, d.aux2);
+  const float* part = reinterpret_cast<const float*>(rp(ab, d.sums));
+  const float* st = reinterpret_cast<const float*>(rp(ab, d.stat));
+  float* out = reinterpret_cast<float*>(rp(ab, d.out));
+  __shared__ double tot[2];
+  const int b = blockIdx.y, W = d.NB + 1;
+  if (threadIdx.x < 2) {                                        // serial sum of F partials: deterministic, tiny
+    double s = 0;
+    for (int f = 0; f < d.F; ++f) s += part[(threadIdx.x * d.B + b) * d.F + f];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const double N = (double)d.F * W * d.TP, sdv = st[d.B + b], sden = sdv + 1e-5;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < (int64_t)d.TP * d.F; i += (int64_t)gridDim.x * 256) {
+    const int f = (int)(i % d.F), t = (int)(i / d.F);
+    const int64_t o = (((int64_t)t * d.B + b) * d.F + f) * W + d.NB;
+    out[((int64_t)t * d.B + b) * d.F + f] = (float)((dsb[o] - tot[1] / N) / sden - (double)ld_elem(sb, d.dt, o) * tot[0] / ((N - 1) * sdv));
   }
 }
 
@@ -255,8 +460,14 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_STFT_FFT: launch_stft_fft(op.fft, ab, st); break;
     case OP_ISTFT_FFT: launch_istft_fft(op.ifft, ab, st); break;
     case OP_REFLECTPAD: hipLaunchKernelGGL(reflectpad_kernel, dim3(gridn((int64_t)op.rpad.B * (op.rpad.L + 2 * op.rpad.pad))), dim3(256), 0, st, op.rpad, ab); break;
-    case OP_CELL_FWD: hipLaunchKernelGGL(cell_fwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
-    case OP_CELL_BWD: hipLaunchKernelGGL(cell_bwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab); break;
+    case OP_CELL_FWD:
+      if (op.cell.kind == 1) hipLaunchKernelGGL(gru_fwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab);
+      else hipLaunchKernelGGL(cell_fwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab);
+      break;
+    case OP_CELL_BWD:
+      if (op.cell.kind == 1) hipLaunchKernelGGL(gru_bwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab);
+      else hipLaunchKernelGGL(cell_bwd_kernel, dim3(gridn(op.cell.rows * op.cell.H)), dim3(256), 0, st, op.cell, ab);
+      break;
     case OP_DROPOUT_FWD:
     case OP_DROPOUT_BWD: hipLaunchKernelGGL(dropout_kernel, dim3(gridn(op.drop.n)), dim3(256), 0, st, op.drop, ab); break;
     case OP_FSN_IN: {
@@ -279,6 +490,23 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
       const Fsn& d = op.fsn;
       hipLaunchKernelGGL(fsn_sbbwd_sum_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
       hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
+      break;
+    }
+    case OP_FSN_NORMSTAT: {
+      const Fsn& d = op.fsn;
+      if (d.mode == 2) hipLaunchKernelGGL(fsn_normstat_utt_kernel, dim3(d.B), dim3(256), 0, st, d, ab);
+      else if (d.src) hipLaunchKernelGGL(fsn_normstat_cum_kernel, dim3(d.F, d.B), dim3(64), 0, st, d, ab);
+      else hipLaunchKernelGGL(fsn_normstat_cum_kernel, dim3(1, d.B), dim3(256), 0, st, d, ab);
+      break;
+    }
+    case OP_FSN_NORMBWD: {
+      const Fsn& d = op.fsn;
+      if (d.mode == 2) {
+        hipLaunchKernelGGL(fsn_normbwd_utt_part_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
+        hipLaunchKernelGGL(fsn_normbwd_utt_kernel, dim3(64, d.B), dim3(256), 0, st, d, ab);
+      } else {
+        hipLaunchKernelGGL(fsn_normbwd_cum_kernel, dim3(d.F, d.B), dim3(64), 0, st, d, ab);
+      }
       break;
     }
     case OP_FSN_SBBWD_APPLY: hipLaunchKernelGGL(fsn_sbbwd_apply_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.FP)), dim3(256), 0, st, op.fsn, ab); break;

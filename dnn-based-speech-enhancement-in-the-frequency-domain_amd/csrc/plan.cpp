@@ -2072,6 +2072,10 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   const int nsb = cfg.kernel_num[0], nfb = cfg.kernel_num[1], LA = cfg.kernel_num[2];
   const int Hf = cfg.kernel_num[3], Hs = cfg.kernel_num[4], actf = cfg.kernel_num[5], acts = cfg.kernel_num[6];
   const float keep = cfg.training ? cfg.kernel_num[7] / 1000.f : 1.f;
+  const bool gru = cfg.kernel_num[8] == 1;        // cfg.sequence_model: nn.GRU instead of nn.LSTM (tools_for_model.py:739-756)
+  const int nmode = cfg.kernel_num[9];            // cfg.norm_type (sefd_desc.h struct Fsn): 0 offline_laplace ... 3 cumulative_layer_norm
+  if (nmode < 0 || nmode > 3) { P->error = "FullSubNet: unknown norm_type"; return P; }
+  const int NG = gru ? 3 : 4;                     // gate blocks of the recurrent weights
   const int adt = cfg.act_dtype;
   const int TP = T + LA, NB = 2 * nsb + 1, W = NB + 1;
   const int FP = (int)rup(F, 8);
@@ -2084,10 +2088,10 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   for (auto& nt : nets) {
     for (int l = 0; l < 2; ++l) {
       const std::string p = nt.name + ".sequence_model.";
-      b.add_param(p + "weight_ih_l" + std::to_string(l), {4 * nt.H, l == 0 ? nt.I : nt.H}, true);
-      b.add_param(p + "weight_hh_l" + std::to_string(l), {4 * nt.H, nt.H}, true);
-      b.add_param(p + "bias_ih_l" + std::to_string(l), {4 * nt.H}, true);
-      b.add_param(p + "bias_hh_l" + std::to_string(l), {4 * nt.H}, true);
+      b.add_param(p + "weight_ih_l" + std::to_string(l), {NG * nt.H, l == 0 ? nt.I : nt.H}, true);
+      b.add_param(p + "weight_hh_l" + std::to_string(l), {NG * nt.H, nt.H}, true);
+      b.add_param(p + "bias_ih_l" + std::to_string(l), {NG * nt.H}, true);
+      b.add_param(p + "bias_hh_l" + std::to_string(l), {NG * nt.H}, true);
     }
     b.add_param(nt.name + ".fc_output_layer.weight", {nt.O, nt.H}, true);
     b.add_param(nt.name + ".fc_output_layer.bias", {nt.O}, true);
@@ -2101,7 +2105,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   std::vector<Op>& Fw = P->fwd;
   std::vector<Op>& R = P->bwd;
 
-  auto fsn0 = [&]() { Fsn f; std::memset(&f, 0, sizeof(f)); f.in = f.out = f.aux = f.aux2 = f.sums = b.none();
+  auto fsn0 = [&]() { Fsn f; std::memset(&f, 0, sizeof(f)); f.in = f.out = f.aux = f.aux2 = f.sums = f.stat = b.none();
                       f.B = B; f.F = F; f.T = T; f.TP = TP; f.FP = FP; f.NB = NB; f.LA = LA; f.dt = adt; f.act = actf; return f; };
   // time-major GEMM over all steps: rows (t, r), source [TP][rows][feat]
   auto seq_gemm = [&](Ptr x, int xdt, int64_t rows, int feat, int off, int len, int N, int ydt) {
@@ -2136,10 +2140,14 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   Ptr mu_fb = b.ws("mu_fb", B, DT_F32);
   Ptr fb_in = b.ws("fb_in", (int64_t)TP * B * FP, adt);
   { Fsn f = fsn0(); f.in = io_mag; f.out = mag_t; f.sums = sum_fb; f.aux2 = mu_fb; b.push(Fw, OP_FSN_IN, 1).fsn = f; }
-  { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
+  Ptr st_fb = b.none(), st_sb = b.none();
+  if (nmode == 2) { st_fb = b.ws("stat_fb", 2 * B, DT_F32); st_sb = b.ws("stat_sb", 2 * B, DT_F32); }
+  else if (nmode) { st_fb = b.ws("stat_fb", (int64_t)TP * B * 2, DT_F32); st_sb = b.ws("stat_sb", (int64_t)TP * B * F * 2, DT_F32); }
+  if (nmode) { Fsn f = fsn0(); f.in = mag_t; f.stat = st_fb; f.mode = nmode; f.src = 0; b.push(Fw, OP_FSN_NORMSTAT, 2).fsn = f; }
+  { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2154,11 +2162,12 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     L.h = b.ws(L.nm + ".h", (int64_t)TP * rows * H, adt);
     // bf16 mode, 128 < H <= 512: the whole recurrence is ONE launch of the cluster kernels (lstm_cluster.hip) on the time-major
     // slabs, gate columns unit-major (sefd_desc.h gate_col); otherwise one GEMM + one cell launch per frame, gate-major columns
-    L.cluster = adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && getenv("SEFD_LSTM_STEPPED") == nullptr;
+    L.cluster = !gru && adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && getenv("SEFD_LSTM_STEPPED") == nullptr;
     const bool um = L.cluster;
-    RunGemm g = seq_gemm(x, adt, rows, xfeat, 0, xlen, 4 * H, DT_F32);
+    RunGemm g = seq_gemm(x, adt, rows, xfeat, 0, xlen, NG * H, DT_F32);
     L.cgx = [=](int nn, int s, int j) -> int32_t { return j < I ? pe(Wih, (int64_t)(um ? gate_torch_row(nn, H) : nn) * I + j, 1) : 0; };
-    L.bgx = [=](int nn, int32_t* o) { const int q = um ? gate_torch_row(nn, H) : nn; o[0] = pe(bih, q, 1); o[1] = pe(bhh, q, 1); };
+    if (gru) L.bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, nn, 1); o[1] = 0; };     // b_hh rides the recurrent GEMM: n = tanh(.. + r * (W_hn h + b_hn))
+    else L.bgx = [=](int nn, int32_t* o) { const int q = um ? gate_torch_row(nn, H) : nn; o[0] = pe(bih, q, 1); o[1] = pe(bhh, q, 1); };
     b.pack_weights(Fw, g, L.cgx, L.nm + ".ih", tag, &L.bgx);
     set_y(g, L.gates, rows, 4 * H, 0);
     b.push(Fw, OP_RUNGEMM, tag).g = g;
@@ -2172,6 +2181,30 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = (int)rows; r.T = TP; r.H = H; r.hdt = adt; r.gdt = DT_F32; r.tmajor = 1;
       b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
       L.rec = Builder::gemm0();
+    } else if (gru) {
+      // per frame: gh = h_{t-1} . W_hh^T + b_hh into one reused [rows][3H] buffer (t = 0 reads a zero slab), then the GRU cell
+      L.gh = b.ws(L.nm + ".gh", rows * 3 * H, DT_F32);
+      L.hzero = b.ws(L.nm + ".h0", rows * H, adt);
+      { Op& m = b.push(Fw, OP_MEMSET, tag); m.ms.dst = L.hzero; m.ms.bytes = rows * H * esize(adt); }
+      RunGemm rec0 = step_gemm(L.hzero, adt, rows, H, 0, 3 * H, L.gh, 3 * H, 0, DT_F32, 0);
+      Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(Whh, (int64_t)nn * H + j, 1); };
+      L.bhh = [=](int nn, int32_t* o) { o[0] = pe(bhh, nn, 1); o[1] = 0; };
+      b.pack_weights(Fw, rec0, chh, L.nm + ".hh", tag, &L.bhh);
+      L.rec = rec0;
+      for (int t = 0; t < TP; ++t) {
+        RunGemm r = rec0;
+        if (t > 0) r.x[0] = b.mk(A_WS, L.h.off + (int64_t)(t - 1) * rows * H * esize(adt));
+        b.push(Fw, OP_RUNGEMM, tag).g = r;
+        LstmCell& cl = b.push(Fw, OP_CELL_FWD, tag).cell;
+        std::memset(&cl, 0, sizeof(cl));
+        cl.gates = b.mk(A_WS, L.gates.off + (int64_t)t * rows * 4 * H * 4);
+        cl.gh = L.gh;
+        cl.c = b.none();
+        cl.c_prev = t > 0 ? b.mk(A_WS, L.h.off + (int64_t)(t - 1) * rows * H * esize(adt)) : b.none();
+        cl.h = b.mk(A_WS, L.h.off + (int64_t)t * rows * H * esize(adt));
+        cl.dh = cl.dc = cl.dgates = b.none();
+        cl.rows = rows; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == 0; cl.kind = 1;
+      }
     } else {
     // recurrent weights, packed once per step list
     RunGemm rec0 = step_gemm(L.h, adt, rows, H, 0, 4 * H, L.gates, 4 * H, 0, DT_F32, kRunAccum);
@@ -2186,6 +2219,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       }
       Op& op = b.push(Fw, OP_CELL_FWD, tag);
       LstmCell& cl = op.cell;
+      cl.kind = 0; cl.gh = b.none();
       cl.gates = b.mk(A_WS, L.gates.off + (int64_t)t * rows * 4 * H * 4);
       cl.c = b.mk(A_WS, L.c.off + (int64_t)t * rows * H * 4);
       cl.c_prev = t > 0 ? b.mk(A_WS, L.c.off + (int64_t)(t - 1) * rows * H * 4) : b.none();
@@ -2232,8 +2266,9 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   Ptr sum_sb = b.ws("sum_sb", (int64_t)B * F, DT_F32);
   Ptr mu_sb = b.ws("mu_sb", B, DT_F32);
   Ptr sb_in = b.ws("sb_in", (int64_t)TP * rs * W, adt);
-  { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.sums = sum_sb; f.aux2 = mu_sb; b.push(Fw, OP_FSN_SBSUM, 200).fsn = f; }
-  { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.sums = mu_sb; f.out = sb_in; b.push(Fw, OP_FSN_SBBUILD, 201).fsn = f; }
+  if (nmode == 0) { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.sums = sum_sb; f.aux2 = mu_sb; b.push(Fw, OP_FSN_SBSUM, 200).fsn = f; }
+  else { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.stat = st_sb; f.mode = nmode; f.src = 1; b.push(Fw, OP_FSN_NORMSTAT, 200).fsn = f; }
+  { Fsn f = fsn0(); f.in = mag_t; f.aux = fbo; f.sums = mu_sb; f.out = sb_in; f.mode = nmode; f.stat = st_sb; b.push(Fw, OP_FSN_SBBUILD, 201).fsn = f; }
   Ptr h2 = lstm_forward("sb_model", 0, 2, sb_in, W, W, rs, Hs, 202);
   Ptr h3 = lstm_forward("sb_model", 1, 3, h2, Hs, Hs, rs, Hs, 203);
   Ptr sbo = b.ws("sbo", (int64_t)TP * rs * 2, DT_F32);
@@ -2245,10 +2280,33 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     auto lstm_backward = [&](LayerRt& L, Ptr dh, bool need_dx, Ptr dx, int dx_ld, int dx_off, int dx_N, int dx_dt, int tag) {
       const int H = L.H;
       const int64_t rows = L.rows;
-      Ptr dgates = b.ws(L.nm + ".dgates", (int64_t)TP * rows * 4 * H, adt);
+      Ptr dgates = b.ws(L.nm + ".dgates", (int64_t)TP * rows * NG * H, adt);
       const ParamInfo* Whh = L.Whh;
       const bool um = L.cluster;
-      if (L.cluster) {
+      Ptr dgh = dgates;                                   // gradient of the recurrent pre-activations: the same slab for the LSTM
+      if (gru) {
+        dgh = b.ws(L.nm + ".dgh", (int64_t)TP * rows * 3 * H, adt);
+        RunGemm rb0 = step_gemm(dgh, adt, rows, 3 * H, 0, H, dh, H, 0, DT_F32, kRunAccum);
+        Builder::Coef cT = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)j * H + nn, 1); };
+        b.pack_weights(R, rb0, cT, L.nm + ".hhT", tag);
+        for (int t = TP - 1; t >= 0; --t) {
+          LstmCell& cl = b.push(R, OP_CELL_BWD, tag).cell;
+          std::memset(&cl, 0, sizeof(cl));
+          cl.gates = b.mk(A_WS, L.gates.off + (int64_t)t * rows * 4 * H * 4);
+          cl.c = cl.h = b.none();
+          cl.c_prev = t > 0 ? b.mk(A_WS, L.h.off + (int64_t)(t - 1) * rows * H * esize(adt)) : b.none();
+          cl.dh = b.mk(A_WS, dh.off + (int64_t)t * rows * H * 4);
+          cl.dc = t > 0 ? b.mk(A_WS, dh.off + (int64_t)(t - 1) * rows * H * 4) : b.none();
+          cl.dgates = b.mk(A_WS, dgates.off + (int64_t)t * rows * 3 * H * esize(adt));
+          cl.gh = b.mk(A_WS, dgh.off + (int64_t)t * rows * 3 * H * esize(adt));
+          cl.rows = rows; cl.H = H; cl.hdt = adt; cl.gdt = adt; cl.first = t == TP - 1; cl.kind = 1;
+          if (t > 0) {
+            RunGemm r = step_gemm(dgh, adt, rows, 3 * H, t, H, dh, H, (int64_t)(t - 1) * rows * H, DT_F32, kRunAccum);
+            r.w = rb0.w;
+            b.push(R, OP_RUNGEMM, tag).g = r;
+          }
+        }
+      } else if (L.cluster) {
         LstmRec r;
         std::memset(&r, 0, sizeof(r));
         r.gx = L.gates; r.gates = L.gates; r.h = L.h; r.c = L.c; r.dh = dh; r.dgates = dgates;
@@ -2282,14 +2340,15 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       // weight gradients over all steps
       RunGemm fw = L.gx;
       fw.ydt = adt;
+      if (gru) set_y(fw, dgates, rows, NG * H, 0);        // the GRU's gradient slab is 3H wide (the forward slab keeps a 4th block for W_hn h + b_hn)
       b.wgrad(R, fw, dgates, L.cgx, tag, &L.bgx);
-      RunGemm fh = seq_gemm(L.h, adt, rows, H, 0, H, 4 * H, adt);
+      RunGemm fh = seq_gemm(L.h, adt, rows, H, 0, H, NG * H, adt);
       fh.seg[0].dt = -1;                                   // h_{t-1}
-      set_y(fh, dgates, rows, 4 * H, 0);
+      set_y(fh, dgh, rows, NG * H, 0);
       Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)(um ? gate_torch_row(nn, H) : nn) * H + j, 1); };
-      b.wgrad(R, fh, dgates, chh, tag, nullptr);
+      b.wgrad(R, fh, dgh, chh, tag, gru ? &L.bhh : nullptr);           // GRU: b_hh belongs to this GEMM (bias "ones" run)
       if (need_dx) {
-        RunGemm g = seq_gemm(dgates, adt, rows, 4 * H, 0, 4 * H, dx_N, dx_dt);
+        RunGemm g = seq_gemm(dgates, adt, rows, NG * H, 0, NG * H, dx_N, dx_dt);
         const Builder::Coef cf = L.cgx;
         Builder::Coef coef = [=](int nn, int s, int j) -> int32_t { return cf(j, 0, nn); };
         b.pack_weights(R, g, coef, L.nm + ".dx", tag);
@@ -2330,8 +2389,16 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     Ptr sumS = b.ws("sum_S", (int64_t)B * F, DT_F32);
     Ptr Sm = b.ws("Sm", B, DT_F32);
     Ptr d_fb = b.ws("d_fb", (int64_t)TP * B * FP, adt);
-    { Fsn f = fsn0(); f.in = d_sbin; f.aux = sb_in; f.sums = sumS; f.aux2 = Sm; b.push(R, OP_FSN_SBBWD_SUM, 201).fsn = f; }
-    { Fsn f = fsn0(); f.in = d_sbin; f.aux = fbo; f.aux2 = mu_sb; f.sums = Sm; f.out = d_fb; b.push(R, OP_FSN_SBBWD_APPLY, 200).fsn = f; }
+    if (nmode == 0) {
+      { Fsn f = fsn0(); f.in = d_sbin; f.aux = sb_in; f.sums = sumS; f.aux2 = Sm; b.push(R, OP_FSN_SBBWD_SUM, 201).fsn = f; }
+      { Fsn f = fsn0(); f.in = d_sbin; f.aux = fbo; f.aux2 = mu_sb; f.sums = Sm; f.out = d_fb; b.push(R, OP_FSN_SBBWD_APPLY, 200).fsn = f; }
+    } else {
+      Ptr dpre = b.ws("d_fb_pre", (int64_t)TP * B * F, DT_F32);
+      Ptr part = b.ws("normbwd_part", (int64_t)2 * B * F, DT_F32);
+      { Fsn f = fsn0(); f.in = d_sbin; f.aux = fbo; f.aux2 = sb_in; f.stat = st_sb; f.sums = part; f.out = dpre; f.mode = nmode; f.src = 1;
+        b.push(R, OP_FSN_NORMBWD, 201).fsn = f; }
+      { Fsn f = fsn0(); f.in = dpre; f.aux = fbo; f.aux2 = mu_sb; f.sums = Sm; f.out = d_fb; f.mode = nmode; b.push(R, OP_FSN_SBBWD_APPLY, 200).fsn = f; }
+    }
     Ptr dh1 = b.ws("dh1", (int64_t)TP * B * Hf, DT_F32);
     fc_backward(fcf, d_fb, h1, B, Hf, F, FP, dh1, 102, "fb_model");
     Ptr dh0d = b.ws("dh0d", (int64_t)TP * B * Hf, DT_F32);

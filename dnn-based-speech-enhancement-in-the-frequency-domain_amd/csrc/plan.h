@@ -13,7 +13,7 @@ struct ModelConfig {
   int32_t B, L;
   int32_t win_len, hop, fft_len;
   int32_t n_layers;
-  int32_t kernel_num[8];    // output channels per encoder layer (complex: real+imag)
+  int32_t kernel_num[12];   // output channels per encoder layer (complex: real+imag); FullSubNet: see build_fsn_plan
   int32_t rnn_layers, rnn_units;
   int32_t mask_mode;        // 0 E, 1 C, 2 R
   int32_t lstm_complex;     // 1 = NavieComplexLSTM stack, 0 = real nn.LSTM(2 layers)+Linear

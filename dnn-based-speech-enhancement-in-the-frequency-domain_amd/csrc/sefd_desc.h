@@ -273,6 +273,13 @@ struct LstmCell {            // forward : gates slab holds pre-activations (inpu
   int32_t G, Bg, unit_major, pad_;
   int64_t rs[5];
   int64_t go[5][4];
+  // kind == 1: GRU cell (torch.nn.GRU, gate order r, z, n; tools_for_model.py:748-756), dense gate-major slabs only.
+  //   forward : gates[:, 0:3H] = W_ih x + b_ih (hoisted GEMM), gh [rows][3H] fp32 = W_hh h_{t-1} + b_hh (this step's GEMM),
+  //             c_prev = h_{t-1} (dtype hdt; A_NONE at t == 0)  ->  h_t, and gates := (r, z, n, W_hn h + b_hn) for the backward
+  //   backward: dh fp32 [rows][H] total gradient of h_t (in);  dgates [rows][3H] := d(W_ih x + b_ih), gh [rows][3H] := d(W_hh h + b_hh)
+  //             (dtype gdt);  dc = dh slab of step t-1 (fp32, += dh_t * z; A_NONE at t == 0).  The recurrent GEMM adds gh . W_hh to it.
+  Ptr gh;
+  int32_t kind, pad2_;
 };
 // Inverted dropout between the LSTM layers (nn.LSTM(dropout=0.8), tools_for_model.py:746): counter-based hash RNG on
 // (seed, element index); backward re-derives the mask from the same seed.  keep == 1 -> identity copy.
@@ -288,10 +295,19 @@ struct Dropout {
 // FSN_SBBUILD: sb_in [TP][B*F][NB+1] = that input / (mean + 1e-5).
 // FSN_OUT: crm [B][F][T][2] = sb_out[t + LA][b*F + f][:] ; FSN_OUT_BWD the reverse (zero for t < LA).
 // FSN_SBBWD_SUM / _APPLY: gradient of the normalised concat w.r.t. the full-band output (through value and mean), x ReLU'.
+// cfg.norm_type (BaseModel.norm_wrapper, tools_for_model.py:1106-1118) = Fsn::mode: 0 offline_laplace_norm (the ops above), 1 cumulative_laplace_norm,
+// 2 offline_gaussian_norm, 3 cumulative_layer_norm.  Modes 1-3 add
+// FSN_NORMSTAT: statistics of the full-band input (src 0: mag_t, rows = B, F values per frame) or of the un-normalised sub-band input (src 1:
+//   rows = B*F, NB+1 values per frame) into `stat`: mode 2 -> [2][B] (mean, unbiased std of the utterance); modes 1 / 3 -> [TP][rows][2]
+//   (running mean over all values of the row up to and including frame t, sqrt(running variance + eps)).
+// FSN_SCALE / FSN_SBBUILD with mode > 0 normalise with `stat`;  FSN_NORMBWD: gradient of the normalised sub-band input w.r.t. the full-band
+//   output column (through the value and through the statistics) -> out fp32 [TP][B][F]; FSN_SBBWD_APPLY with mode > 0 takes that as `in`.
 struct Fsn {
   Ptr in, out, aux, aux2, sums;
   int32_t B, F, T, TP, FP, NB, LA, dt;
-  int32_t act, pad_;
+  int32_t act, mode;
+  Ptr stat;
+  int32_t src, pad_;
 };
 
 enum OpKind : int32_t {
@@ -303,7 +319,8 @@ enum OpKind : int32_t {
   OP_SPECPAD,       // Mags struct reused: spec fp32 [frames][NF][2] -> mags [frames][NF][MS] (dtype dt), channels 2..MS-1 zero (NF = slots here)
   OP_STFT_FFT,
   OP_PACKMULTI,
-  OP_ISTFT_FFT
+  OP_ISTFT_FFT,
+  OP_FSN_NORMSTAT, OP_FSN_NORMBWD,   // cfg.norm_type other than offline_laplace_norm (struct Fsn)
 };
 
 struct Op {

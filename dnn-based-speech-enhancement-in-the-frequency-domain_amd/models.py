@@ -489,14 +489,15 @@ class CRN(_SefdModule):
 
 # ------------------------------------------------------------------------------------------ FullSubNet (models.py:568-682)
 class SequenceModel(nn.Module):
-    """Parameter holder (tools_for_model.py:726-777): 2-layer nn.LSTM(dropout=0.8) + Linear (+ activation)."""
+    """Parameter holder (tools_for_model.py:726-777): 2-layer nn.LSTM or nn.GRU (dropout=0.8) + Linear (+ activation)."""
 
     def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="LSTM", output_activate_function="Tanh"):
         super().__init__()
-        if sequence_model != "LSTM" or bidirectional or num_layers != 2:
-            raise NotImplementedError("only the 2-layer unidirectional LSTM SequenceModel is on the HIP path (cfg.sequence_model == 'LSTM')")
-        self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True,
-                                      bidirectional=False, dropout=0.8)
+        if sequence_model not in ("LSTM", "GRU") or bidirectional or num_layers != 2:
+            raise NotImplementedError("only the 2-layer unidirectional LSTM / GRU SequenceModel is on the HIP path")
+        rnn = nn.LSTM if sequence_model == "LSTM" else nn.GRU
+        self.sequence_model = rnn(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True,
+                                  bidirectional=False, dropout=0.8)
         self.fc_output_layer = nn.Linear(hidden_size, output_size)
         self.output_activate_function = output_activate_function
 
@@ -534,8 +535,9 @@ class FullSubNet(_SefdModule):
                  sb_model_hidden_size=cfg.sb_model_hidden_size, weight_init=cfg.weight_init, norm_type=cfg.norm_type):
         super().__init__()
         assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        if norm_type != "offline_laplace_norm":
-            raise NotImplementedError("only offline_laplace_norm (the config.py default) is on the HIP path")
+        from .plan import FSN_NORMS
+        if norm_type not in FSN_NORMS:                # norm_wrapper (tools_for_model.py:1106-1118)
+            raise NotImplementedError("You must set up a type of Norm. e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
         if weight_init:
             raise NotImplementedError("weight_init=True is not mirrored (config.py default is False)")
         self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model, fb_output_activate_function)
@@ -544,7 +546,7 @@ class FullSubNet(_SefdModule):
         self.sb_num_neighbors, self.fb_num_neighbors, self.look_ahead, self.num_freqs = sb_num_neighbors, fb_num_neighbors, look_ahead, num_freqs
         self._fsn = dict(sb_num_neighbors=sb_num_neighbors, fb_num_neighbors=fb_num_neighbors, look_ahead=look_ahead,
                          fb_hidden=fb_model_hidden_size, sb_hidden=sb_model_hidden_size, fb_act=fb_output_activate_function,
-                         sb_act=sb_output_activate_function)
+                         sb_act=sb_output_activate_function, sequence_model=sequence_model, norm_type=norm_type)
         self.dropout_keep = 0.2                      # nn.LSTM(dropout=0.8); tests set 1.0 to compare with the dropout-free goldens
         self.masking_mode, self.act_dtype = "cIRM", cfg.act_dtype
         self._init_runtime_state()

@@ -13,6 +13,9 @@ MASK_MODES = {"E": 0, "C": 1, "R": 2, "Direct(None make)": 4}
 DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
 
+FSN_NORMS = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_gaussian_norm": 2, "cumulative_layer_norm": 3}   # tools_for_model.py:1106-1118
+
+
 class Plan:
     def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
                  win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
@@ -27,11 +30,12 @@ class Plan:
             # L = number of STFT frames T; kernel_num carries (sb_neighbors, fb_neighbors, look_ahead, fb_hidden, sb_hidden,
             #                                                   fb_act, sb_act, dropout keep probability in 1/1000)
             f = dict(sb_num_neighbors=15, fb_num_neighbors=0, look_ahead=2, fb_hidden=512, sb_hidden=384, fb_act="ReLU",
-                     sb_act=None, keep=0.2)
+                     sb_act=None, keep=0.2, sequence_model="LSTM", norm_type="offline_laplace_norm")
             f.update(fsn or {})
             acts = {None: 0, "None": 0, "ReLU": 1, "Tanh": 2, "ReLU6": 3}
             kernel_num = (f["sb_num_neighbors"], f["fb_num_neighbors"], f["look_ahead"], f["fb_hidden"], f["sb_hidden"],
-                          acts[f["fb_act"]], acts[f["sb_act"]], int(round(f["keep"] * 1000)))
+                          acts[f["fb_act"]], acts[f["sb_act"]], int(round(f["keep"] * 1000)),
+                          {"LSTM": 0, "GRU": 1}[f["sequence_model"]], FSN_NORMS[f["norm_type"]])
         cfg.win_len, cfg.hop, cfg.fft_len = win_len, win_inc, fft_len
         cfg.n_layers = len(kernel_num) if model != "FullSubNet" else 0
         for i, k in enumerate(kernel_num):

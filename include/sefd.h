@@ -27,7 +27,9 @@ typedef struct sefd_model_config {
   int32_t B, L;           /* batch, samples per clip */
   int32_t win_len, hop, fft_len;
   int32_t n_layers;
-  int32_t kernel_num[8];  /* cfg.dccrn_kernel_num */
+  int32_t kernel_num[12]; /* cfg.dccrn_kernel_num; FullSubNet (model 3): sb/fb neighbours, look_ahead, fb/sb hidden, fb/sb activation,
+                             dropout keep in 1/1000, [8] sequence model (0 LSTM, 1 GRU), [9] norm type (0 offline_laplace_norm,
+                             1 cumulative_laplace_norm, 2 offline_gaussian_norm, 3 cumulative_layer_norm) */
   int32_t rnn_layers, rnn_units;
   int32_t mask_mode;      /* 0 'E', 1 'C', 2 'R' (cfg.masking_mode) */
   int32_t lstm_complex;   /* cfg.lstm == 'complex' */

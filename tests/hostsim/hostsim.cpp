@@ -168,11 +168,36 @@ void means(const Fsn& d, const AB& ab, double count) {
   for (int b = 0; b < d.B; ++b) { double s = 0; for (int f = 0; f < d.F; ++f) s += sums[b * d.F + f]; mu[b] = (float)(s / count); }
 }
 
+constexpr float kNormEps = 1.1920928955078125e-07f;
+// one value through cfg.norm_type (struct Fsn): mu = per-utterance means (mode 0), stat = the statistics of FSN_NORMSTAT, r = frame*rows + row
+inline float norm_apply(const Fsn& d, const AB& ab, float x, const float* mu, int b, int64_t r) {
+  if (d.mode == 0) return x / (mu[b] + 1e-5f);
+  const float* stt = (const float*)rp(ab, d.stat);
+  if (d.mode == 2) return (x - stt[b]) / (stt[d.B + b] + 1e-5f);
+  if (d.mode == 1) return x / (stt[r * 2] + kNormEps);
+  return (x - stt[r * 2]) / stt[r * 2 + 1];
+}
+
 bool run_fsn(const Op& op, const AB& ab) {
   switch (op.kind) {
     case OP_CELL_FWD: {
       const LstmCell& d = op.cell;
       float* g = (float*)rp(ab, d.gates);
+      if (d.kind == 1) {                                  // GRU (sefd_desc.h LstmCell kind 1)
+        const float* gh = (const float*)rp(ab, d.gh);
+        const int H = d.H;
+        for (int64_t i = 0; i < d.rows * H; ++i) {
+          const int64_t r = i / H; const int j = (int)(i % H);
+          float* gr = g + r * 4 * H;
+          const float* hr = gh + r * 3 * H;
+          const double rg = sgm(gr[j] + hr[j]), zg = sgm(gr[H + j] + hr[H + j]), hn = hr[2 * H + j];
+          const double ng = std::tanh((double)gr[2 * H + j] + rg * hn);
+          const double hprev = d.first ? 0.0 : ld(rp(ab, d.c_prev), d.hdt, r * H + j);
+          gr[j] = (float)rg; gr[H + j] = (float)zg; gr[2 * H + j] = (float)ng; gr[3 * H + j] = (float)hn;
+          st(rp(ab, d.h), d.hdt, r * H + j, (float)((1 - zg) * ng + zg * hprev));
+        }
+        return true;
+      }
       const float* cp = d.first ? nullptr : (const float*)rp(ab, d.c_prev);
       float* c = (float*)rp(ab, d.c);
       for (int64_t i = 0; i < d.rows * d.H; ++i) {
@@ -192,6 +217,25 @@ bool run_fsn(const Op& op, const AB& ab) {
     case OP_CELL_BWD: {
       const LstmCell& d = op.cell;
       const float* g = (const float*)rp(ab, d.gates);
+      if (d.kind == 1) {
+        const float* dh = (const float*)rp(ab, d.dh);
+        float* dhp = d.dc.arena >= 0 ? (float*)rp(ab, d.dc) : nullptr;
+        const int H = d.H;
+        for (int64_t i = 0; i < d.rows * H; ++i) {
+          const int64_t r = i / H; const int j = (int)(i % H);
+          const float* gr = g + r * 4 * H;
+          const double rg = gr[j], zg = gr[H + j], ng = gr[2 * H + j], hn = gr[3 * H + j];
+          const double hprev = d.c_prev.arena >= 0 ? ld(rp(ab, d.c_prev), d.hdt, r * H + j) : 0.0;
+          const double dht = dh[r * H + j];
+          const double dn = dht * (1 - zg) * (1 - ng * ng), dz = dht * (hprev - ng) * zg * (1 - zg), dr = dn * hn * rg * (1 - rg);
+          st(rp(ab, d.dgates), d.gdt, r * 3 * H + j, (float)dr); st(rp(ab, d.dgates), d.gdt, r * 3 * H + H + j, (float)dz);
+          st(rp(ab, d.dgates), d.gdt, r * 3 * H + 2 * H + j, (float)dn);
+          st(rp(ab, d.gh), d.gdt, r * 3 * H + j, (float)dr); st(rp(ab, d.gh), d.gdt, r * 3 * H + H + j, (float)dz);
+          st(rp(ab, d.gh), d.gdt, r * 3 * H + 2 * H + j, (float)(dn * rg));
+          if (dhp) dhp[r * H + j] = (float)(dhp[r * H + j] + dht * zg);
+        }
+        return true;
+      }
       const float* cp = d.c_prev.arena >= 0 ? (const float*)rp(ab, d.c_prev) : nullptr;
       const float* c = (const float*)rp(ab, d.c);
       const float* dh = (const float*)rp(ab, d.dh);
@@ -251,7 +295,9 @@ bool run_fsn(const Op& op, const AB& ab) {
       const float* mu = (const float*)rp(ab, d.sums);
       for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.FP; ++i) {
         const int f = (int)(i % d.FP); const int64_t tb = i / d.FP; const int b = (int)(tb % d.B);
-        st(rp(ab, d.out), d.dt, i, f < d.F ? mt[tb * d.F + f] / (mu[b] + 1e-5f) : 0.f);
+        float v = 0.f;
+        if (f < d.F) v = norm_apply(d, ab, mt[tb * d.F + f], mu, b, tb);
+        st(rp(ab, d.out), d.dt, i, v);
       }
       return true;
     }
@@ -283,7 +329,85 @@ bool run_fsn(const Op& op, const AB& ab) {
       for (int64_t i = 0; i < (int64_t)d.TP * d.B * d.F * W; ++i) {
         const int k = (int)(i % W); const int64_t r = i / W; const int f = (int)(r % d.F); const int64_t tb = r / d.F;
         const int b = (int)(tb % d.B), t = (int)(tb / d.B);
-        st(rp(ab, d.out), d.dt, i, sb_raw(d, (const float*)rp(ab, d.in), (const float*)rp(ab, d.aux), t, b, f, k) / (mu[b] + 1e-5f));
+        st(rp(ab, d.out), d.dt, i, norm_apply(d, ab, sb_raw(d, (const float*)rp(ab, d.in), (const float*)rp(ab, d.aux), t, b, f, k), mu, b, r));
+      }
+      return true;
+    }
+    case OP_FSN_NORMSTAT: {
+      const Fsn& d = op.fsn;
+      const float* mt = (const float*)rp(ab, d.in);
+      const float* fbo = d.src ? (const float*)rp(ab, d.aux) : nullptr;
+      float* stt = (float*)rp(ab, d.stat);
+      const int W = d.src ? d.NB + 1 : d.F, nf = d.src ? d.F : 1;
+      auto val = [&](int t, int b, int f, int j) { return d.src ? sb_raw(d, mt, fbo, t, b, f, j) : mt[((int64_t)t * d.B + b) * d.F + j]; };
+      for (int b = 0; b < d.B; ++b) {
+        if (d.mode == 2) {
+          double s_ = 0, q = 0;
+          const double n = (double)d.TP * nf * W;
+          for (int t = 0; t < d.TP; ++t) for (int f = 0; f < nf; ++f) for (int j = 0; j < W; ++j) { const double x = val(t, b, f, j); s_ += x; q += x * x; }
+          const double mu = s_ / n, var = (q - n * mu * mu) / (n - 1);
+          stt[b] = (float)mu; stt[d.B + b] = (float)std::sqrt(var > 0 ? var : 0.0);
+          continue;
+        }
+        for (int f = 0; f < nf; ++f) {
+          const int64_t rows = (int64_t)d.B * nf, row = (int64_t)b * nf + f;
+          double cs = 0, cq = 0;
+          for (int t = 0; t < d.TP; ++t) {
+            for (int j = 0; j < W; ++j) { const double x = val(t, b, f, j); cs += x; cq += x * x; }
+            const double n = (double)W * (t + 1), m = cs / n;
+            stt[((int64_t)t * rows + row) * 2] = (float)m;
+            stt[((int64_t)t * rows + row) * 2 + 1] = d.mode == 3 ? (float)std::sqrt((cq - 2 * m * cs) / n + m * m + (double)kNormEps) : 0.f;
+          }
+        }
+      }
+      return true;
+    }
+    case OP_FSN_NORMBWD: {
+      const Fsn& d = op.fsn;
+      const float* dsb = (const float*)rp(ab, d.in);
+      const float* fbo = (const float*)rp(ab, d.aux);
+      const float* stt = (const float*)rp(ab, d.stat);
+      float* out = (float*)rp(ab, d.out);
+      const int W = d.NB + 1;
+      const int64_t rows = (int64_t)d.B * d.F;
+      for (int b = 0; b < d.B; ++b) {
+        if (d.mode == 2) {
+          double S = 0, G = 0;
+          float* part = (float*)rp(ab, d.sums);                 // the kernel's per-(b, f) partial sums are part of the op's output
+          for (int f = 0; f < d.F; ++f) {
+            double s1 = 0, g1 = 0;
+            for (int t = 0; t < d.TP; ++t) for (int k = 0; k < W; ++k) {
+              const int64_t o = (((int64_t)t * d.B + b) * d.F + f) * W + k;
+              g1 += dsb[o]; s1 += (double)dsb[o] * ld(rp(ab, d.aux2), d.dt, o);
+            }
+            part[b * d.F + f] = (float)s1; part[(d.B + b) * d.F + f] = (float)g1;
+            S += s1; G += g1;
+          }
+          const double N = (double)d.F * W * d.TP, sdv = stt[d.B + b], sden = sdv + 1e-5;
+          for (int t = 0; t < d.TP; ++t) for (int f = 0; f < d.F; ++f) {
+            const int64_t o = (((int64_t)t * d.B + b) * d.F + f) * W + d.NB;
+            out[((int64_t)t * d.B + b) * d.F + f] = (float)((dsb[o] - G / N) / sden - (double)ld(rp(ab, d.aux2), d.dt, o) * S / ((N - 1) * sdv));
+          }
+          continue;
+        }
+        for (int f = 0; f < d.F; ++f) {
+          const int64_t row = (int64_t)b * d.F + f;
+          double accA = 0, accB = 0, accBM = 0;
+          for (int t = d.TP - 1; t >= 0; --t) {
+            const int64_t o = ((int64_t)t * rows + row) * W;
+            double G = 0, S = 0;
+            for (int k = 0; k < W; ++k) { G += dsb[o + k]; S += (double)dsb[o + k] * ld(rp(ab, d.aux2), d.dt, o + k); }
+            const double m = stt[((int64_t)t * rows + row) * 2], sd = stt[((int64_t)t * rows + row) * 2 + 1], n = (double)W * (t + 1), gk = dsb[o + d.NB];
+            double v;
+            if (d.mode == 1) { const double den = m + (double)kNormEps; accA += S / (den * n); v = gk / den - accA; }
+            else {
+              const double bb = S / (n * sd * sd);
+              accA += G / (n * sd); accB += bb; accBM += bb * m;
+              v = gk / sd - accA - (double)fbo[((int64_t)t * d.B + b) * d.FP + f] * accB + accBM;
+            }
+            out[((int64_t)t * d.B + b) * d.F + f] = (float)v;
+          }
+        }
       }
       return true;
     }
@@ -373,8 +497,8 @@ bool run_fsn(const Op& op, const AB& ab) {
         const int f = (int)(i % d.FP); const int64_t tb = i / d.FP; const int b = (int)(tb % d.B);
         float v = 0.f;
         if (f < d.F) {
-          const float den = mu[b] + 1e-5f;
-          v = dsb[(tb * d.F + f) * W + d.NB] / den - Sm[b] / den;
+          if (d.mode == 0) { const float den = mu[b] + 1e-5f; v = dsb[(tb * d.F + f) * W + d.NB] / den - Sm[b] / den; }
+          else v = dsb[tb * d.F + f];
           const float y = fbo[i];
           if (d.act == 1) v = y > 0.f ? v : 0.f; else if (d.act == 2) v *= (1.f - y * y); else if (d.act == 3) v = (y > 0.f && y < 6.f) ? v : 0.f;
         }

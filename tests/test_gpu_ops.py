@@ -45,6 +45,9 @@ def _typed(t_u8, dt):
                                                         ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("FullSubNet", 2, 13, "E", (128, 64), 0, "fp32"),
                                                         ("FullSubNet", 2, 9, "E", (64, 32), 0, "bf16"),
+                                                        ("FullSubNet", 2, 8, "GRU/cumulative_layer_norm", (64, 32), 0, "bf16"),     # cfg.sequence_model / cfg.norm_type variants
+                                                        ("FullSubNet", 2, 8, "GRU/offline_gaussian_norm", (64, 32), 0, "fp32"),
+                                                        ("FullSubNet", 2, 8, "LSTM/cumulative_laplace_norm", (64, 32), 0, "fp32"),
                                                         ("FullSubNet", 2, 9, "E", (256, 192), 0, "bf16"),      # cluster LSTM kernels on the time-major slabs
                                                         ("FullSubNet", 2, 10, "E", (512, 384), 0, "bf16")])    # reference sizes; T = 10 marks the case that walks 3 row tiles per workgroup
 def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
@@ -63,8 +66,9 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         os.environ["SEFD_LSTM_MT"] = "3"
     if model == "FullSubNet":              # L = STFT frames, kn = (fb_hidden, sb_hidden); dropout keep 0.2 exercises the mask hash
         from oracle.fullsubnet import FSNConfig, fsn_state_shapes
-        P = formula_state_dict(fsn_state_shapes(FSNConfig(fb_hidden=kn[0], sb_hidden=kn[1])))
-        plan = Plan(B, L, act_dtype=dtype, model="FullSubNet", fsn=dict(fb_hidden=kn[0], sb_hidden=kn[1], keep=0.2))
+        seq, norm = mode.split("/") if "/" in mode else ("LSTM", "offline_laplace_norm")
+        P = formula_state_dict(fsn_state_shapes(FSNConfig(fb_hidden=kn[0], sb_hidden=kn[1], sequence_model=seq)))
+        plan = Plan(B, L, act_dtype=dtype, model="FullSubNet", fsn=dict(fb_hidden=kn[0], sb_hidden=kn[1], keep=0.2, sequence_model=seq, norm_type=norm))
     elif model == "CRN":
         from oracle.crn import CRNConfig, crn_state_shapes
         P = formula_state_dict(crn_state_shapes(CRNConfig(kernel_num=kn, rnn_units=ru, rnn_input_size=4 * (kn[-1] // 2))))
@@ -150,7 +154,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
             if not (worst < 1.0) or stray:
                 bad.append(lines[-1])
     os.environ.pop("SEFD_LSTM_MT", None)
-    with open(_report_path(f"ops_report_{model}_B{B}_{mode}_{dtype}_{L}.txt"), "w") as f:
+    with open(_report_path(f"ops_report_{model}_B{B}_{mode.replace('/', '-')}_{dtype}_{L}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])
 

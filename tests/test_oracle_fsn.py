@@ -10,10 +10,15 @@ from oracle.weights import formula_state_dict, test_signals as make_signals
 from util import load_golden, rel_err, sub
 
 
-@pytest.mark.parametrize("name,hid", [("default_mse", (512, 384)), ("small_mse", (128, 64))])
-def test_fsn_step_against_reference(name, hid):
+@pytest.mark.parametrize("name,hid,seq,norm", [("default_mse", (512, 384), "LSTM", "offline_laplace_norm"),
+                                               ("small_mse", (128, 64), "LSTM", "offline_laplace_norm"),
+                                               ("small_gru_mse", (128, 64), "GRU", "offline_laplace_norm"),
+                                               ("small_cumlaplace_mse", (128, 64), "LSTM", "cumulative_laplace_norm"),
+                                               ("small_gaussian_mse", (128, 64), "LSTM", "offline_gaussian_norm"),
+                                               ("small_cumlayer_gru_mse", (128, 64), "GRU", "cumulative_layer_norm")])
+def test_fsn_step_against_reference(name, hid, seq, norm):
     g = load_golden("fsn_" + name)
-    cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])
+    cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1], sequence_model=seq, norm_type=norm)
     P = formula_state_dict(fsn_state_shapes(cfg))
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     x, y = make_signals(B, L)

@@ -359,16 +359,19 @@ def test_crn_direct_mode_hostsim_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------ FullSubNet
-def test_fsn_hostsim_forward_backward_vs_oracle():
+@pytest.mark.parametrize("seq,norm", [("LSTM", "offline_laplace_norm"), ("GRU", "offline_laplace_norm"), ("LSTM", "cumulative_laplace_norm"),
+                                      ("GRU", "offline_gaussian_norm"), ("LSTM", "cumulative_layer_norm")])
+def test_fsn_hostsim_forward_backward_vs_oracle(seq, norm):
+    """cfg.sequence_model (tools_for_model.py:739-756) and cfg.norm_type (:1106-1118) variants of the FullSubNet plan."""
     from oracle.fullsubnet import FSNConfig, fsn_forward, fsn_state_shapes, fsn_targets
     hid = (128, 64)
-    cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])
+    cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1], sequence_model=seq, norm_type=norm)
     P = formula_state_dict(fsn_state_shapes(cfg))
     B, L = 2, 6000
     x, y = make_signals(B, L)
     mag, cirm = fsn_targets(x, y, cfg)
     T = mag.shape[-1]
-    plan = Plan(B, T, model="FullSubNet", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=1.0))
+    plan = Plan(B, T, model="FullSubNet", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=1.0, sequence_model=seq, norm_type=norm))
     assert [(k, shp) for k, (off, shp) in plan.params.items()] == [(k, tuple(v)) for k, v in fsn_state_shapes(cfg).items()]
     ar = plan.alloc_arenas("cpu")
     fill_params(plan, ar, P)
