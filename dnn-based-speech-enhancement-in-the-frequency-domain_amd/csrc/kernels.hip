@@ -830,7 +830,8 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_LSTM_FWD:
     case OP_LSTM_BWD: {
       const bool fwd = op.kind == OP_LSTM_FWD;
-      if (op.lstm.hdt == DT_BF16 && op.lstm.H > 128) launch_lstm_cluster(op.lstm, ab, st, fwd);
+      if (op.lstm.hdt == DT_BF16 && op.lstm.impl == 1) launch_lstm_rows(op.lstm, ab, st, fwd);
+      else if (op.lstm.hdt == DT_BF16 && op.lstm.H > 128) launch_lstm_cluster(op.lstm, ab, st, fwd);
       else if (op.lstm.hdt == DT_BF16) launch_lstm_bf16(op.lstm, ab, st, fwd);
       else if (op.lstm.H <= 64) launch_lstm<64>(op, ab, st, fwd);
       else launch_lstm<128>(op, ab, st, fwd);

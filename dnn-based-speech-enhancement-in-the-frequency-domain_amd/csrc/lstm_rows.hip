@@ -1,0 +1,259 @@
+// LSTM recurrence over THOUSANDS of independent sequences (FullSubNet's sub-band model: B * 257 rows, H = 384; reference
+// tools_for_model.py:726-795 with nn.LSTM): a throughput problem, bound by the HBM traffic of the gate slabs (fp32 pre-activations in,
+// i/f/g/o out: ~230 MB per frame at 16 448 rows), not by the matrix pipe (19 GFLOP per frame).  The cluster kernels (lstm_cluster.hip)
+// pay an inter-workgroup hand-off per 16-row tile here; these kernels have NO inter-workgroup dependence:
+//   * a workgroup (4 waves) owns 16 * MT sequences and all H hidden units for the whole sequence;
+//   * forward: h_{t-1} of its rows lives in LDS (bf16, ping-pong); per block of 16 units a wave loads the 4 x H/32 B fragments of
+//     W_hh straight from the packed bf16 copy in L2 into registers, multiplies all MT row tiles, adds the input GEMM's
+//     pre-activations, does the cell update lane-locally and writes gates / c to memory and h_t to the other LDS buffer; one LDS
+//     barrier per frame, then h_t leaves as whole 16-byte chunks;
+//   * backward: the cells a lane owns in the accumulator layout of dh_{t-1} = dgates_t . W_hh are the cells whose gate gradients
+//     it computes, so the recurrent gradient and the cell-state carry never leave its registers; dgates_t (16 MT x 4H, bf16) goes
+//     to LDS (the GEMM's A operand) and to memory (the weight / input gradient GEMMs read it), W_hh^T fragments stream from L2.
+// Same descriptor, buffers, gate-column order (unit-major) and arithmetic contract as the other LSTM kernels (LstmRec, impl == 1).
+#include <hip/hip_runtime.h>
+#include "sefd_desc.h"
+#include "dev_common.h"
+
+#pragma clang fp contract(off)
+
+namespace sefd {
+
+namespace {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ f32x2 rcp_2(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) { return rcp_2(exp2_2(x * -1.4426950408889634f) + 1.f); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) { return fma2(rcp_2(exp2_2(x * 2.8853900817779268f) + 1.f), f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}); }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------- forward
+// NW = 8 waves per workgroup, two per SIMD: the loads of one wave (gate pre-activations from HBM, weight fragments from L2) wait under
+// the other's MFMAs (measured on FullSubNet's sub-band layers, ms per launch: 4 waves 19.7 forward / 18.5 backward)
+template <int H, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
+  constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = NW == 8 ? (KS % 3 == 0 ? 3 : 4) : KS / 2, NTHR = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS]
+  const int T = d.T;
+  const int64_t rows = d.B;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const float* gx = reinterpret_cast<const float*>(rp(ab, d.gx));
+  float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
+  float* cs = reinterpret_cast<float*>(rp(ab, d.c));
+  uint16_t* hout = reinterpret_cast<uint16_t*>(rp(ab, d.h));
+  const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_f));   // [4H][H] bf16, row = gate column 4 * unit + q
+  const int kq = lane >> 4, ln = lane & 15;
+  const int64_t gx_ld = d.gx_ld;
+  for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                  // h_{-1} = 0
+  __syncthreads();
+  bool rvalid[MT][4];
+  int64_t rrow[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t b = row0 + 16 * mt + 4 * kq + r;
+      rvalid[mt][r] = b < rows;
+      rrow[mt][r] = rvalid[mt][r] ? b : 0;
+    }
+  for (int t = 0; t < T; ++t) {
+    const uint16_t* hc = hl + (t & 1) * RB * HS;
+    uint16_t* hn = hl + ((t + 1) & 1) * RB * HS;
+    for (int ub = w; ub < NUB; ub += NW) {
+      const int unit = 16 * ub + ln;
+      float4 gxv[MT][4];
+      float cpv[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t rt = (int64_t)t * rows + rrow[mt][r];
+          gxv[mt][r] = *reinterpret_cast<const float4*>(gx + rt * gx_ld + 4 * unit);
+          cpv[mt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
+        }
+      f32x4 acc[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > 0) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < KS; k0 += KC) {
+          uint4 bq[KC][4];
+#pragma unroll
+          for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              bq[ks][q] = *reinterpret_cast<const uint4*>(wp + (int64_t)(4 * unit + q) * H + 32 * (k0 + ks) + 8 * kq);
+#pragma unroll
+          for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const uint4 a = *reinterpret_cast<const uint4*>(hc + (16 * mt + ln) * HS + 32 * (k0 + ks) + 8 * kq);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][q]), acc[mt][q], 0, 0, 0);
+            }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rp2 = 0; rp2 < 4; rp2 += 2) {
+          const f32x2 ig = sigmoid2(f32x2{acc[mt][0][rp2] + gxv[mt][rp2].x, acc[mt][0][rp2 + 1] + gxv[mt][rp2 + 1].x});
+          const f32x2 fg = sigmoid2(f32x2{acc[mt][1][rp2] + gxv[mt][rp2].y, acc[mt][1][rp2 + 1] + gxv[mt][rp2 + 1].y});
+          const f32x2 gg = tanh2(f32x2{acc[mt][2][rp2] + gxv[mt][rp2].z, acc[mt][2][rp2 + 1] + gxv[mt][rp2 + 1].z});
+          const f32x2 og = sigmoid2(f32x2{acc[mt][3][rp2] + gxv[mt][rp2].w, acc[mt][3][rp2 + 1] + gxv[mt][rp2 + 1].w});
+          const f32x2 cn = fma2(fg, f32x2{cpv[mt][rp2], cpv[mt][rp2 + 1]}, ig * gg);
+          const f32x2 hv = og * tanh2(cn);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int r = rp2 + k;
+            hn[(16 * mt + 4 * kq + r) * HS + unit] = f2bf(hv[k]);
+            if (rvalid[mt][r]) {
+              const int64_t rt = (int64_t)t * rows + rrow[mt][r];
+              *reinterpret_cast<float4*>(gates + rt * gx_ld + 4 * unit) = make_float4(ig[k], fg[k], gg[k], og[k]);
+              cs[rt * H + unit] = cn[k];
+            }
+          }
+        }
+    }
+    lds_barrier();
+    // h_t leaves as 16-byte chunks: RB rows x H/8 chunks
+    for (int i = tid; i < RB * (H / 8); i += NTHR) {
+      const int row = i / (H / 8), ch = i - row * (H / 8);
+      if (row0 + row < rows)
+        *reinterpret_cast<uint4*>(hout + ((int64_t)t * rows + row0 + row) * H + 8 * ch) = *reinterpret_cast<const uint4*>(hn + row * HS + 8 * ch);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------- backward
+template <int H, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
+  constexpr int KS = 4 * H / 32, NT = H / 16 / NW, RB = 16 * MT, AS = 4 * H + 8, KC = H >= 512 ? 4 : 8;   // wave w owns units [H/NW * w, +H/NW) = NT tiles of 16
+  extern __shared__ __attribute__((aligned(16))) uint16_t al[];          // dgates_t of the workgroup's rows: [RB][AS]
+  const int T = d.T;
+  const int64_t rows = d.B;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates));
+  const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
+  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
+  uint16_t* dgo = reinterpret_cast<uint16_t*>(rp(ab, d.dgates));
+  const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_b));   // [H][4H] bf16: row = unit u', column = gate column (unit-major)
+  const int kq = lane >> 4, ln = lane & 15;
+  const int64_t gx_ld = d.gx_ld;
+  const int ubase = (H / NW) * w;
+  f32x4 acc[MT][NT], dcar[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dcar[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int t = T - 1; t >= 0; --t) {
+    // ---- cell backward of frame t for this lane's cells; dh_rec = acc of the previous (later) frame
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float4 gv[NT][4];
+      float ctv[NT][4], cpv[NT][4], dhv[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t b = row0 + 16 * mt + 4 * kq + r;
+          const int64_t rt = (int64_t)t * rows + (b < rows ? b : 0);
+          const int unit = ubase + 16 * nt + ln;
+          gv[nt][r] = *reinterpret_cast<const float4*>(gates + rt * gx_ld + 4 * unit);
+          ctv[nt][r] = cs[rt * H + unit];
+          cpv[nt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
+          dhv[nt][r] = dh[rt * H + unit];
+        }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int unit = ubase + 16 * nt + ln;
+#pragma unroll
+        for (int rp2 = 0; rp2 < 4; rp2 += 2) {
+          const f32x2 ig = {gv[nt][rp2].x, gv[nt][rp2 + 1].x}, fg = {gv[nt][rp2].y, gv[nt][rp2 + 1].y};
+          const f32x2 gg = {gv[nt][rp2].z, gv[nt][rp2 + 1].z}, og = {gv[nt][rp2].w, gv[nt][rp2 + 1].w};
+          const f32x2 cp = {cpv[nt][rp2], cpv[nt][rp2 + 1]};
+          const f32x2 dht = f32x2{dhv[nt][rp2], dhv[nt][rp2 + 1]} + f32x2{acc[mt][nt][rp2], acc[mt][nt][rp2 + 1]};
+          const f32x2 tc = tanh2(f32x2{ctv[nt][rp2], ctv[nt][rp2 + 1]});
+          const f32x2 dog = dht * tc * og * (1.f - og);
+          const f32x2 dc = dht * og * (1.f - tc * tc) + f32x2{dcar[mt][nt][rp2], dcar[mt][nt][rp2 + 1]};
+          const f32x2 di = dc * gg * ig * (1.f - ig);
+          const f32x2 df = dc * cp * fg * (1.f - fg);
+          const f32x2 dg = dc * ig * (1.f - gg * gg);
+          const f32x2 dcn = dc * fg;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int r = rp2 + k;
+            const int64_t b = row0 + 16 * mt + 4 * kq + r;
+            const bool v = b < rows;
+            dcar[mt][nt][r] = v ? dcn[k] : 0.f;
+            const uint2 pk = v ? make_uint2(pack_bf16x2(di[k], df[k]), pack_bf16x2(dg[k], dog[k])) : make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(al + (16 * mt + 4 * kq + r) * AS + 4 * unit) = pk;
+            if (v) *reinterpret_cast<uint2*>(dgo + ((int64_t)t * rows + b) * gx_ld + 4 * unit) = pk;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- dh_{t-1}[rows, this wave's units] = dgates_t . W_hh
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {
+#pragma unroll 1
+      for (int k0 = 0; k0 < KS; k0 += KC) {
+        uint4 bq[KC][NT];
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (int64_t)(ubase + 16 * nt + ln) * (4 * H) + 32 * (k0 + ks) + 8 * kq);
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const uint4 a = *reinterpret_cast<const uint4*>(al + (16 * mt + ln) * AS + 32 * (k0 + ks) + 8 * kq);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][nt]), acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+    lds_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ launch
+bool lstm_rows_supported(int H) { return H == 256 || H == 384 || H == 512; }
+
+template <int H, int MT, int NW = 8>
+static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  const unsigned grid = (unsigned)((d.B + 16 * MT - 1) / (16 * MT));
+  if (fwd) {
+    const size_t sh = (size_t)2 * 16 * MT * (H + 8) * 2;
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    (void)once;
+    hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+  } else {
+    const size_t sh = (size_t)16 * MT * (4 * H + 8) * 2;
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    (void)once;
+    hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+  }
+}
+
+void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  switch (d.H) {
+    case 256: launch_r<256, 3>(d, ab, st, fwd); break;
+    case 384: launch_r<384, 3>(d, ab, st, fwd); break;
+    default: launch_r<512, 2>(d, ab, st, fwd); break;      // 32 rows: dgates_t of 48 rows x 2048 columns does not fit 160 KB
+  }
+}
+
+}  // namespace sefd

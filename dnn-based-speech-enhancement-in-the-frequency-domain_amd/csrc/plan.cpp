@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2179,8 +2179,18 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       r.whh[0] = r.whh[1] = b.pptr(pp + "weight_hh_l" + std::to_string(l));
       r.h = L.h; r.c = L.c; r.dh = r.dgates = b.none();
       r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = (int)rows; r.T = TP; r.H = H; r.hdt = adt; r.gdt = DT_F32; r.tmajor = 1;
-      b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
+      // thousands of rows (the sub-band model): row-block kernels (lstm_rows.hip) on a packed bf16 copy of W_hh, rows = gate columns
+      const int64_t rows_min = getenv("SEFD_LSTM_ROWS_MIN") ? atoll(getenv("SEFD_LSTM_ROWS_MIN")) : 1024;
+      L.rowsk = rows >= rows_min && (H == 256 || H == 384 || H == 512);
       L.rec = Builder::gemm0();
+      if (L.rowsk) {
+        RunGemm pk = step_gemm(L.h, adt, rows, H, 0, 4 * H, L.gates, 4 * H, 0, DT_F32, 0);
+        Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(Whh, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
+        b.pack_weights(Fw, pk, chh, L.nm + ".hhpk", tag);
+        if (pk.ldw != H) { P->error = "FullSubNet: packed W_hh layout"; return b.none(); }
+        r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none();
+      }
+      b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
     } else if (gru) {
       // per frame: gh = h_{t-1} . W_hh^T + b_hh into one reused [rows][3H] buffer (t = 0 reads a zero slab), then the GRU cell
       L.gh = b.ws(L.nm + ".gh", rows * 3 * H, DT_F32);
@@ -2312,6 +2322,13 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         r.gx = L.gates; r.gates = L.gates; r.h = L.h; r.c = L.c; r.dh = dh; r.dgates = dgates;
         r.whh[0] = r.whh[1] = b.mk(A_PARAM, Whh->off * 4);
         r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = (int)rows; r.T = TP; r.H = H; r.hdt = adt; r.gdt = adt; r.tmajor = 1;
+        if (L.rowsk) {                                      // W_hh^T packed: row = hidden unit, column = gate column (unit-major)
+          RunGemm pk = step_gemm(dgates, adt, rows, 4 * H, 0, H, dh, H, 0, DT_F32, 0);
+          Builder::Coef cT = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)gate_torch_row(j, H) * H + nn, 1); };
+          b.pack_weights(R, pk, cT, L.nm + ".hhTpk", tag);
+          if (pk.ldw != 4 * H) { P->error = "FullSubNet: packed W_hh^T layout"; return; }
+          r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none();
+        }
         b.push(R, OP_LSTM_BWD, tag).lstm = r;
       } else {
       Ptr dc = b.ws(L.nm + ".dc", rows * H, DT_F32);

@@ -167,8 +167,12 @@ struct LstmRec {
   int32_t t0, t1;              // forward only: time range [t0, t1) of this launch (t1 == 0: the whole sequence).  t0 > 0 resumes
                                // from the saved h[t0-1], c[t0-1]: the planner chunks the sequence so that layer l+1 can start on
                                // a chunk while layer l works on the next one (two HIP streams)
-  int32_t tmajor, pad_;        // 0: buffers are [group][sequence][T][..] (DCCRN / CRN); 1: [group][T][sequence][..] (FullSubNet's
+  int32_t tmajor, impl;        // tmajor 0: buffers are [group][sequence][T][..] (DCCRN / CRN); 1: [group][T][sequence][..] (FullSubNet's
                                // time-major slabs; cluster kernels of lstm_cluster.hip and the host simulator only)
+  // impl 1 (time-major, G == 1, thousands of sequences: FullSubNet's sub-band model): row-block kernels of lstm_rows.hip - a
+  // workgroup owns 48 sequences and ALL hidden units, h_t / dgates_t live in LDS, the packed bf16 weights are streamed from L2 every
+  // frame: wpk_f = W_hh as [4H gate columns (unit-major)][H], wpk_b = its transpose [H][4H] (both written by PACK ops of the plan)
+  Ptr wpk_f, wpk_b;
 };
 
 // Complex combine (tools_for_model.py:171-172): out[b,t, 0:H] = h[g0] - h[g3];  out[b,t,H:2H] = h[g2] + h[g1]

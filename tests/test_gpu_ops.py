@@ -49,7 +49,9 @@ def _typed(t_u8, dt):
                                                         ("FullSubNet", 2, 8, "GRU/offline_gaussian_norm", (64, 32), 0, "fp32"),
                                                         ("FullSubNet", 2, 8, "LSTM/cumulative_laplace_norm", (64, 32), 0, "fp32"),
                                                         ("FullSubNet", 2, 9, "E", (256, 192), 0, "bf16"),      # cluster LSTM kernels on the time-major slabs
-                                                        ("FullSubNet", 2, 10, "E", (512, 384), 0, "bf16")])    # reference sizes; T = 10 marks the case that walks 3 row tiles per workgroup
+                                                        ("FullSubNet", 2, 10, "E", (512, 384), 0, "bf16"),     # reference sizes; T = 10 marks the case that walks 3 row tiles per workgroup
+                                                        ("FullSubNet", 2, 11, "E", (512, 384), 0, "bf16"),     # T = 11 marks the case that runs the sub-band model on the row-block kernels (lstm_rows.hip)
+                                                        ("FullSubNet", 1, 11, "E", (256, 256), 0, "bf16")])
 def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     """Tolerances: fp32 buffers 1e-3 (observed <= 3e-6); bf16 buffers 1.6e-2 = two bf16 ulps of the largest element
     (simulator and kernel round slightly different fp32 accumulations of the SAME bf16 operands)."""
@@ -64,6 +66,9 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     os.environ.pop("SEFD_LSTM_MT", None)
     if model == "FullSubNet" and L == 10:
         os.environ["SEFD_LSTM_MT"] = "3"
+    os.environ.pop("SEFD_LSTM_ROWS_MIN", None)
+    if model == "FullSubNet" and L == 11:
+        os.environ["SEFD_LSTM_ROWS_MIN"] = "64"
     if model == "FullSubNet":              # L = STFT frames, kn = (fb_hidden, sb_hidden); dropout keep 0.2 exercises the mask hash
         from oracle.fullsubnet import FSNConfig, fsn_state_shapes
         seq, norm = mode.split("/") if "/" in mode else ("LSTM", "offline_laplace_norm")
@@ -78,6 +83,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
     os.environ.pop("SEFD_CG256_MINM", None)        # the plan is built: later tests get the default thresholds again
     os.environ.pop("SEFD_WG256_MINM", None)
+    os.environ.pop("SEFD_LSTM_ROWS_MIN", None)
     dev = plan.alloc_arenas("cuda")
     host = plan.alloc_arenas("cpu")
     fill_params(plan, dev, P)
