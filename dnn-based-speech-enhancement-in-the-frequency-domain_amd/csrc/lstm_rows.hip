@@ -26,21 +26,45 @@ __device__ __forceinline__ f32x2 rcp_2(f32x2 x) { return f32x2{__builtin_amdgcn_
 __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) { return rcp_2(exp2_2(x * -1.4426950408889634f) + 1.f); }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 tanh2(f32x2 x) { return fma2(rcp_2(exp2_2(x * 2.8853900817779268f) + 1.f), f32x2{-2.f, -2.f}, f32x2{1.f, 1.f}); }
+template <bool G16> struct GateRaw;
+template <> struct GateRaw<true> {
+  typedef uint2 type;
+  static __device__ __forceinline__ float4 cvt(uint2 r) { return make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16)); }
+};
+template <> struct GateRaw<false> {
+  typedef float4 type;
+  static __device__ __forceinline__ float4 cvt(float4 r) { return r; }
+};
+// four gate values of one cell from / to a slab of dtype fp32 or bf16 (element offset o, a multiple of 4)
+template <bool G16>
+__device__ __forceinline__ float4 ld_gate4(const char* base, int64_t o) {
+  if constexpr (G16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(base + o * 2);
+    return make_float4(bf2f(r.x & 0xffff), bf2f(r.x >> 16), bf2f(r.y & 0xffff), bf2f(r.y >> 16));
+  } else {
+    return *reinterpret_cast<const float4*>(base + o * 4);
+  }
+}
+template <bool G16>
+__device__ __forceinline__ void st_gate4(char* base, int64_t o, float a, float b, float c, float e) {
+  if constexpr (G16) *reinterpret_cast<uint2*>(base + o * 2) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, e));
+  else *reinterpret_cast<float4*>(base + o * 4) = make_float4(a, b, c, e);
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- forward
 // NW = 8 waves per workgroup, two per SIMD: the loads of one wave (gate pre-activations from HBM, weight fragments from L2) wait under
 // the other's MFMAs (measured on FullSubNet's sub-band layers, ms per launch: 4 waves 19.7 forward / 18.5 backward)
-template <int H, int MT, int NW>
+template <int H, int MT, int NW, bool G16>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
-  constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = NW == 8 ? (KS % 3 == 0 ? 3 : 4) : KS / 2, NTHR = NW * 64;
+  constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = KS % 3 == 0 ? 3 : 4, NTHR = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS]
   const int T = d.T;
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * RB;
-  const float* gx = reinterpret_cast<const float*>(rp(ab, d.gx));
-  float* gates = reinterpret_cast<float*>(rp(ab, d.gates));
+  const char* gx = rp(ab, d.gx);
+  char* gates = rp(ab, d.gates);
   float* cs = reinterpret_cast<float*>(rp(ab, d.c));
   uint16_t* hout = reinterpret_cast<uint16_t*>(rp(ab, d.h));
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_f));   // [4H][H] bf16, row = gate column 4 * unit + q
@@ -63,14 +87,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
     uint16_t* hn = hl + ((t + 1) & 1) * RB * HS;
     for (int ub = w; ub < NUB; ub += NW) {
       const int unit = 16 * ub + ln;
-      float4 gxv[MT][4];
+      typename GateRaw<G16>::type gxr[MT][4];      // raw gate pre-activations (bf16: 8 bytes per cell), converted in the epilogue
       float cpv[MT][4];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t rt = (int64_t)t * rows + rrow[mt][r];
-          gxv[mt][r] = *reinterpret_cast<const float4*>(gx + rt * gx_ld + 4 * unit);
+          gxr[mt][r] = *reinterpret_cast<const typename GateRaw<G16>::type*>(gx + (rt * gx_ld + 4 * unit) * (G16 ? 2 : 4));
           cpv[mt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
         }
       f32x4 acc[MT][4];
@@ -79,14 +103,16 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t > 0) {
-#pragma unroll 1
-        for (int k0 = 0; k0 < KS; k0 += KC) {
-          uint4 bq[KC][4];
+        // weight fragments in chunks of KC k-steps, double buffered: the loads of chunk c + 1 (L2, ~1 us) fly under the MFMAs of chunk c
+        uint4 bqA[KC][4];
+        const uint16_t* wrow = wp + (int64_t)(4 * unit) * H + 8 * kq;
+        auto loadc = [&](uint4 (&bq)[KC][4], int k0) {
 #pragma unroll
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              bq[ks][q] = *reinterpret_cast<const uint4*>(wp + (int64_t)(4 * unit + q) * H + 32 * (k0 + ks) + 8 * kq);
+            for (int q = 0; q < 4; ++q) bq[ks][q] = *reinterpret_cast<const uint4*>(wrow + q * H + 32 * (k0 + ks));
+        };
+        auto mulc = [&](const uint4 (&bq)[KC][4], int k0) {
 #pragma unroll
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
@@ -96,8 +122,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
               for (int q = 0; q < 4; ++q)
                 acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][q]), acc[mt][q], 0, 0, 0);
             }
+        };
+        // measured (sub-band layers, ms per launch): one chunk of 3 k-steps at a time 15.6; chunks of 2 double buffered 17.5 (the second
+        // buffer spills: 8 waves leave 256 registers each) - the two waves of a SIMD already overlap each other's load latency
+#pragma unroll 1
+        for (int k0 = 0; k0 < KS; k0 += KC) {
+          loadc(bqA, k0);
+          mulc(bqA, k0);
         }
       }
+      float4 gxv[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gxv[mt][r] = GateRaw<G16>::cvt(gxr[mt][r]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -114,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
             hn[(16 * mt + 4 * kq + r) * HS + unit] = f2bf(hv[k]);
             if (rvalid[mt][r]) {
               const int64_t rt = (int64_t)t * rows + rrow[mt][r];
-              *reinterpret_cast<float4*>(gates + rt * gx_ld + 4 * unit) = make_float4(ig[k], fg[k], gg[k], og[k]);
+              st_gate4<G16>(gates, rt * gx_ld + 4 * unit, ig[k], fg[k], gg[k], og[k]);
               cs[rt * H + unit] = cn[k];
             }
           }
@@ -131,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
-template <int H, int MT, int NW>
+template <int H, int MT, int NW, bool G16>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
   constexpr int KS = 4 * H / 32, NT = H / 16 / NW, RB = 16 * MT, AS = 4 * H + 8, KC = H >= 512 ? 4 : 8;   // wave w owns units [H/NW * w, +H/NW) = NT tiles of 16
   extern __shared__ __attribute__((aligned(16))) uint16_t al[];          // dgates_t of the workgroup's rows: [RB][AS]
@@ -139,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * RB;
-  const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates));
+  const char* gates = rp(ab, d.gates);
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
   const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
   uint16_t* dgo = reinterpret_cast<uint16_t*>(rp(ab, d.dgates));
@@ -165,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
           const int64_t b = row0 + 16 * mt + 4 * kq + r;
           const int64_t rt = (int64_t)t * rows + (b < rows ? b : 0);
           const int unit = ubase + 16 * nt + ln;
-          gv[nt][r] = *reinterpret_cast<const float4*>(gates + rt * gx_ld + 4 * unit);
+          gv[nt][r] = ld_gate4<G16>(gates, rt * gx_ld + 4 * unit);
           ctv[nt][r] = cs[rt * H + unit];
           cpv[nt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
           dhv[nt][r] = dh[rt * H + unit];
@@ -206,14 +244,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
-#pragma unroll 1
-      for (int k0 = 0; k0 < KS; k0 += KC) {
-        uint4 bq[KC][NT];
+      uint4 bqA[KC][NT];
+      const uint16_t* wrow = wp + (int64_t)(ubase + ln) * (4 * H) + 8 * kq;
+      auto loadc = [&](uint4 (&bq)[KC][NT], int k0) {
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (int64_t)(ubase + 16 * nt + ln) * (4 * H) + 32 * (k0 + ks) + 8 * kq);
+          for (int nt = 0; nt < NT; ++nt) bq[ks][nt] = *reinterpret_cast<const uint4*>(wrow + (int64_t)(16 * nt) * (4 * H) + 32 * (k0 + ks));
+      };
+      auto mulc = [&](const uint4 (&bq)[KC][NT], int k0) {
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
@@ -223,6 +262,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
             for (int nt = 0; nt < NT; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][nt]), acc[mt][nt], 0, 0, 0);
           }
+      };
+#pragma unroll 1
+      for (int k0 = 0; k0 < KS; k0 += KC) {
+        loadc(bqA, k0);
+        mulc(bqA, k0);
       }
     }
     lds_barrier();
@@ -232,20 +276,25 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
 // ------------------------------------------------------------------------------------------------------------------ launch
 bool lstm_rows_supported(int H) { return H == 256 || H == 384 || H == 512; }
 
-template <int H, int MT, int NW = 8>
-static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+template <int H, int MT, bool G16, int NW = 8>
+static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
   const unsigned grid = (unsigned)((d.B + 16 * MT - 1) / (16 * MT));
   if (fwd) {
     const size_t sh = (size_t)2 * 16 * MT * (H + 8) * 2;
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
     (void)once;
-    hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
   } else {
     const size_t sh = (size_t)16 * MT * (4 * H + 8) * 2;
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
     (void)once;
-    hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
   }
+}
+template <int H, int MT>
+static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  if (d.gxdt == DT_BF16) launch_r2<H, MT, true>(d, ab, st, fwd);
+  else launch_r2<H, MT, false>(d, ab, st, fwd);
 }
 
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {

@@ -240,7 +240,7 @@ struct Builder {
     const bool wide_on = !(getenv("SEFD_WG256") && atoi(getenv("SEFD_WG256")) == 0);
     const int64_t wide_minm = getenv("SEFD_WG256_MINM") ? atoll(getenv("SEFD_WG256_MINM")) : 32768;
     int tk = kWgTK;
-    if (narrow && wide_on && g.Npad % 256 == 0 && g.ldw >= 512 && g.M >= wide_minm) { tn = 256; tk = 256; g.flags |= kRunWgWide; }
+    if (narrow && wide_on && g.Npad % 256 == 0 && g.ldw >= 384 && g.M >= wide_minm) { tn = 256; tk = 256; g.flags |= kRunWgWide; }
     else if (narrow && wide_on && g.Npad == 128 && g.ldw >= 1024 && g.M >= wide_minm) { tn = 128; tk = 512; g.flags |= kRunWgWide; }
     const int slots = g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768;
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk; int sdt; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2157,14 +2157,19 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     const ParamInfo &bih = b.par(pp + "bias_ih_l" + std::to_string(l)), &bhh = b.par(pp + "bias_hh_l" + std::to_string(l));
     L.Whh = &Whh;
     const int I = (int)Wih.shape[1];
-    L.gates = b.ws(L.nm + ".gates", (int64_t)TP * rows * 4 * H, DT_F32);
+    // thousands of rows (the sub-band model) in bf16: row-block kernels (lstm_rows.hip) on a packed bf16 copy of W_hh; their gate
+    // slabs are bf16 too - at B * 257 rows those layers are bound by the HBM traffic of exactly these slabs (SEFD_LSTM_SLAB32=1: fp32)
+    const int64_t rows_min = getenv("SEFD_LSTM_ROWS_MIN") ? atoll(getenv("SEFD_LSTM_ROWS_MIN")) : 1024;
+    L.cluster = !gru && adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && getenv("SEFD_LSTM_STEPPED") == nullptr;
+    L.rowsk = L.cluster && rows >= rows_min && (H == 256 || H == 384 || H == 512);
+    L.sdt = (L.rowsk && getenv("SEFD_LSTM_SLAB32") == nullptr) ? DT_BF16 : DT_F32;
+    L.gates = b.ws(L.nm + ".gates", (int64_t)TP * rows * 4 * H, L.sdt);
     L.c = b.ws(L.nm + ".c", (int64_t)TP * rows * H, DT_F32);
     L.h = b.ws(L.nm + ".h", (int64_t)TP * rows * H, adt);
     // bf16 mode, 128 < H <= 512: the whole recurrence is ONE launch of the cluster kernels (lstm_cluster.hip) on the time-major
     // slabs, gate columns unit-major (sefd_desc.h gate_col); otherwise one GEMM + one cell launch per frame, gate-major columns
-    L.cluster = !gru && adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && getenv("SEFD_LSTM_STEPPED") == nullptr;
     const bool um = L.cluster;
-    RunGemm g = seq_gemm(x, adt, rows, xfeat, 0, xlen, NG * H, DT_F32);
+    RunGemm g = seq_gemm(x, adt, rows, xfeat, 0, xlen, NG * H, L.sdt);
     L.cgx = [=](int nn, int s, int j) -> int32_t { return j < I ? pe(Wih, (int64_t)(um ? gate_torch_row(nn, H) : nn) * I + j, 1) : 0; };
     if (gru) L.bgx = [=](int nn, int32_t* o) { o[0] = pe(bih, nn, 1); o[1] = 0; };     // b_hh rides the recurrent GEMM: n = tanh(.. + r * (W_hn h + b_hn))
     else L.bgx = [=](int nn, int32_t* o) { const int q = um ? gate_torch_row(nn, H) : nn; o[0] = pe(bih, q, 1); o[1] = pe(bhh, q, 1); };
@@ -2180,15 +2185,13 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       r.h = L.h; r.c = L.c; r.dh = r.dgates = b.none();
       r.gx_ld = 4 * H; r.G = 1; r.nset = 1; r.B = (int)rows; r.T = TP; r.H = H; r.hdt = adt; r.gdt = DT_F32; r.tmajor = 1;
       // thousands of rows (the sub-band model): row-block kernels (lstm_rows.hip) on a packed bf16 copy of W_hh, rows = gate columns
-      const int64_t rows_min = getenv("SEFD_LSTM_ROWS_MIN") ? atoll(getenv("SEFD_LSTM_ROWS_MIN")) : 1024;
-      L.rowsk = rows >= rows_min && (H == 256 || H == 384 || H == 512);
       L.rec = Builder::gemm0();
       if (L.rowsk) {
         RunGemm pk = step_gemm(L.h, adt, rows, H, 0, 4 * H, L.gates, 4 * H, 0, DT_F32, 0);
         Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(Whh, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
         b.pack_weights(Fw, pk, chh, L.nm + ".hhpk", tag);
         if (pk.ldw != H) { P->error = "FullSubNet: packed W_hh layout"; return b.none(); }
-        r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none();
+        r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none(); r.gxdt = L.sdt;
       }
       b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
     } else if (gru) {
@@ -2327,7 +2330,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
           Builder::Coef cT = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)gate_torch_row(j, H) * H + nn, 1); };
           b.pack_weights(R, pk, cT, L.nm + ".hhTpk", tag);
           if (pk.ldw != 4 * H) { P->error = "FullSubNet: packed W_hh^T layout"; return; }
-          r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none();
+          r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none(); r.gxdt = L.sdt;
         }
         b.push(R, OP_LSTM_BWD, tag).lstm = r;
       } else {

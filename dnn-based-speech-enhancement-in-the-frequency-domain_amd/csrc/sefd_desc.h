@@ -173,6 +173,8 @@ struct LstmRec {
   // workgroup owns 48 sequences and ALL hidden units, h_t / dgates_t live in LDS, the packed bf16 weights are streamed from L2 every
   // frame: wpk_f = W_hh as [4H gate columns (unit-major)][H], wpk_b = its transpose [H][4H] (both written by PACK ops of the plan)
   Ptr wpk_f, wpk_b;
+  int32_t gxdt, pad2_;          // impl 1 only: dtype of the gx / gates slabs (DT_BF16 halves the HBM traffic that bounds these layers; the cell
+                               // update itself uses the unrounded fp32 gate values, the backward reads the stored ones)
 };
 
 // Complex combine (tools_for_model.py:171-172): out[b,t, 0:H] = h[g0] - h[g3];  out[b,t,H:2H] = h[g2] + h[g1]

@@ -660,8 +660,7 @@ void run_op(const Op& op, const AB& ab) {
     case OP_LSTM_FWD: {
       const LstmRec& d = op.lstm;
       const int H = d.H, T = d.T;
-      const float* gxb = (const float*)rp(ab, d.gx);
-      float* gates = (float*)rp(ab, d.gates);
+      const int sdt = d.impl == 1 ? d.gxdt : DT_F32;        // dtype of the gx / gates slabs (row-block kernels: optionally bf16)
       float* cs = (float*)rp(ab, d.c);
       for (int g = 0; g < d.G; ++g) {
         const float* whh_ = (const float*)rp(ab, d.whh[g % d.nset]);
@@ -676,12 +675,12 @@ void run_op(const Op& op, const AB& ab) {
           }
           for (int t = tb; t < te; ++t) {
             const int64_t rt = d.tmajor ? (int64_t)t * d.B + b : (int64_t)b * T + t;      // (sequence, frame) -> row of the buffers
-            const float* gx = gxb + d.gx_goff[g] + rt * d.gx_ld;
+            const int64_t gxo = d.gx_goff[g] + rt * d.gx_ld;
             const int64_t row = (int64_t)g * d.B * T + rt;
             for (int j = 0; j < H; ++j) {
               double pre[4];
               for (int q = 0; q < 4; ++q) {
-                double s = gx[gate_col(q, j)];
+                double s = ld(rp(ab, d.gx), sdt, gxo + gate_col(q, j));
                 const float* wr = whh.data() + (int64_t)(q * H + j) * H;
                 for (int k = 0; k < H; ++k) s += h[k] * wr[k];
                 pre[q] = s;
@@ -689,8 +688,9 @@ void run_op(const Op& op, const AB& ab) {
               const double ig = 1 / (1 + std::exp(-pre[0])), fg = 1 / (1 + std::exp(-pre[1])), gg = std::tanh(pre[2]), og = 1 / (1 + std::exp(-pre[3]));
               c[j] = (double)(float)(fg * c[j] + ig * gg);      // the kernels carry the cell state in fp32 (and resume chunks from the stored value)
               hn[j] = og * std::tanh(c[j]);
-              float* gq = gates + (row * H + j) * 4;
-              gq[0] = (float)ig; gq[1] = (float)fg; gq[2] = (float)gg; gq[3] = (float)og;
+              const int64_t gq = (row * H + j) * 4;
+              st(rp(ab, d.gates), sdt, gq, (float)ig); st(rp(ab, d.gates), sdt, gq + 1, (float)fg);
+              st(rp(ab, d.gates), sdt, gq + 2, (float)gg); st(rp(ab, d.gates), sdt, gq + 3, (float)og);
               cs[row * H + j] = (float)c[j];
             }
             for (int j = 0; j < H; ++j) {
@@ -705,7 +705,7 @@ void run_op(const Op& op, const AB& ab) {
     case OP_LSTM_BWD: {
       const LstmRec& d = op.lstm;
       const int H = d.H, T = d.T;
-      const float* gates = (const float*)rp(ab, d.gates);
+      const int sdt = d.impl == 1 ? d.gxdt : DT_F32;
       const float* cs = (const float*)rp(ab, d.c);
       const float* dh = (const float*)rp(ab, d.dh);
       for (int g = 0; g < d.G; ++g) {
@@ -718,8 +718,8 @@ void run_op(const Op& op, const AB& ab) {
             const int64_t rt = d.tmajor ? (int64_t)t * d.B + b : (int64_t)b * T + t;
             const int64_t row = (int64_t)g * d.B * T + rt, rowp = row - (d.tmajor ? d.B : 1);
             for (int j = 0; j < H; ++j) {
-              const float* gq = gates + (row * H + j) * 4;
-              const double ig = gq[0], fg = gq[1], gg = gq[2], og = gq[3];
+              const int64_t gq = (row * H + j) * 4;
+              const double ig = ld(rp(ab, d.gates), sdt, gq), fg = ld(rp(ab, d.gates), sdt, gq + 1), gg = ld(rp(ab, d.gates), sdt, gq + 2), og = ld(rp(ab, d.gates), sdt, gq + 3);
               const double ct = cs[row * H + j], cp = t > 0 ? cs[rowp * H + j] : 0.0;
               const double dht = dh[row * H + j] + dhrec[j];
               const double tc = std::tanh(ct);

@@ -402,12 +402,19 @@ def test_fsn_bf16_cluster_lstm_plan_equals_the_per_step_plan(monkeypatch):
     mag = torch.rand(B, 257, T) * 2
     gc = torch.randn(B, 257, T, 2) * 1e-3
     outs = []
-    for stepped in (False, True):
-        if stepped:
+    cfg0, P0 = cfg, P
+    for stepped in (False, True, "rows"):
+        if stepped is True:
             monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+        if stepped == "rows":                                   # sub-band model on the row-block kernels' ops: packed W_hh, bf16 gate slabs
+            monkeypatch.delenv("SEFD_LSTM_STEPPED")
+            monkeypatch.setenv("SEFD_LSTM_ROWS_MIN", "64")
+            hid = (256, 256)
+            cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])
+            P = formula_state_dict(fsn_state_shapes(cfg))
         plan = Plan(B, T, model="FullSubNet", act_dtype="bf16", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=1.0))
         kinds = [plan.op_info(PHASE_FWD, i)["kind"] for i in range(plan.num_ops(PHASE_FWD))]
-        assert (kinds.count(1) < 12) == (not stepped)
+        assert (kinds.count(1) < 12) == (stepped is not True)
         ar = plan.alloc_arenas("cpu")
         fill_params(plan, ar, P)
         plan.io(ar, "mag", (B, 257, T)).copy_(mag)
@@ -415,10 +422,14 @@ def test_fsn_bf16_cluster_lstm_plan_equals_the_per_step_plan(monkeypatch):
         plan.io(ar, "grad_crm", (B, 257, T, 2)).copy_(gc)
         sim_run(plan, PHASE_BWD, ar)
         outs.append((plan.io(ar, "crm", (B, 257, T, 2)).clone(), read_params(plan, ar, ARENA_GRAD)))
-    monkeypatch.delenv("SEFD_LSTM_STEPPED")
+    monkeypatch.delenv("SEFD_LSTM_ROWS_MIN")
     assert rel_err(outs[0][0], outs[1][0]) < 5e-3
     _grads_close(outs[0][1], outs[1][1], 3e-2)
-    assert rel_err(outs[0][0], fsn_forward(P, mag, cfg)) < 3e-2
+    assert rel_err(outs[0][0], fsn_forward(P0, mag, cfg0)) < 3e-2
+    assert rel_err(outs[2][0], fsn_forward(P, mag, cfg)) < 3e-2          # bf16 pre-activation / gate slabs: still inside the bf16 output budget
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = torch.autograd.grad((fsn_forward(Pg, mag, cfg) * gc).sum(), list(Pg.values()))
+    _grads_close(outs[2][1], dict(zip(Pg, ref)), 8e-2)
 
 
 def test_fsn_dropout_mask_statistics_and_backward_consistency():
