@@ -137,8 +137,9 @@ def roofline(plan, arenas):
     a = agg[key]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[key[1]]
-    prefixes = {"rungemm": ["void sefd::rungemm_kernel<sefd::bf16_t" if key[1] else "void sefd::rungemm_kernel<float"],
-                "cgemm256": ["sefd::cgemm256_kernel"], "wgrad": ["void sefd::wgrad_bf16" if key[1] else "void sefd::wgrad_kernel<float"]}[key[0]]
+    # kernel names as tools/pmc_traffic.py stores them ("void sefd::" / "sefd::" stripped, template arguments kept)
+    prefixes = {"rungemm": ["rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float"],
+                "cgemm256": ["cgemm256_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
     return dict(bound="mfma", kernel=f"{key[0]}<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                 frac=round(achieved / peak, 4), traffic=pmc_traffic(prefixes), launches_per_step=a["launches"],
                 avg_launch_ms=round(a["ms"] / a["launches"], 4),

@@ -3,6 +3,7 @@
 // workgroup in LDS, row -> (batch item, frame) decode kept incremental (no 64-bit divisions in the loops).
 // Statistics themselves come for free from the producing GEMM's epilogue (rungemm.hip) -> bn_finalize (kernels.hip).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ void stage_params(float* sp, int C, const float* mi, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel_v(const BnApply d, const ArenaBases ab) {
+__global__ __launch_bounds__(256) void bn_apply_kernel_v(const BnApply d, const ArenaBases ab, const int rev) {
   constexpr int V = VecIO<T>::V;
   __shared__ float sp[4 * kMaxC];
   const int C = d.C;
@@ -59,11 +60,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel_v(const BnApply d, const 
   if (cmask >= 0 && ((stride * V) & cmask) == 0) {
     // the grid stride is a whole number of rows: a thread always meets the same V channels, so their parameters live in
     // registers (the LDS look-ups, 4 per element, were costing more issue slots than the 16-byte HBM accesses they serve)
-    const int c = (int)(((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * V) & cmask);
+    // rev: walk the tensor from its END - the producer GEMM wrote it front to back, so its tail is what the 256 MB Infinity Cache
+    // still holds (the tensors here are 32-126 MB)
+    const int64_t idx0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int c = (int)(((rev ? nq - 1 - idx0 : idx0) * V) & cmask);
     float pm[V], pis[V], pg[V], pb[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { pm[e] = sp[c + e]; pis[e] = sp[C + c + e]; pg[e] = sp[2 * C + c + e]; pb[e] = sp[3 * C + c + e]; }
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += stride) {
+    for (int64_t qq = idx0; qq < nq; qq += stride) {
+      const int64_t q = rev ? nq - 1 - qq : qq;
       float v[V];
       VecIO<T>::load(y, q * V, v);
 #pragma unroll
@@ -105,7 +110,7 @@ __device__ __forceinline__ void load_dz_v(const BnBwdReduce& d, const char* dz0,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce d, const ArenaBases ab) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce d, const ArenaBases ab, const int rev) {
   constexpr int V = VecIO<T>::V;
   __shared__ float sp[4 * kMaxC];
   __shared__ float red[512 * V + 8];
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce 
   float s0[V], s1[V], sa = 0.f;
 #pragma unroll
   for (int e = 0; e < V; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
-  const int64_t row0 = (int64_t)blockIdx.x * d.rows_per_blk;
+  const int blk = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;      // rev: last rows first (the dgrad GEMM wrote them last)
+  const int64_t row0 = (int64_t)blk * d.rows_per_blk;
   const int64_t row1 = min(d.R, row0 + d.rows_per_blk);
   if (rl < nrl && cc < CV) {
     const int c = cc * V;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce 
     }
   }
   __syncthreads();
-  float* part = reinterpret_cast<float*>(rp(ab, d.part)) + (int64_t)blockIdx.x * 3 * C;
+  float* part = reinterpret_cast<float*>(rp(ab, d.part)) + (int64_t)blk * 3 * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     float t0 = 0.f, t1 = 0.f;
     for (int k = 0; k < nrl; ++k) { t0 += red[(k * C + c) * 2 + 0]; t1 += red[(k * C + c) * 2 + 1]; }
@@ -258,14 +264,15 @@ static inline int gridcap(int64_t n, int cap = 16384) {
 }
 
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st) {
+  static const int rev = getenv("SEFD_BN_REV") ? atoi(getenv("SEFD_BN_REV")) : 0;
   if (op.kind == OP_BN_APPLY) {
     const BnApply& d = op.bna;
-    if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_apply_kernel_v<bf16_t>), dim3(gridcap(d.R * d.C / 8)), dim3(256), 0, st, d, ab);
-    else hipLaunchKernelGGL((bn_apply_kernel_v<float>), dim3(gridcap(d.R * d.C / 4)), dim3(256), 0, st, d, ab);
+    if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_apply_kernel_v<bf16_t>), dim3(gridcap(d.R * d.C / 8)), dim3(256), 0, st, d, ab, rev);
+    else hipLaunchKernelGGL((bn_apply_kernel_v<float>), dim3(gridcap(d.R * d.C / 4)), dim3(256), 0, st, d, ab, rev);
   } else if (op.kind == OP_BN_BWD_REDUCE) {
     const BnBwdReduce& d = op.bnr;
-    if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel_v<bf16_t>), dim3(d.nblk), dim3(256), 0, st, d, ab);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel_v<float>), dim3(d.nblk), dim3(256), 0, st, d, ab);
+    if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel_v<bf16_t>), dim3(d.nblk), dim3(256), 0, st, d, ab, rev);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel_v<float>), dim3(d.nblk), dim3(256), 0, st, d, ab, rev);
   } else if (op.kind == OP_BN_BWD_APPLY) {
     const BnBwdApply& d = op.bnb;
     const int nb = (int)(d.r.R / d.r.rpb);

@@ -12,6 +12,7 @@
 //     to LDS (the GEMM's A operand) and to memory (the weight / input gradient GEMMs read it), W_hh^T fragments stream from L2.
 // Same descriptor, buffers, gate-column order (unit-major) and arithmetic contract as the other LSTM kernels (LstmRec, impl == 1).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ void st_gate4(char* base, int64_t o, float a, float b
 // the other's MFMAs (measured on FullSubNet's sub-band layers, ms per launch: 4 waves 19.7 forward / 18.5 backward)
 template <int H, int MT, int NW, bool G16>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
-  constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = KS % 3 == 0 ? 3 : 4, NTHR = NW * 64;
+  constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = (KS % 3 == 0 ? 3 : 4) * (NW == 4 ? 2 : 1), NTHR = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS]
   const int T = d.T;
   const int64_t rows = d.B;
@@ -169,10 +170,16 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
-template <int H, int MT, int NW, bool G16>
+// HV > 1: the gate columns are walked in HV parts through ONE LDS tile of 16 MT x 4H / HV (cell backward of the part's units, barrier,
+// its share of the GEMM, barrier), so that 80 rows would fit (16 MT x 4H of bf16 is 245 KB at MT = 5) and the launch would need one
+// dispatch round instead of two.  Tried (80 rows: 4 waves x 2 parts, 8 waves x 3 parts): both spill ~350 registers - the old and the new
+// recurrent gradient and the cell-state carry are all live across the parts - so only HV = 1 with 48 rows is launched.
+template <int H, int MT, int NW, bool G16, int HV>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
-  constexpr int KS = 4 * H / 32, NT = H / 16 / NW, RB = 16 * MT, AS = 4 * H + 8, KC = H >= 512 ? 4 : 8;   // wave w owns units [H/NW * w, +H/NW) = NT tiles of 16
-  extern __shared__ __attribute__((aligned(16))) uint16_t al[];          // dgates_t of the workgroup's rows: [RB][AS]
+  constexpr int KS = 4 * H / 32, NT = H / 16 / NW, RB = 16 * MT, AS = 4 * H / HV + 8, KC = H >= 512 ? 4 : (HV > 1 ? 4 : 8);
+  constexpr int NTH = NT / HV, KSH = KS / HV;       // unit tiles per wave and k-steps per half
+  static_assert(NT % HV == 0, "unit tiles per half");
+  extern __shared__ __attribute__((aligned(16))) uint16_t al[];          // dgates_t (one half of the gate columns) of the workgroup's rows: [RB][AS]
   const int T = d.T;
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -184,99 +191,103 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_b));   // [H][4H] bf16: row = unit u', column = gate column (unit-major)
   const int kq = lane >> 4, ln = lane & 15;
   const int64_t gx_ld = d.gx_ld;
-  const int ubase = (H / NW) * w;
-  f32x4 acc[MT][NT], dcar[MT][NT];
+  // unit of (tile nt, this lane): half nt / NTH, inside the half the wave's NTH consecutive tiles
+  auto unit_of = [&](int nt) { return (nt / NTH) * (H / HV) + (NTH * 16) * w + 16 * (nt % NTH) + ln; };
+  f32x4 acc[MT][NT], accp[MT][NT], dcar[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dcar[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   for (int t = T - 1; t >= 0; --t) {
-    // ---- cell backward of frame t for this lane's cells; dh_rec = acc of the previous (later) frame
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float4 gv[NT][4];
-      float ctv[NT][4], cpv[NT][4], dhv[NT][4];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t b = row0 + 16 * mt + 4 * kq + r;
-          const int64_t rt = (int64_t)t * rows + (b < rows ? b : 0);
-          const int unit = ubase + 16 * nt + ln;
-          gv[nt][r] = ld_gate4<G16>(gates, rt * gx_ld + 4 * unit);
-          ctv[nt][r] = cs[rt * H + unit];
-          cpv[nt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
-          dhv[nt][r] = dh[rt * H + unit];
-        }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int unit = ubase + 16 * nt + ln;
-#pragma unroll
-        for (int rp2 = 0; rp2 < 4; rp2 += 2) {
-          const f32x2 ig = {gv[nt][rp2].x, gv[nt][rp2 + 1].x}, fg = {gv[nt][rp2].y, gv[nt][rp2 + 1].y};
-          const f32x2 gg = {gv[nt][rp2].z, gv[nt][rp2 + 1].z}, og = {gv[nt][rp2].w, gv[nt][rp2 + 1].w};
-          const f32x2 cp = {cpv[nt][rp2], cpv[nt][rp2 + 1]};
-          const f32x2 dht = f32x2{dhv[nt][rp2], dhv[nt][rp2 + 1]} + f32x2{acc[mt][nt][rp2], acc[mt][nt][rp2 + 1]};
-          const f32x2 tc = tanh2(f32x2{ctv[nt][rp2], ctv[nt][rp2 + 1]});
-          const f32x2 dog = dht * tc * og * (1.f - og);
-          const f32x2 dc = dht * og * (1.f - tc * tc) + f32x2{dcar[mt][nt][rp2], dcar[mt][nt][rp2 + 1]};
-          const f32x2 di = dc * gg * ig * (1.f - ig);
-          const f32x2 df = dc * cp * fg * (1.f - fg);
-          const f32x2 dg = dc * ig * (1.f - gg * gg);
-          const f32x2 dcn = dc * fg;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int r = rp2 + k;
-            const int64_t b = row0 + 16 * mt + 4 * kq + r;
-            const bool v = b < rows;
-            dcar[mt][nt][r] = v ? dcn[k] : 0.f;
-            const uint2 pk = v ? make_uint2(pack_bf16x2(di[k], df[k]), pack_bf16x2(dg[k], dog[k])) : make_uint2(0u, 0u);
-            *reinterpret_cast<uint2*>(al + (16 * mt + 4 * kq + r) * AS + 4 * unit) = pk;
-            if (v) *reinterpret_cast<uint2*>(dgo + ((int64_t)t * rows + b) * gx_ld + 4 * unit) = pk;
-          }
-        }
-      }
-    }
-    lds_barrier();
-    // ---- dh_{t-1}[rows, this wave's units] = dgates_t . W_hh
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t > 0) {
-      uint4 bqA[KC][NT];
-      const uint16_t* wrow = wp + (int64_t)(ubase + ln) * (4 * H) + 8 * kq;
-      auto loadc = [&](uint4 (&bq)[KC][NT], int k0) {
+      for (int nt = 0; nt < NT; ++nt) { accp[mt][nt] = acc[mt][nt]; acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int ks = 0; ks < KC; ++ks)
+    for (int hv = 0; hv < HV; ++hv) {
+      // ---- cell backward of frame t for this lane's cells of half hv; dh_rec = the previous (later) frame's accumulators
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bq[ks][nt] = *reinterpret_cast<const uint4*>(wrow + (int64_t)(16 * nt) * (4 * H) + 32 * (k0 + ks));
-      };
-      auto mulc = [&](const uint4 (&bq)[KC][NT], int k0) {
+      for (int mt = 0; mt < MT; ++mt) {
+        float4 gv[NTH][4];
+        float ctv[NTH][4], cpv[NTH][4], dhv[NTH][4];
 #pragma unroll
-        for (int ks = 0; ks < KC; ++ks)
+        for (int n2 = 0; n2 < NTH; ++n2)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const uint4 a = *reinterpret_cast<const uint4*>(al + (16 * mt + ln) * AS + 32 * (k0 + ks) + 8 * kq);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][nt]), acc[mt][nt], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+            const int64_t b = row0 + 16 * mt + 4 * kq + r;
+            const int64_t rt = (int64_t)t * rows + (b < rows ? b : 0);
+            const int unit = unit_of(hv * NTH + n2);
+            gv[n2][r] = ld_gate4<G16>(gates, rt * gx_ld + 4 * unit);
+            ctv[n2][r] = cs[rt * H + unit];
+            cpv[n2][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
+            dhv[n2][r] = dh[rt * H + unit];
           }
-      };
-#pragma unroll 1
-      for (int k0 = 0; k0 < KS; k0 += KC) {
-        loadc(bqA, k0);
-        mulc(bqA, k0);
+#pragma unroll
+        for (int n2 = 0; n2 < NTH; ++n2) {
+          const int nt = hv * NTH + n2;
+          const int unit = unit_of(nt);
+#pragma unroll
+          for (int rp2 = 0; rp2 < 4; rp2 += 2) {
+            const f32x2 ig = {gv[n2][rp2].x, gv[n2][rp2 + 1].x}, fg = {gv[n2][rp2].y, gv[n2][rp2 + 1].y};
+            const f32x2 gg = {gv[n2][rp2].z, gv[n2][rp2 + 1].z}, og = {gv[n2][rp2].w, gv[n2][rp2 + 1].w};
+            const f32x2 cp = {cpv[n2][rp2], cpv[n2][rp2 + 1]};
+            const f32x2 dht = f32x2{dhv[n2][rp2], dhv[n2][rp2 + 1]} + f32x2{accp[mt][nt][rp2], accp[mt][nt][rp2 + 1]};
+            const f32x2 tc = tanh2(f32x2{ctv[n2][rp2], ctv[n2][rp2 + 1]});
+            const f32x2 dog = dht * tc * og * (1.f - og);
+            const f32x2 dc = dht * og * (1.f - tc * tc) + f32x2{dcar[mt][nt][rp2], dcar[mt][nt][rp2 + 1]};
+            const f32x2 di = dc * gg * ig * (1.f - ig);
+            const f32x2 df = dc * cp * fg * (1.f - fg);
+            const f32x2 dg = dc * ig * (1.f - gg * gg);
+            const f32x2 dcn = dc * fg;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int r = rp2 + k;
+              const int64_t b = row0 + 16 * mt + 4 * kq + r;
+              const bool v = b < rows;
+              dcar[mt][nt][r] = v ? dcn[k] : 0.f;
+              const uint2 pk = v ? make_uint2(pack_bf16x2(di[k], df[k]), pack_bf16x2(dg[k], dog[k])) : make_uint2(0u, 0u);
+              *reinterpret_cast<uint2*>(al + (16 * mt + 4 * kq + r) * AS + 4 * (unit - hv * (H / HV))) = pk;
+              if (v) *reinterpret_cast<uint2*>(dgo + ((int64_t)t * rows + b) * gx_ld + 4 * unit) = pk;
+            }
+          }
+        }
       }
+      lds_barrier();
+      // ---- dh_{t-1}[rows, this wave's units] += dgates_t[:, half hv] . W_hh[half hv, :]
+      if (t > 0) {
+        uint4 bqA[KC][NT];
+        auto loadc = [&](uint4 (&bq)[KC][NT], int k0) {
+#pragma unroll
+          for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (int64_t)unit_of(nt) * (4 * H) + 32 * (k0 + ks) + 8 * kq);
+        };
+        auto mulc = [&](const uint4 (&bq)[KC][NT], int k0) {
+#pragma unroll
+          for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const uint4 a = *reinterpret_cast<const uint4*>(al + (16 * mt + ln) * AS + 32 * (k0 + ks - hv * KSH) + 8 * kq);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][nt]), acc[mt][nt], 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int k0 = hv * KSH; k0 < (hv + 1) * KSH; k0 += KC) {
+          loadc(bqA, k0);
+          mulc(bqA, k0);
+        }
+      }
+      lds_barrier();
     }
-    lds_barrier();
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ launch
 bool lstm_rows_supported(int H) { return H == 256 || H == 384 || H == 512; }
 
-template <int H, int MT, bool G16, int NW = 8>
+template <int H, int MT, bool G16, int NW = 8, int HV = 1>
 static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
   const unsigned grid = (unsigned)((d.B + 16 * MT - 1) / (16 * MT));
   if (fwd) {
@@ -285,10 +296,10 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
     (void)once;
     hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
   } else {
-    const size_t sh = (size_t)16 * MT * (4 * H + 8) * 2;
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    const size_t sh = (size_t)16 * MT * (4 * H / HV + 8) * 2;
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16, HV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
     (void)once;
-    hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16, HV>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
   }
 }
 template <int H, int MT>
@@ -298,6 +309,10 @@ static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
 }
 
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  // forward, H = 384 (FullSubNet's sub-band model), measured ms per training step: 48 rows x 8 waves 110.8, 48 x 4 111.9, 80 x 8 114.8
+  // (spills), 80 rows x 4 waves 102.7 - one dispatch round over the chip instead of two.  SEFD_ROWS_FWD=38 selects 48 x 8.
+  static const int fv = getenv("SEFD_ROWS_FWD") ? atoi(getenv("SEFD_ROWS_FWD")) : 54;
+  if (fwd && d.H == 384 && fv == 54) { if (d.gxdt == DT_BF16) launch_r2<384, 5, true, 4>(d, ab, st, true); else launch_r2<384, 5, false, 4>(d, ab, st, true); return; }
   switch (d.H) {
     case 256: launch_r<256, 3>(d, ab, st, fwd); break;
     case 384: launch_r<384, 3>(d, ab, st, fwd); break;
