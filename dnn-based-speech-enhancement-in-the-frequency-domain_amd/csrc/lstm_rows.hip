@@ -106,12 +106,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
       if (t > 0) {
         // weight fragments in chunks of KC k-steps, double buffered: the loads of chunk c + 1 (L2, ~1 us) fly under the MFMAs of chunk c
         uint4 bqA[KC][4];
-        const uint16_t* wrow = wp + (int64_t)(4 * unit) * H + 8 * kq;
+        const uint16_t* wrow = wp + ((int64_t)ub * KS * 4 * 64 + lane) * 8;      // fragment-major packing (sefd_desc.h rows_wf_index)
         auto loadc = [&](uint4 (&bq)[KC][4], int k0) {
 #pragma unroll
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[ks][q] = *reinterpret_cast<const uint4*>(wrow + q * H + 32 * (k0 + ks));
+            for (int q = 0; q < 4; ++q) bq[ks][q] = *reinterpret_cast<const uint4*>(wrow + ((k0 + ks) * 4 + q) * 512);
         };
         auto mulc = [&](const uint4 (&bq)[KC][4], int k0) {
 #pragma unroll
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
 #pragma unroll
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (int64_t)unit_of(nt) * (4 * H) + 32 * (k0 + ks) + 8 * kq);
+            for (int nt = 0; nt < NT; ++nt)                       // fragment-major packing (sefd_desc.h rows_wb_index)
+              bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (((int64_t)(unit_of(nt) >> 4) * KS + k0 + ks) * 64 + lane) * 8);
         };
         auto mulc = [&](const uint4 (&bq)[KC][NT], int k0) {
 #pragma unroll

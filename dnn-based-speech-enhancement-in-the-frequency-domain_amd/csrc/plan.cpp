@@ -2190,7 +2190,13 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         RunGemm pk = step_gemm(L.h, adt, rows, H, 0, 4 * H, L.gates, 4 * H, 0, DT_F32, 0);
         Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(Whh, (int64_t)gate_torch_row(nn, H) * H + j, 1); };
         b.pack_weights(Fw, pk, chh, L.nm + ".hhpk", tag);
-        if (pk.ldw != H) { P->error = "FullSubNet: packed W_hh layout"; return b.none(); }
+        if (pk.ldw != H || pk.Npad != 4 * H) { P->error = "FullSubNet: packed W_hh layout"; return b.none(); }
+        {   // re-order the gather table into MFMA B-fragment order: one wave-load of the kernel = 1 KB contiguous (lstm_rows.hip)
+          int32_t* tab = reinterpret_cast<int32_t*>(P->consts.data() + Fw.back().pack.tab.off);
+          std::vector<int32_t> old(tab, tab + (size_t)4 * H * H);
+          for (int c = 0; c < 4 * H; ++c)
+            for (int k = 0; k < H; ++k) tab[rows_wf_index(H, c, k)] = old[(size_t)c * H + k];
+        }
         r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none(); r.gxdt = L.sdt;
       }
       b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
@@ -2329,7 +2335,13 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
           RunGemm pk = step_gemm(dgates, adt, rows, 4 * H, 0, H, dh, H, 0, DT_F32, 0);
           Builder::Coef cT = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)gate_torch_row(j, H) * H + nn, 1); };
           b.pack_weights(R, pk, cT, L.nm + ".hhTpk", tag);
-          if (pk.ldw != 4 * H) { P->error = "FullSubNet: packed W_hh^T layout"; return; }
+          if (pk.ldw != 4 * H || pk.Npad != H) { P->error = "FullSubNet: packed W_hh^T layout"; return; }
+          {
+            int32_t* tab = reinterpret_cast<int32_t*>(P->consts.data() + R.back().pack.tab.off);
+            std::vector<int32_t> old(tab, tab + (size_t)4 * H * H);
+            for (int n = 0; n < H; ++n)
+              for (int k = 0; k < 4 * H; ++k) tab[rows_wb_index(H, n, k)] = old[(size_t)n * 4 * H + k];
+          }
           r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none(); r.gxdt = L.sdt;
         }
         b.push(R, OP_LSTM_BWD, tag).lstm = r;

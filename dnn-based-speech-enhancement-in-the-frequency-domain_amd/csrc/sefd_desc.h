@@ -375,6 +375,16 @@ constexpr int kWgTN = 64, kWgTK = 128, kWgRows = 32;       // WGRAD block tile (
 static inline constexpr int wgrad_tn(int xdt, int N, int Npad) {
   return xdt != DT_BF16 ? kWgTN : Npad >= 128 ? 128 : N > 32 ? 64 : 32;
 }
+// Packed bf16 W_hh of the row-block LSTM kernels (lstm_rows.hip), in MFMA 16x16x32 B-fragment order: the 64 lanes of a wave read
+// 64 x 16 contiguous bytes.  Forward: element (gate column c = 4 * unit + q, input k); backward: element (unit n, gate column k).
+static inline int64_t rows_wf_index(int H, int c, int k) {
+  const int u = c >> 2, q = c & 3, ub = u >> 4, ln = u & 15, ks = k >> 5, kq = (k & 31) >> 3, e = k & 7;
+  return ((((int64_t)(ub * (H / 32) + ks) * 4 + q) * 64 + (kq * 16 + ln)) * 8) + e;
+}
+static inline int64_t rows_wb_index(int H, int n, int k) {
+  const int nt = n >> 4, ln = n & 15, ks = k >> 5, kq = (k & 31) >> 3, e = k & 7;
+  return (((int64_t)(nt * (4 * H / 32) + ks) * 64 + (kq * 16 + ln)) * 8) + e;
+}
 inline int esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
 
 }  // namespace sefd
