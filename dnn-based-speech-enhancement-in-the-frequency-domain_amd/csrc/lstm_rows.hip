@@ -310,9 +310,10 @@ static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
 }
 
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
-  // forward, H = 384 (FullSubNet's sub-band model), measured ms per training step: 48 rows x 8 waves 110.8, 48 x 4 111.9, 80 x 8 114.8
-  // (spills), 80 rows x 4 waves 102.7 - one dispatch round over the chip instead of two.  SEFD_ROWS_FWD=38 selects 48 x 8.
-  static const int fv = getenv("SEFD_ROWS_FWD") ? atoi(getenv("SEFD_ROWS_FWD")) : 54;
+  // forward, H = 384 (FullSubNet's sub-band model), ms per training step.  Row-major packed weights: 48 rows x 8 waves 110.8, 48 x 4 111.9,
+  // 80 rows x 4 waves 102.7.  Fragment-major weights: 88.6 / 88.7 / 89.9 - the geometry stopped mattering (HBM-bound); 48 x 8 is launched,
+  // SEFD_ROWS_FWD=54 / 34 select the others.
+  static const int fv = getenv("SEFD_ROWS_FWD") ? atoi(getenv("SEFD_ROWS_FWD")) : 0;
   if (fwd && d.H == 384 && fv == 54) { if (d.gxdt == DT_BF16) launch_r2<384, 5, true, 4>(d, ab, st, true); else launch_r2<384, 5, false, 4>(d, ab, st, true); return; }
   switch (d.H) {
     case 256: launch_r<256, 3>(d, ab, st, fwd); break;
