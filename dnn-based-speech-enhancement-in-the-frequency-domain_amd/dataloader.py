@@ -130,3 +130,26 @@ def create_dataloader(mode, type=0, snr=0, path=None, rank=None, world=None, dev
     ds = Wave_Dataset(mode, type, snr, path)
     train = mode == "train"
     return ShardedBatchLoader(ds, cfg.batch, shuffle=train, drop_last=train, rank=rank, world=world, seed=seed, device=device)
+
+
+def mix_snr(speech, noise_bank, noise_start, snr_db, quantize=True):
+    """On-GPU replacement of generate_noisy_data.py:46-67 for a batch: speech [B, L] fp32 cuda, noise_bank flat fp32 cuda, noise_start [B] int64
+    (the reference draws it with np.random.randint(0, len_noise - len_speech)), snr_db [B] -> noisy [B, L].  quantize reproduces the int16
+    file round trip of the offline script.  HIP kernels behind sefd_mix_snr; no CPU fallback."""
+    import torch
+    from . import _lib
+    if not speech.is_cuda:
+        raise RuntimeError("sefd mix_snr runs on the MI355X only (cuda tensors)")
+    speech = speech.float().contiguous()
+    B, L = speech.shape
+    noise_bank = noise_bank.float().contiguous().view(-1)
+    st = torch.as_tensor(noise_start, dtype=torch.int64, device=speech.device).contiguous()
+    snr = torch.as_tensor(snr_db, dtype=torch.float32, device=speech.device).contiguous()
+    assert int(st.max()) + L <= noise_bank.numel() and st.numel() == B and snr.numel() == B
+    ws = torch.empty(4 * B, dtype=torch.float64, device=speech.device)
+    out = torch.empty_like(speech)
+    rc = _lib.lib().sefd_mix_snr(speech.data_ptr(), noise_bank.data_ptr(), st.data_ptr(), snr.data_ptr(), B, L, 1 if quantize else 0,
+                                 ws.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"sefd_mix_snr failed ({rc})")
+    return out

@@ -116,6 +116,12 @@ int32_t sefd_lms_backward(const float* clean_r, const float* clean_i, const floa
 /* ---- FullSubNet training targets (trainer.py:100-104; tools_for_model.py:683-717) -------------------------------------
  * noisy_c64 / clean_c64: interleaved complex64 [n] (the torch.stft outputs).  Any of mag / phase / cirm may be NULL.
  * mag = |noisy| (mag_phase), phase = angle(noisy), cirm [n][2] = compress_cIRM(build_complex_ideal_ratio_mask(noisy, clean)). */
+/* On-GPU SNR mixing of a batch (replaces the offline generate_noisy_data.py:46-67 `generate_noisy_wav`, the random segment start chosen by
+   the caller): noisy[b] = speech[b] + alpha_b * noise[noise_start[b] : +L], alpha_b = sqrt(10^(-snr_db[b]/10) * P_speech / (P_noise + 1e-6)) with
+   the powers taken after removing the DC bias; quantize != 0 adds the reference's int16 file round trip.  speech / noisy [B][L] fp32, noise a
+   flat fp32 bank, ws: 4 * B doubles.  All device pointers. */
+int32_t sefd_mix_snr(const float* speech, const float* noise, const int64_t* noise_start, const float* snr_db, int32_t B, int32_t L,
+                     int32_t quantize, double* ws, float* noisy, void* stream);
 int32_t sefd_fsn_targets(const float* noisy_c64, const float* clean_c64, int64_t n, float* mag, float* phase, float* cirm, void* stream);
 
 /* ---- Adam (torch.optim.Adam defaults, train_interface.py:59) on flat fp32 buffers ------------------

@@ -196,3 +196,30 @@ def test_train_interface_driver_writes_the_reference_artifacts_and_resumes(tmp_p
         del cfg.chkpt_path
     assert d2 == d and os.path.exists(os.path.join(d, "chkpt_3.pt")) and o2._step == 6 and mse2[0] == mse[0] and mse2[2] != 0
     _cfg(job_dir='./models/', logs_dir='./logs/', expr_num='EXPERIMENT_NUMBER', batch=10)
+
+
+@pytest.mark.gpu
+def test_on_gpu_snr_mixing_against_the_offline_script():
+    """generate_noisy_data.py:46-67 on the GPU for a batch (sefd_mix_snr): same samples as the offline numpy path (restated in
+    oracle/mixing.py and pinned to the reference function on CPU), including the int16 truncation; one LSB of slack on a handful of
+    samples (one-pass variance in the kernel, two-pass in numpy)."""
+    import numpy as np
+    import sefd_amd  # noqa: F401
+    from sefd_amd.dataloader import mix_snr
+    from oracle.mixing import generate_noisy_wav
+    rng = np.random.default_rng(3)
+    B, L = 5, 48000
+    speech = (rng.standard_normal((B, L)) * 0.08 + 0.003).astype(np.float32)
+    noise = (rng.standard_normal(400000) * 0.2 - 0.01).astype(np.float32)
+    start = rng.integers(0, noise.size - L, B)
+    snr = np.array([0, 5, 10, -5, 15], np.float32)
+    got = mix_snr(torch.from_numpy(speech).cuda(), torch.from_numpy(noise).cuda(), start, snr, quantize=True).cpu().numpy()
+    for b in range(B):
+        want = generate_noisy_wav(speech[b].astype(np.float64), noise.astype(np.float64), float(snr[b]), int(start[b])).astype(np.float64) / 32768
+        d = np.abs(got[b].astype(np.float64) - want) * 32768
+        assert d.max() <= 1.0 + 1e-6 and (d > 0.5).mean() < 1e-4, (b, d.max(), (d > 0.5).mean())
+    raw = mix_snr(torch.from_numpy(speech).cuda(), torch.from_numpy(noise).cuda(), start, snr, quantize=False).cpu().numpy()
+    want = generate_noisy_wav(speech[1].astype(np.float64), noise.astype(np.float64), 5.0, int(start[1]), quantize=False)
+    assert np.abs(raw[1] - want).max() < 1e-6
+    with pytest.raises(RuntimeError):
+        mix_snr(torch.from_numpy(speech), torch.from_numpy(noise), start, snr)
