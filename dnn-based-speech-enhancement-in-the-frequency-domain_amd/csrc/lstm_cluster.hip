@@ -79,6 +79,8 @@ constexpr int kMaxMT = 8;
 template <int H, bool PF>
 __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT) {
   constexpr int KS = H / 32;
+  constexpr int HAS = H + 8, HCPR = H / 8, HNCH = (16 * HCPR + 255) / 256;      // cooperative gather tile: row stride, chunks per row / thread
+  __shared__ __attribute__((aligned(16))) uint16_t htile[PF ? 8 : 2 * 16 * HAS];
   __shared__ __attribute__((aligned(16))) uint16_t stage[4][16 * 16];
   __shared__ __attribute__((aligned(16))) float4 cst[4][kMaxMT][64];
   const int T = d.T;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
       }
     }
   };
-  int t = tb, mt = 0;
+  int t = tb, mt = 0, hpar = 0;
   auto tile = [&](const float4 (&cur)[4], float4 (&pre)[4]) {
     f32x4 acc[4];
 #pragma unroll
@@ -176,7 +178,41 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
           have = !__any((bad & 0x80008000u) != 0);
         }
       }
-      if (!have) gather<KS>(hres(t - 1), a_off(mt), 64u, a, budget);
+      if constexpr (!PF) {
+        // the 16 x H tile of h_{t-1} is gathered once per workgroup (thread i: chunks i, i + 256, ...: whole lines, a quarter of the loads and
+        // checks per wave), shared through a ping-pong LDS tile - see the backward kernel
+        const auto rs = hres(t - 1);
+        uint16_t* at = htile + hpar * 16 * HAS;
+        u32x4 ch[HNCH];
+        uint32_t off[HNCH];
+#pragma unroll
+        for (int i = 0; i < HNCH; ++i) {
+          const int c = (int)threadIdx.x + 256 * i, row = c / HCPR, col = c - row * HCPR;
+          const int b = b0 + 16 * mt + row;
+          off[i] = (uint32_t)(((int64_t)(b < d.B ? b : 0) * rstr * H + 8 * col) * 2);
+        }
+        for (;;) {
+          uint32_t bad = 0;
+#pragma unroll
+          for (int i = 0; i < HNCH; ++i) if (HNCH * 256 == 16 * HCPR || (int)threadIdx.x + 256 * i < 16 * HCPR) ch[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[i], 0, kSc1);
+#pragma unroll
+          for (int i = 0; i < HNCH; ++i) if (HNCH * 256 == 16 * HCPR || (int)threadIdx.x + 256 * i < 16 * HCPR) bad = unset4(bad, ch[i]);
+          if (!__any((bad & 0x80008000u) != 0) || budget <= 0) break;
+          --budget;
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int i = 0; i < HNCH; ++i) {
+          const int c = (int)threadIdx.x + 256 * i, row = c / HCPR, col = c - row * HCPR;
+          if (HNCH * 256 == 16 * HCPR || c < 16 * HCPR) *reinterpret_cast<u32x4*>(at + row * HAS + 8 * col) = ch[i];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const u32x4*>(at + (lane & 15) * HAS + 32 * ks + 8 * kq);
+        hpar ^= 1;
+      } else {
+        if (!have) gather<KS>(hres(t - 1), a_off(mt), 64u, a, budget);
+      }
       issue_next(t, mt);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -243,7 +279,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
 template <int H>
 __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT) {
   constexpr int KS = 4 * H / 32;                 // k32 steps over the 4H gate columns
-  constexpr int GK = (KS % 16 == 0 && H < 512) ? 16 : 8;   // fragments gathered at a time (KS = H/8 is a multiple of 8; 8 at H = 512: registers)
+  constexpr int AS = 4 * H + 8, CPR = 4 * H / 8, NCH = 16 * CPR / 256;   // LDS tile row stride, 16-byte chunks per row, chunks per thread
+  constexpr bool DB = H <= 448;                  // two tiles (ping-pong, one barrier per tile) while 2 x 16 x 4H bf16 fits next to the rest
+  __shared__ __attribute__((aligned(16))) uint16_t atile[(DB ? 2 : 1) * 16 * AS];
   __shared__ __attribute__((aligned(16))) uint16_t stage[4][16 * 64];
   __shared__ __attribute__((aligned(16))) float4 dcs[4][kMaxMT][64];
   const int T = d.T;
@@ -281,7 +319,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, 
   };
   for (int mt = 0; mt < MT; ++mt) dcs[w][mt][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   uint16_t* stg = &stage[w][0];
-  int budget = kSpinBudget;
+  int budget = kSpinBudget, par = 0;
   const int ntile = T * MT;
 
   struct Sav { float4 g[4]; float cp[4], ct[4], dh[4]; };
@@ -304,19 +342,44 @@ __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, 
     fetch(pre);
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     if (t < T - 1) {
+      // The 16 x 4H tile of dgates_{t+1} is gathered ONCE per workgroup: thread i takes the 16-byte chunks i, i + 256, ... (whole lines,
+      // a quarter of the tile and of the validity checks per wave instead of all of it), re-reads them until none holds an unwritten
+      // half-word, and puts them into the LDS tile; after the barrier every wave reads its A fragments from there.
       const auto r = gres(t + 1);
-      const int b = b0 + 16 * mt + (lane & 15);
-      const uint32_t o = (uint32_t)(((int64_t)(b < d.B ? b : 0) * rstr * gx_ld + 8 * kq) * 2);
+      uint16_t* at = atile + (DB ? par * 16 * AS : 0);
+      u32x4 ch[NCH];
+      uint32_t off[NCH];
 #pragma unroll
-      for (int k0 = 0; k0 < KS; k0 += GK) {
-        u32x4 a[GK];
-        gather<GK>(r, o + 64u * k0, 64u, a, budget);
-#pragma unroll
-        for (int i = 0; i < GK; i += 2) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, wreg[k0 + i]), a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i + 1]), __builtin_bit_cast(bf16x8, wreg[k0 + i + 1]), a1, 0, 0, 0);
-        }
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (int)threadIdx.x + 256 * i, row = c / CPR, col = c - row * CPR;
+        const int b = b0 + 16 * mt + row;
+        off[i] = (uint32_t)(((int64_t)(b < d.B ? b : 0) * rstr * gx_ld + 8 * col) * 2);
       }
+      for (;;) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) ch[i] = __builtin_amdgcn_raw_buffer_load_b128(r, off[i], 0, kSc1);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) bad = unset4(bad, ch[i]);
+        if (!__any((bad & 0x80008000u) != 0) || budget <= 0) break;
+        --budget;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!DB) lds_barrier();                     // single tile (H = 512): the previous tile's readers must be done before it is overwritten
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (int)threadIdx.x + 256 * i, row = c / CPR, col = c - row * CPR;
+        *reinterpret_cast<u32x4*>(at + row * AS + 8 * col) = ch[i];
+      }
+      lds_barrier();
+#pragma unroll
+      for (int ks = 0; ks < KS; ks += 2) {
+        const u32x4 x0 = *reinterpret_cast<const u32x4*>(at + (lane & 15) * AS + 32 * ks + 8 * kq);
+        const u32x4 x1 = *reinterpret_cast<const u32x4*>(at + (lane & 15) * AS + 32 * (ks + 1) + 8 * kq);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x0), __builtin_bit_cast(bf16x8, wreg[ks]), a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x1), __builtin_bit_cast(bf16x8, wreg[ks + 1]), a1, 0, 0, 0);
+      }
+      par ^= 1;
     }
     const f32x4 dhrec = a0 + a1;
     const float4 dcv = dcs[w][mt][lane];
