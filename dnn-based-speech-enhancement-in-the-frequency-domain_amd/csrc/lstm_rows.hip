@@ -56,7 +56,7 @@ __device__ __forceinline__ void st_gate4(char* base, int64_t o, float a, float b
 // ---------------------------------------------------------------------------------------------------------------- forward
 // NW = 8 waves per workgroup, two per SIMD: the loads of one wave (gate pre-activations from HBM, weight fragments from L2) wait under
 // the other's MFMAs (measured on FullSubNet's sub-band layers, ms per launch: 4 waves 19.7 forward / 18.5 backward)
-template <int H, int MT, int NW, bool G16>
+template <int H, int MT, int NW, bool G16, bool XK>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
   constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = (KS % 3 == 0 ? 3 : 4) * (NW == 4 ? 2 : 1), NTHR = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS]
@@ -71,6 +71,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_f));   // [4H][H] bf16, row = gate column 4 * unit + q
   const int kq = lane >> 4, ln = lane & 15;
   const int64_t gx_ld = d.gx_ld;
+  const uint16_t* xin = XK ? reinterpret_cast<const uint16_t*>(rp(ab, d.xin)) : nullptr;      // [T][rows][32] bf16
+  const uint16_t* wx = XK ? reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_x)) : nullptr;
+  const float* bias = XK ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                  // h_{-1} = 0
   __syncthreads();
   bool rvalid[MT][4];
@@ -86,16 +89,31 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
   for (int t = 0; t < T; ++t) {
     const uint16_t* hc = hl + (t & 1) * RB * HS;
     uint16_t* hn = hl + ((t + 1) & 1) * RB * HS;
+    uint4 xa[XK ? MT : 1];                          // fused input projection: A fragments of x_t (one k-step of 32 features), all unit blocks
+    if constexpr (XK) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int64_t b = row0 + 16 * mt + ln;
+        xa[mt] = *reinterpret_cast<const uint4*>(xin + ((int64_t)t * rows + (b < rows ? b : 0)) * 32 + 8 * kq);
+      }
+    }
     for (int ub = w; ub < NUB; ub += NW) {
       const int unit = 16 * ub + ln;
-      typename GateRaw<G16>::type gxr[MT][4];      // raw gate pre-activations (bf16: 8 bytes per cell), converted in the epilogue
+      typename GateRaw<G16>::type gxr[XK ? 1 : MT][4];      // raw gate pre-activations (bf16: 8 bytes per cell), converted in the epilogue
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint4 bx[4];
       float cpv[MT][4];
+      if constexpr (XK) {
+        bias4 = *reinterpret_cast<const float4*>(bias + 4 * unit);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const uint4*>(wx + ((int64_t)(ub * 4 + q) * 64 + lane) * 8);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t rt = (int64_t)t * rows + rrow[mt][r];
-          gxr[mt][r] = *reinterpret_cast<const typename GateRaw<G16>::type*>(gx + (rt * gx_ld + 4 * unit) * (G16 ? 2 : 4));
+          if constexpr (!XK) gxr[mt][r] = *reinterpret_cast<const typename GateRaw<G16>::type*>(gx + (rt * gx_ld + 4 * unit) * (G16 ? 2 : 4));
           cpv[mt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
         }
       f32x4 acc[MT][4];
@@ -132,11 +150,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
           mulc(bqA, k0);
         }
       }
+      if constexpr (XK) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa[mt]), __builtin_bit_cast(bf16x8, bx[q]), acc[mt][q], 0, 0, 0);
+      }
       float4 gxv[MT][4];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gxv[mt][r] = GateRaw<G16>::cvt(gxr[mt][r]);
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (XK) gxv[mt][r] = bias4; else gxv[mt][r] = GateRaw<G16>::cvt(gxr[mt][r]);
+        }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -293,9 +320,15 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
   const unsigned grid = (unsigned)((d.B + 16 * MT - 1) / (16 * MT));
   if (fwd) {
     const size_t sh = (size_t)2 * 16 * MT * (H + 8) * 2;
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-    (void)once;
-    hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    if (d.xfeat == 32) {
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+      (void)once;
+      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, true>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    } else {
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+      (void)once;
+      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, false>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    }
   } else {
     const size_t sh = (size_t)16 * MT * (4 * H / HV + 8) * 2;
     static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16, HV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();

@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk; int sdt; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse; int sdt; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2175,7 +2175,22 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     else L.bgx = [=](int nn, int32_t* o) { const int q = um ? gate_torch_row(nn, H) : nn; o[0] = pe(bih, q, 1); o[1] = pe(bhh, q, 1); };
     b.pack_weights(Fw, g, L.cgx, L.nm + ".ih", tag, &L.bgx);
     set_y(g, L.gates, rows, 4 * H, 0);
-    b.push(Fw, OP_RUNGEMM, tag).g = g;
+    // row-block kernels, 32 input features (the sub-band model's first layer): the input projection is fused into the recurrence (one more
+    // k-step per frame) instead of writing and re-reading a [T x rows x 4H] pre-activation slab (8 GB at B = 64); SEFD_LSTM_XFUSE=0 keeps the GEMM
+    L.xfuse = L.rowsk && xlen == 32 && xfeat == 32 && g.ldw == 64 && !(getenv("SEFD_LSTM_XFUSE") && atoi(getenv("SEFD_LSTM_XFUSE")) == 0);
+    if (L.xfuse) {
+      // the packed W_ih ([4H][64], K = 32 zero padded) re-ordered to MFMA B-fragment order in its first 4H x 32 slots
+      int32_t* tab = nullptr;
+      for (auto it = Fw.rbegin(); it != Fw.rend(); ++it)
+        if (it->kind == OP_PACK && it->pack.dst.arena == g.w.arena && it->pack.dst.off == g.w.off) { tab = reinterpret_cast<int32_t*>(P->consts.data() + it->pack.tab.off); break; }
+      if (!tab) { P->error = "FullSubNet: packed W_ih not found"; return b.none(); }
+      std::vector<int32_t> old(tab, tab + (size_t)4 * H * 64);
+      std::fill(tab, tab + (size_t)4 * H * 64, 0);
+      for (int c = 0; c < 4 * H; ++c)
+        for (int k = 0; k < 32; ++k) tab[rows_wf_index(32, c, k)] = old[(size_t)c * 64 + k];
+    } else {
+      b.push(Fw, OP_RUNGEMM, tag).g = g;
+    }
     L.gx = g;
     if (L.cluster) {
       LstmRec r;
@@ -2198,6 +2213,8 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
             for (int k = 0; k < H; ++k) tab[rows_wf_index(H, c, k)] = old[(size_t)c * H + k];
         }
         r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none(); r.gxdt = L.sdt;
+        r.xin = r.wpk_x = r.bias = b.none();
+        if (L.xfuse) { r.xin = x; r.wpk_x = g.w; r.bias = g.bias; r.xfeat = 32; }
       }
       b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
     } else if (gru) {

@@ -173,6 +173,11 @@ struct LstmRec {
   // workgroup owns 48 sequences and ALL hidden units, h_t / dgates_t live in LDS, the packed bf16 weights are streamed from L2 every
   // frame: wpk_f = W_hh as [4H gate columns (unit-major)][H], wpk_b = its transpose [H][4H] (both written by PACK ops of the plan)
   Ptr wpk_f, wpk_b;
+  // impl 1, forward, xfeat == 32 (the sub-band model's first layer: 31 neighbour bins + the full-band output): the input projection is
+  // fused - gate pre-activations = bias (b_ih + b_hh, fp32 [4H] unit-major) + x_t . W_ih^T (xin bf16 [T][rows][32], wpk_x packed like
+  // wpk_f with ONE k-step: rows_wf_index(32, c, k)) + h_{t-1} . W_hh^T; `gx` is not read (no 8 GB pre-activation slab to write and re-read)
+  Ptr xin, wpk_x, bias;
+  int32_t xfeat, pad3_;
   int32_t gxdt, pad2_;          // impl 1 only: dtype of the gx / gates slabs (DT_BF16 halves the HBM traffic that bounds these layers; the cell
                                // update itself uses the unrounded fp32 gate values, the backward reads the stored ones)
 };

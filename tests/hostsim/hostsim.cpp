@@ -680,7 +680,14 @@ void run_op(const Op& op, const AB& ab) {
             for (int j = 0; j < H; ++j) {
               double pre[4];
               for (int q = 0; q < 4; ++q) {
-                double s = ld(rp(ab, d.gx), sdt, gxo + gate_col(q, j));
+                double s;
+                if (d.impl == 1 && d.xfeat == 32) {          // fused input projection: bias + x_t . W_ih^T from the fragment-ordered packed copy
+                  const int c = gate_col(q, j);
+                  s = ((const float*)rp(ab, d.bias))[c];
+                  for (int k = 0; k < 32; ++k) s += (double)ld(rp(ab, d.xin), DT_BF16, rt * 32 + k) * ld(rp(ab, d.wpk_x), DT_BF16, rows_wf_index(32, c, k));
+                } else {
+                  s = ld(rp(ab, d.gx), sdt, gxo + gate_col(q, j));
+                }
                 const float* wr = whh.data() + (int64_t)(q * H + j) * H;
                 for (int k = 0; k < H; ++k) s += h[k] * wr[k];
                 pre[q] = s;
