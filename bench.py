@@ -74,7 +74,7 @@ def pmc_traffic(kernel_prefixes):
     return round(tot / n) if n else None
 
 
-def roofline(plan, arenas):
+def roofline(plan, arenas, pmc_ok=True):
     """Every MFMA GEMM, LSTM recurrence and STFT launch of one step is timed with HIP events on the launch stream while the
     whole phase runs in program order on that ONE stream (each op sees the cache state its predecessors left; the two-stream
     overlap of the real step is off, so these are per-kernel rates, not a decomposition of ms_per_step).
@@ -141,7 +141,7 @@ def roofline(plan, arenas):
     prefixes = {"rungemm": ["rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float"],
                 "cgemm256": ["cgemm256_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
     return dict(bound="mfma", kernel=f"{key[0]}<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                frac=round(achieved / peak, 4), traffic=pmc_traffic(prefixes), launches_per_step=a["launches"],
+                frac=round(achieved / peak, 4), traffic=pmc_traffic(prefixes) if pmc_ok else None, launches_per_step=a["launches"],
                 avg_launch_ms=round(a["ms"] / a["launches"], 4),
                 timing="per-launch HIP events, whole phase in program order on one stream (no two-stream overlap)", kernels=detail)
 
@@ -249,7 +249,8 @@ def main():
             else:
                 rt = next(v for k, v in model._runtimes.items() if isinstance(k[0], int))
                 plan, arenas = rt.plan, rt.arenas
-            out["roofline"] = roofline(plan, arenas)
+            # the committed PMC summary was collected on the default workload (DCCRN, B = 32): other workloads report traffic null
+            out["roofline"] = roofline(plan, arenas, pmc_ok=(args.model == "dccrn" and B == 32))
             info = [plan.op_info(ph, i) for ph in (0, 1) for i in range(plan.num_ops(ph))]
             mf = sum(o["flops"] for o in info if o["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD))
             peak = PEAK_TFLOPS[1 if args.dtype == "bf16" else 0]
