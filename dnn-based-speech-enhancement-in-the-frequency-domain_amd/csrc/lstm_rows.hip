@@ -56,10 +56,14 @@ __device__ __forceinline__ void st_gate4(char* base, int64_t o, float a, float b
 // ---------------------------------------------------------------------------------------------------------------- forward
 // NW = 8 waves per workgroup, two per SIMD: the loads of one wave (gate pre-activations from HBM, weight fragments from L2) wait under
 // the other's MFMAs (measured on FullSubNet's sub-band layers, ms per launch: 4 waves 19.7 forward / 18.5 backward)
-template <int H, int MT, int NW, bool G16, bool XK>
+// XF: input features whose projection is fused into the recurrence: 0 (gx holds the hoisted GEMM's pre-activations), 32 (one extra k-step,
+// A fragments of x_t in registers) or H (x_t = the layer below's h_t: a third LDS tile, H/32 more k-steps per unit block)
+template <int H, int MT, int NW, bool G16, int XF>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
   constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = (KS % 3 == 0 ? 3 : 4) * (NW == 4 ? 2 : 1), NTHR = NW * 64;
-  extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS]
+  constexpr bool XK = XF > 0, X32 = XF == 32, XH = XF == H && H != 32;
+  static_assert(XF == 0 || X32 || XH, "fused input width");
+  extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS] (+ [RB][HS] for x_t when XH)
   const int T = d.T;
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +79,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
   const uint16_t* wx = XK ? reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_x)) : nullptr;
   const float* bias = XK ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                  // h_{-1} = 0
+  uint16_t* xl = hl + 2 * RB * HS;
+  auto fill_x = [&](int tt) {                      // x_tt of the workgroup's rows -> LDS (16-byte chunks)
+    if constexpr (XH) {
+      for (int i = tid; i < RB * (H / 8); i += NTHR) {
+        const int row = i / (H / 8), ch = i - row * (H / 8);
+        const int64_t b = row0 + row;
+        *reinterpret_cast<uint4*>(xl + row * HS + 8 * ch) = *reinterpret_cast<const uint4*>(xin + ((int64_t)tt * rows + (b < rows ? b : 0)) * H + 8 * ch);
+      }
+    }
+  };
+  fill_x(0);
   __syncthreads();
   bool rvalid[MT][4];
   int64_t rrow[MT][4];
@@ -89,8 +104,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
   for (int t = 0; t < T; ++t) {
     const uint16_t* hc = hl + (t & 1) * RB * HS;
     uint16_t* hn = hl + ((t + 1) & 1) * RB * HS;
-    uint4 xa[XK ? MT : 1];                          // fused input projection: A fragments of x_t (one k-step of 32 features), all unit blocks
-    if constexpr (XK) {
+    uint4 xa[X32 ? MT : 1];                         // fused input projection: A fragments of x_t (one k-step of 32 features), all unit blocks
+    if constexpr (X32) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int64_t b = row0 + 16 * mt + ln;
@@ -103,8 +118,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
       uint4 bx[4];
       float cpv[MT][4];
-      if constexpr (XK) {
-        bias4 = *reinterpret_cast<const float4*>(bias + 4 * unit);
+      if constexpr (XK) bias4 = *reinterpret_cast<const float4*>(bias + 4 * unit);
+      if constexpr (X32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bx[q] = *reinterpret_cast<const uint4*>(wx + ((int64_t)(ub * 4 + q) * 64 + lane) * 8);
       }
@@ -121,10 +136,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t > 0) {
-        // weight fragments in chunks of KC k-steps, double buffered: the loads of chunk c + 1 (L2, ~1 us) fly under the MFMAs of chunk c
+      // weight fragments in chunks of KC k-steps (fragment-major packing, sefd_desc.h rows_wf_index), A fragments from an LDS tile
+      auto gemm_part = [&](const uint16_t* wbase, const uint16_t* atile) {
         uint4 bqA[KC][4];
-        const uint16_t* wrow = wp + ((int64_t)ub * KS * 4 * 64 + lane) * 8;      // fragment-major packing (sefd_desc.h rows_wf_index)
+        const uint16_t* wrow = wbase + ((int64_t)ub * KS * 4 * 64 + lane) * 8;
         auto loadc = [&](uint4 (&bq)[KC][4], int k0) {
 #pragma unroll
           for (int ks = 0; ks < KC; ++ks)
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              const uint4 a = *reinterpret_cast<const uint4*>(hc + (16 * mt + ln) * HS + 32 * (k0 + ks) + 8 * kq);
+              const uint4 a = *reinterpret_cast<const uint4*>(atile + (16 * mt + ln) * HS + 32 * (k0 + ks) + 8 * kq);
 #pragma unroll
               for (int q = 0; q < 4; ++q)
                 acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][q]), acc[mt][q], 0, 0, 0);
@@ -149,8 +164,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
           loadc(bqA, k0);
           mulc(bqA, k0);
         }
-      }
-      if constexpr (XK) {
+      };
+      if (t > 0) gemm_part(wp, hc);
+      if constexpr (XH) gemm_part(wx, xl);
+      if constexpr (X32) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -192,6 +209,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
       const int row = i / (H / 8), ch = i - row * (H / 8);
       if (row0 + row < rows)
         *reinterpret_cast<uint4*>(hout + ((int64_t)t * rows + row0 + row) * H + 8 * ch) = *reinterpret_cast<const uint4*>(hn + row * HS + 8 * ch);
+    }
+    if constexpr (XH) {                             // every wave is past the barrier: x_t is no longer read; x_{t+1} must be visible before the next frame
+      if (t + 1 < T) fill_x(t + 1);
+      lds_barrier();
     }
   }
 }
@@ -320,14 +341,19 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
   const unsigned grid = (unsigned)((d.B + 16 * MT - 1) / (16 * MT));
   if (fwd) {
     const size_t sh = (size_t)2 * 16 * MT * (H + 8) * 2;
-    if (d.xfeat == 32) {
-      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    if (d.xfeat == H && H != 32) {
+      const size_t sh3 = (size_t)3 * 16 * MT * (H + 8) * 2;
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
       (void)once;
-      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, true>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, H>), dim3(grid), dim3(NW * 64), sh3, st, d, ab);
+    } else if (d.xfeat == 32) {
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+      (void)once;
+      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, 32>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
     } else {
-      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
       (void)once;
-      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, false>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, 0>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
     }
   } else {
     const size_t sh = (size_t)16 * MT * (4 * H / HV + 8) * 2;

@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse; int sdt; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse; int sdt, xf; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2177,17 +2177,21 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     set_y(g, L.gates, rows, 4 * H, 0);
     // row-block kernels, 32 input features (the sub-band model's first layer): the input projection is fused into the recurrence (one more
     // k-step per frame) instead of writing and re-reading a [T x rows x 4H] pre-activation slab (8 GB at B = 64); SEFD_LSTM_XFUSE=0 keeps the GEMM
-    L.xfuse = L.rowsk && xlen == 32 && xfeat == 32 && g.ldw == 64 && !(getenv("SEFD_LSTM_XFUSE") && atoi(getenv("SEFD_LSTM_XFUSE")) == 0);
+    // ... and the layers above it (input = the layer below's h, H features): H/32 more k-steps per frame instead of an 8 GB slab + a GEMM
+    const bool x32 = xlen == 32 && xfeat == 32 && g.ldw == 64, xh = xlen == H && xfeat == H && g.ldw == H;
+    L.xfuse = L.rowsk && (x32 || xh) && g.Npad == 4 * H && !(getenv("SEFD_LSTM_XFUSE") && atoi(getenv("SEFD_LSTM_XFUSE")) == 0);
     if (L.xfuse) {
-      // the packed W_ih ([4H][64], K = 32 zero padded) re-ordered to MFMA B-fragment order in its first 4H x 32 slots
+      // the packed W_ih re-ordered to MFMA B-fragment order ([4H][64] with K = 32 zero padded: in its first 4H x 32 slots)
       int32_t* tab = nullptr;
       for (auto it = Fw.rbegin(); it != Fw.rend(); ++it)
         if (it->kind == OP_PACK && it->pack.dst.arena == g.w.arena && it->pack.dst.off == g.w.off) { tab = reinterpret_cast<int32_t*>(P->consts.data() + it->pack.tab.off); break; }
       if (!tab) { P->error = "FullSubNet: packed W_ih not found"; return b.none(); }
-      std::vector<int32_t> old(tab, tab + (size_t)4 * H * 64);
-      std::fill(tab, tab + (size_t)4 * H * 64, 0);
+      const int ldw = g.ldw, kf = x32 ? 32 : H;
+      std::vector<int32_t> old(tab, tab + (size_t)4 * H * ldw);
+      std::fill(tab, tab + (size_t)4 * H * ldw, 0);
       for (int c = 0; c < 4 * H; ++c)
-        for (int k = 0; k < 32; ++k) tab[rows_wf_index(32, c, k)] = old[(size_t)c * 64 + k];
+        for (int k = 0; k < kf; ++k) tab[rows_wf_index(kf, c, k)] = old[(size_t)c * ldw + k];
+      L.xf = kf;
     } else {
       b.push(Fw, OP_RUNGEMM, tag).g = g;
     }
@@ -2214,7 +2218,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         }
         r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none(); r.gxdt = L.sdt;
         r.xin = r.wpk_x = r.bias = b.none();
-        if (L.xfuse) { r.xin = x; r.wpk_x = g.w; r.bias = g.bias; r.xfeat = 32; }
+        if (L.xfuse) { r.xin = x; r.wpk_x = g.w; r.bias = g.bias; r.xfeat = L.xf; }
       }
       b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
     } else if (gru) {

@@ -173,7 +173,8 @@ struct LstmRec {
   // workgroup owns 48 sequences and ALL hidden units, h_t / dgates_t live in LDS, the packed bf16 weights are streamed from L2 every
   // frame: wpk_f = W_hh as [4H gate columns (unit-major)][H], wpk_b = its transpose [H][4H] (both written by PACK ops of the plan)
   Ptr wpk_f, wpk_b;
-  // impl 1, forward, xfeat == 32 (the sub-band model's first layer: 31 neighbour bins + the full-band output): the input projection is
+  // impl 1, forward, xfeat == 32 (the sub-band model's first layer: 31 neighbour bins + the full-band output) or xfeat == H (a layer above it,
+  // fed by the layer below's h - after dropout -, wpk_x then has H/32 k-steps: rows_wf_index(H, c, k)): the input projection is
   // fused - gate pre-activations = bias (b_ih + b_hh, fp32 [4H] unit-major) + x_t . W_ih^T (xin bf16 [T][rows][32], wpk_x packed like
   // wpk_f with ONE k-step: rows_wf_index(32, c, k)) + h_{t-1} . W_hh^T; `gx` is not read (no 8 GB pre-activation slab to write and re-read)
   Ptr xin, wpk_x, bias;

@@ -681,10 +681,10 @@ void run_op(const Op& op, const AB& ab) {
               double pre[4];
               for (int q = 0; q < 4; ++q) {
                 double s;
-                if (d.impl == 1 && d.xfeat == 32) {          // fused input projection: bias + x_t . W_ih^T from the fragment-ordered packed copy
-                  const int c = gate_col(q, j);
+                if (d.impl == 1 && d.xfeat > 0) {            // fused input projection: bias + x_t . W_ih^T from the fragment-ordered packed copy
+                  const int c = gate_col(q, j), xf = d.xfeat;
                   s = ((const float*)rp(ab, d.bias))[c];
-                  for (int k = 0; k < 32; ++k) s += (double)ld(rp(ab, d.xin), DT_BF16, rt * 32 + k) * ld(rp(ab, d.wpk_x), DT_BF16, rows_wf_index(32, c, k));
+                  for (int k = 0; k < xf; ++k) s += (double)ld(rp(ab, d.xin), DT_BF16, rt * xf + k) * ld(rp(ab, d.wpk_x), DT_BF16, rows_wf_index(xf, c, k));
                 } else {
                   s = ld(rp(ab, d.gx), sdt, gxo + gate_col(q, j));
                 }

@@ -54,7 +54,8 @@ def _typed(t_u8, dt):
                                                         ("FullSubNet", 1, 11, "E", (256, 256), 0, "bf16")])
 def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     """Tolerances: fp32 buffers 1e-3 (observed <= 3e-6); bf16 buffers 1.6e-2 = two bf16 ulps of the largest element
-    (simulator and kernel round slightly different fp32 accumulations of the SAME bf16 operands)."""
+    (simulator and kernel round slightly different fp32 accumulations of the SAME bf16 operands); fp32 state written by a whole
+    bf16 recurrence op (LSTM_FWD / LSTM_BWD): 4e-3 = one bf16 ulp of h fed back through the frames."""
     from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, sim_run
     if L == 2401:                          # the wide-tile kernel needs M >= 4096 by default: lower the bar so that this small case runs it
         L = 2400
@@ -146,6 +147,9 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
                         if not np.isfinite(err):
                             err = float("inf")
                         tol = 1.6e-2 if dt == 1 else 1e-3
+                        if dt != 1 and dtype == "bf16" and int(kinds[i]) in (9, 10):
+                            tol = 4e-3     # fp32 state of a bf16 recurrence (cell state, dh): h_t is rounded to bf16 every frame, and a
+                                           # rounding flip (one bf16 ulp = 4e-3 of h) between kernel and simulator feeds back into c
                         nchg += hv.numel()
                         if err / tol > worst:
                             worst, where = err / tol, f"{name} err {err:.2e} tol {tol:.0e}"
