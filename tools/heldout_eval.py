@@ -81,7 +81,7 @@ def train(args):
     res = {}
     init = None
     # third leg: fp32 again with another batch order - the run-to-run spread of the metric, against which the bf16 delta is read
-    for tag in ("fp32", "bf16", "fp32_rerun"):
+    for tag in ("fp32", "bf16", "fp32_rerun", "bf16_rerun"):
         dt = tag.split("_")[0]
         cfg.masking_mode, cfg.loss, cfg.act_dtype = "E", "SI-SNR", dt
         torch.manual_seed(0)
@@ -120,6 +120,7 @@ def score(args):
     from sefd_amd import tools_for_estimate as est
     ld = lambda n: np.load(os.path.join(args.dir, n)).astype(np.float64)
     clean, noisy, e32, e16, e32b = ld("clean.npy"), ld("noisy.npy"), ld("enhanced_fp32.npy"), ld("enhanced_bf16.npy"), ld("enhanced_fp32_rerun.npy")
+    e16b = ld("enhanced_bf16_rerun.npy") if os.path.exists(os.path.join(args.dir, "enhanced_bf16_rerun.npy")) else None
     pesq = None
     so = "/root/reference/PESQ.so"
     if os.path.exists(so):
@@ -132,7 +133,7 @@ def score(args):
     rows = []
     for i in range(len(clean)):
         r = dict(utt=i)
-        for name, sig in (("noisy", noisy), ("fp32", e32), ("bf16", e16), ("fp32_rerun", e32b)):
+        for name, sig in (("noisy", noisy), ("fp32", e32), ("bf16", e16), ("fp32_rerun", e32b)) + ((("bf16_rerun", e16b),) if e16b is not None else ()):
             r["stoi_" + name] = float(est.cal_stoi([sig[i] / 32768.0], [clean[i] / 32768.0])[0])
             if pesq:
                 r["pesq_" + name] = pesq(clean[i], sig[i])
@@ -143,10 +144,12 @@ def score(args):
                n_utts=len(rows), mean=mean,
                delta_bf16_minus_fp32={k: mean[k + "_bf16"] - mean[k + "_fp32"] for k in (("pesq", "stoi") if pesq else ("stoi",))},
                delta_fp32_rerun_minus_fp32={k: mean[k + "_fp32_rerun"] - mean[k + "_fp32"] for k in (("pesq", "stoi") if pesq else ("stoi",))},
+               delta_bf16_mean_minus_fp32_mean={k: (mean[k + "_bf16"] + mean.get(k + "_bf16_rerun", mean[k + "_bf16"])) / 2 - (mean[k + "_fp32"] + mean[k + "_fp32_rerun"]) / 2
+                                                for k in (("pesq", "stoi") if pesq else ("stoi",))},
                per_utt_abs_delta_max={k: float(max(abs(r[k + "_bf16"] - r[k + "_fp32"]) for r in rows)) for k in (("pesq", "stoi") if pesq else ("stoi",))},
                train=json.load(open(os.path.join(args.dir, "train_log.json"))), rows=rows)
     json.dump(out, open(args.json, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("mean", "delta_bf16_minus_fp32", "delta_fp32_rerun_minus_fp32", "per_utt_abs_delta_max")}, indent=1))
+    print(json.dumps({k: out[k] for k in ("mean", "delta_bf16_minus_fp32", "delta_fp32_rerun_minus_fp32", "delta_bf16_mean_minus_fp32_mean", "per_utt_abs_delta_max")}, indent=1))
 
 
 if __name__ == "__main__":
