@@ -95,6 +95,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
+// Inverted-dropout scale of element i (counter hash on (seed, layer, i); nn.LSTM(dropout=0.8) between FullSubNet's two layers,
+// tools_for_model.py:746): 1/keep with probability keep, else 0.  Shared by dropout_kernel (fsn.hip) and the LSTM kernels that fuse it.
+__device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x632BE5ABu) * 0xC2B2AE3Du;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_scale(uint32_t seed0, uint32_t seed1, int layer, float keep, int64_t i) {
+  if (keep >= 1.f) return 1.f;
+  const uint32_t r = mix32(seed0 + (uint32_t)layer * 0x51ED27u, seed1 ^ (uint32_t)(i >> 32), (uint32_t)i);
+  return ((r >> 8) * (1.f / 16777216.f)) < keep ? 1.f / keep : 0.f;
+}
+
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st);

@@ -121,16 +121,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const LstmCell d, const A
 }
 
 // ---------------------------------------------------------------------------------------------- dropout
-__device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x632BE5ABu) * 0xC2B2AE3Du;
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ float keep_scale(const Dropout& d, const uint32_t* seed, int64_t i) {
-  if (d.keep >= 1.f) return 1.f;
-  const uint32_t r = mix32(seed[0] + (uint32_t)d.layer * 0x51ED27u, seed[1] ^ (uint32_t)(i >> 32), (uint32_t)i);
-  return ((r >> 8) * (1.f / 16777216.f)) < d.keep ? 1.f / d.keep : 0.f;
-}
+__device__ __forceinline__ float keep_scale(const Dropout& d, const uint32_t* seed, int64_t i) { return drop_scale(seed[0], seed[1], d.layer, d.keep, i); }
 __global__ __launch_bounds__(256) void dropout_kernel(const Dropout d, const ArenaBases ab) {   // forward and backward are the same map
   const char* x = rp(ab, d.x);
   char* y = rp(ab, d.y);

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
   const uint16_t* xin = XK ? reinterpret_cast<const uint16_t*>(rp(ab, d.xin)) : nullptr;      // [T][rows][32] bf16
   const uint16_t* wx = XK ? reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_x)) : nullptr;
   const float* bias = XK ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
+  uint16_t* hd = d.hd.arena >= 0 ? reinterpret_cast<uint16_t*>(rp(ab, d.hd)) : nullptr;
+  const uint32_t seed0 = hd ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = hd ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
   for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                  // h_{-1} = 0
   uint16_t* xl = hl + 2 * RB * HS;
   auto fill_x = [&](int tt) {                      // x_tt of the workgroup's rows -> LDS (16-byte chunks)
@@ -207,8 +209,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
     // h_t leaves as 16-byte chunks: RB rows x H/8 chunks
     for (int i = tid; i < RB * (H / 8); i += NTHR) {
       const int row = i / (H / 8), ch = i - row * (H / 8);
-      if (row0 + row < rows)
-        *reinterpret_cast<uint4*>(hout + ((int64_t)t * rows + row0 + row) * H + 8 * ch) = *reinterpret_cast<const uint4*>(hn + row * HS + 8 * ch);
+      if (row0 + row < rows) {
+        const uint4 v = *reinterpret_cast<const uint4*>(hn + row * HS + 8 * ch);
+        const int64_t o = ((int64_t)t * rows + row0 + row) * H + 8 * ch;
+        *reinterpret_cast<uint4*>(hout + o) = v;
+        if (hd) {                                     // fused inter-layer dropout (same map as dropout_kernel)
+          const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+          uint32_t ov[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            ov[e] = pack_bf16x2(bf2f(wv[e] & 0xffff) * drop_scale(seed0, seed1, d.drop_layer, d.keep, o + 2 * e),
+                                bf2f(wv[e] >> 16) * drop_scale(seed0, seed1, d.drop_layer, d.keep, o + 2 * e + 1));
+          *reinterpret_cast<uint4*>(hd + o) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        }
+      }
     }
     if constexpr (XH) {                             // every wave is past the barrier: x_t is no longer read; x_{t+1} must be visible before the next frame
       if (t + 1 < T) fill_x(t + 1);

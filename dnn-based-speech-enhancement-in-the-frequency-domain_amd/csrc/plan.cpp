@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse; int sdt, xf; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false; int sdt, xf; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2219,6 +2219,12 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         r.impl = 1; r.wpk_f = pk.w; r.wpk_b = b.none(); r.gxdt = L.sdt;
         r.xin = r.wpk_x = r.bias = b.none();
         if (L.xfuse) { r.xin = x; r.wpk_x = g.w; r.bias = g.bias; r.xfeat = L.xf; }
+        r.hd = r.seed = b.none();
+        if (l == 0 && keep < 1.f && !(getenv("SEFD_LSTM_DROPFUSE") && atoi(getenv("SEFD_LSTM_DROPFUSE")) == 0)) {   // dropout applied while h_t is stored
+          L.hd_fused = b.ws(L.nm + ".hd", (int64_t)TP * rows * H, adt);
+          r.hd = L.hd_fused; r.seed = io_seed; r.keep = keep; r.drop_layer = lid;
+          L.dropfused = true;
+        }
       }
       b.push(Fw, OP_LSTM_FWD, tag).lstm = r;
     } else if (gru) {
@@ -2270,8 +2276,8 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     }
     L.hd = L.h;
     if (l == 0) {               // inter-layer dropout (nn.LSTM(dropout=0.8)): only after the first of the two layers
-      L.hd = keep < 1.f ? b.ws(L.nm + ".hd", (int64_t)TP * rows * H, adt) : L.h;
-      if (keep < 1.f) {
+      L.hd = L.dropfused ? L.hd_fused : keep < 1.f ? b.ws(L.nm + ".hd", (int64_t)TP * rows * H, adt) : L.h;
+      if (keep < 1.f && !L.dropfused) {
         Op& op = b.push(Fw, OP_DROPOUT_FWD, tag);
         op.drop.x = L.h; op.drop.y = L.hd; op.drop.seed = io_seed; op.drop.n = (int64_t)TP * rows * H; op.drop.keep = keep; op.drop.dt = adt; op.drop.layer = lid;
       }

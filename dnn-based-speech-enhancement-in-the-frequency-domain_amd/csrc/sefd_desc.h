@@ -179,6 +179,11 @@ struct LstmRec {
   // wpk_f with ONE k-step: rows_wf_index(32, c, k)) + h_{t-1} . W_hh^T; `gx` is not read (no 8 GB pre-activation slab to write and re-read)
   Ptr xin, wpk_x, bias;
   int32_t xfeat, pad3_;
+  // impl 1, forward, hd != A_NONE: the inverted dropout that follows the layer (struct Dropout: seed, keep, layer) is applied while h_t is
+  // stored - hd [T][rows][H] (dtype hdt) = h * scale, no separate pass over the 2 GB h array
+  Ptr hd, seed;
+  float keep;
+  int32_t drop_layer;
   int32_t gxdt, pad2_;          // impl 1 only: dtype of the gx / gates slabs (DT_BF16 halves the HBM traffic that bounds these layers; the cell
                                // update itself uses the unrounded fp32 gate values, the backward reads the stored ones)
 };

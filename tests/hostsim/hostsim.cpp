@@ -703,6 +703,16 @@ void run_op(const Op& op, const AB& ab) {
             for (int j = 0; j < H; ++j) {
               st(rp(ab, d.h), d.hdt, row * H + j, (float)hn[j]);
               h[j] = d.hdt == DT_BF16 ? bf2f(f2bf((float)hn[j])) : hn[j];
+              if (d.impl == 1 && d.hd.arena >= 0) {           // fused inter-layer dropout: the same map as OP_DROPOUT_FWD on the stored h
+                const uint32_t* seed = (const uint32_t*)rp(ab, d.seed);
+                const int64_t i = row * H + j;
+                float sc = 1.f;
+                if (d.keep < 1.f) {
+                  const uint32_t r = mix32(seed[0] + (uint32_t)d.drop_layer * 0x51ED27u, seed[1] ^ (uint32_t)(i >> 32), (uint32_t)i);
+                  sc = ((r >> 8) * (1.f / 16777216.f)) < d.keep ? 1.f / d.keep : 0.f;
+                }
+                st(rp(ab, d.hd), d.hdt, i, ld(rp(ab, d.h), d.hdt, i) * sc);
+              }
             }
           }
         }
