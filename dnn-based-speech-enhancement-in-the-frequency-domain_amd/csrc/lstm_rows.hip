@@ -251,6 +251,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
   const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
   uint16_t* dgo = reinterpret_cast<uint16_t*>(rp(ab, d.dgates));
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_b));   // [H][4H] bf16: row = unit u', column = gate column (unit-major)
+  const bool dmask = d.seed.arena >= 0;            // dh arrives as the gradient of the dropped h (fused inter-layer dropout backward)
+  const uint32_t seed0 = dmask ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = dmask ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
   const int kq = lane >> 4, ln = lane & 15;
   const int64_t gx_ld = d.gx_ld;
   // unit of (tile nt, this lane): half nt / NTH, inside the half the wave's NTH consecutive tiles
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
             gv[n2][r] = ld_gate4<G16>(gates, rt * gx_ld + 4 * unit);
             ctv[n2][r] = cs[rt * H + unit];
             cpv[n2][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
-            dhv[n2][r] = dh[rt * H + unit];
+            dhv[n2][r] = dh[rt * H + unit] * (dmask ? drop_scale(seed0, seed1, d.drop_layer, d.keep, rt * H + unit) : 1.f);
           }
 #pragma unroll
         for (int n2 = 0; n2 < NTH; ++n2) {

@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false; int sdt, xf; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false, dropbwd = false; int sdt, xf; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2370,6 +2370,8 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
               for (int k = 0; k < 4 * H; ++k) tab[rows_wb_index(H, n, k)] = old[(size_t)n * 4 * H + k];
           }
           r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none(); r.gxdt = L.sdt;
+          r.xin = r.wpk_x = r.bias = r.hd = r.seed = b.none();
+          if (L.dropbwd) { r.seed = io_seed; r.keep = keep; r.drop_layer = L.lid; }
         }
         b.push(R, OP_LSTM_BWD, tag).lstm = r;
       } else {
@@ -2428,6 +2430,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     };
     auto dropout_bwd = [&](LayerRt& L, Ptr dxd, int tag) -> Ptr {      // gradient wrt the un-dropped h (fp32, in place semantics via a copy)
       if (!(keep < 1.f)) return dxd;
+      if (L.dropfused) { L.dropbwd = true; return dxd; }               // the row-block backward kernel multiplies dh by the mask as it loads it
       Ptr dhu = b.ws(L.nm + ".dhu", (int64_t)TP * L.rows * L.H, DT_F32);
       Op& op = b.push(R, OP_DROPOUT_BWD, tag);
       op.drop.x = dxd; op.drop.y = dhu; op.drop.seed = io_seed; op.drop.n = (int64_t)TP * L.rows * L.H; op.drop.keep = keep; op.drop.dt = DT_F32; op.drop.layer = L.lid;

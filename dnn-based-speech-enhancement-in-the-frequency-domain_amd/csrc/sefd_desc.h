@@ -181,6 +181,7 @@ struct LstmRec {
   int32_t xfeat, pad3_;
   // impl 1, forward, hd != A_NONE: the inverted dropout that follows the layer (struct Dropout: seed, keep, layer) is applied while h_t is
   // stored - hd [T][rows][H] (dtype hdt) = h * scale, no separate pass over the 2 GB h array
+  // backward, seed != A_NONE: `dh` is the gradient w.r.t. the DROPPED h: it is multiplied by the same mask as it is loaded
   Ptr hd, seed;
   float keep;
   int32_t drop_layer;

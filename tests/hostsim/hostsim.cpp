@@ -738,7 +738,14 @@ void run_op(const Op& op, const AB& ab) {
               const int64_t gq = (row * H + j) * 4;
               const double ig = ld(rp(ab, d.gates), sdt, gq), fg = ld(rp(ab, d.gates), sdt, gq + 1), gg = ld(rp(ab, d.gates), sdt, gq + 2), og = ld(rp(ab, d.gates), sdt, gq + 3);
               const double ct = cs[row * H + j], cp = t > 0 ? cs[rowp * H + j] : 0.0;
-              const double dht = dh[row * H + j] + dhrec[j];
+              double dup = dh[row * H + j];
+              if (d.impl == 1 && d.seed.arena >= 0 && d.keep < 1.f) {   // fused inter-layer dropout backward: dh is the gradient of the dropped h
+                const uint32_t* seed = (const uint32_t*)rp(ab, d.seed);
+                const int64_t i = row * H + j;
+                const uint32_t r = mix32(seed[0] + (uint32_t)d.drop_layer * 0x51ED27u, seed[1] ^ (uint32_t)(i >> 32), (uint32_t)i);
+                dup = (float)dup * (((r >> 8) * (1.f / 16777216.f)) < d.keep ? 1.f / d.keep : 0.f);
+              }
+              const double dht = dup + dhrec[j];
               const double tc = std::tanh(ct);
               const double dcv = dht * og * (1 - tc * tc) + dc[j];
               dg[j] = dcv * gg * ig * (1 - ig);
