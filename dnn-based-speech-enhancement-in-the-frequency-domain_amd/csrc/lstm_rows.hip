@@ -13,6 +13,7 @@
 // Same descriptor, buffers, gate-column order (unit-major) and arithmetic contract as the other LSTM kernels (LstmRec, impl == 1).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -236,7 +237,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
 // its share of the GEMM, barrier), so that 80 rows would fit (16 MT x 4H of bf16 is 245 KB at MT = 5) and the launch would need one
 // dispatch round instead of two.  Tried (80 rows: 4 waves x 2 parts, 8 waves x 3 parts): both spill ~350 registers - the old and the new
 // recurrent gradient and the cell-state carry are all live across the parts - so only HV = 1 with 48 rows is launched.
-template <int H, int MT, int NW, bool G16, int HV>
+// UP: where the upstream gradient of h_t comes from: 0 the dh array, 1 dh x the inter-layer dropout mask, 2 the 2-output head (rank-2 update).
+// A template parameter, not a run-time flag: with a branch per cell the compiler stops batching the loads of a row tile (9.8 -> 13.3 ms).
+template <int H, int MT, int NW, bool G16, int HV, int UP>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
   constexpr int KS = 4 * H / 32, NT = H / 16 / NW, RB = 16 * MT, AS = 4 * H / HV + 8, KC = H >= 512 ? 4 : (HV > 1 ? 4 : 8);
   constexpr int NTH = NT / HV, KSH = KS / HV;       // unit tiles per wave and k-steps per half
@@ -248,11 +251,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
   const int64_t row0 = (int64_t)blockIdx.x * RB;
   const char* gates = rp(ab, d.gates);
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
-  const float* dh = reinterpret_cast<const float*>(rp(ab, d.dh));
+  const float* dh = UP == 2 ? nullptr : reinterpret_cast<const float*>(rp(ab, d.dh));
   uint16_t* dgo = reinterpret_cast<uint16_t*>(rp(ab, d.dgates));
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_b));   // [H][4H] bf16: row = unit u', column = gate column (unit-major)
-  const bool dmask = d.seed.arena >= 0;            // dh arrives as the gradient of the dropped h (fused inter-layer dropout backward)
-  const uint32_t seed0 = dmask ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = dmask ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
+  const uint16_t* dyo = UP == 2 ? reinterpret_cast<const uint16_t*>(rp(ab, d.dyo)) : nullptr;
+  const float* wo = UP == 2 ? reinterpret_cast<const float*>(rp(ab, d.wo)) : nullptr;
+  const uint32_t seed0 = UP == 1 ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = UP == 1 ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
   const int kq = lane >> 4, ln = lane & 15;
   const int64_t gx_ld = d.gx_ld;
   // unit of (tile nt, this lane): half nt / NTH, inside the half the wave's NTH consecutive tiles
@@ -284,7 +288,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
             gv[n2][r] = ld_gate4<G16>(gates, rt * gx_ld + 4 * unit);
             ctv[n2][r] = cs[rt * H + unit];
             cpv[n2][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
-            dhv[n2][r] = dh[rt * H + unit] * (dmask ? drop_scale(seed0, seed1, d.drop_layer, d.keep, rt * H + unit) : 1.f);
+            if constexpr (UP == 2) {                      // rank-2 upstream gradient from the 2-output head (bf16 pair per row)
+              const uint32_t pr = reinterpret_cast<const uint32_t*>(dyo)[rt];
+              dhv[n2][r] = bf2f(pr & 0xffff) * wo[unit] + bf2f(pr >> 16) * wo[H + unit];
+            } else if constexpr (UP == 1) {
+              dhv[n2][r] = dh[rt * H + unit] * drop_scale(seed0, seed1, d.drop_layer, d.keep, rt * H + unit);
+            } else {
+              dhv[n2][r] = dh[rt * H + unit];
+            }
           }
 #pragma unroll
         for (int n2 = 0; n2 < NTH; ++n2) {
@@ -373,9 +384,16 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
     }
   } else {
     const size_t sh = (size_t)16 * MT * (4 * H / HV + 8) * 2;
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16, HV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-    (void)once;
-    hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16, HV>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    const int up = d.no == 2 ? 2 : (d.seed.arena >= 0 && d.keep < 1.f) ? 1 : 0;
+    auto go = [&](auto upc) {
+      constexpr int UPC = decltype(upc)::value;
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16, HV, UPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+      (void)once;
+      hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16, HV, UPC>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+    };
+    if (up == 2) go(std::integral_constant<int, 2>{});
+    else if (up == 1) go(std::integral_constant<int, 1>{});
+    else go(std::integral_constant<int, 0>{});
   }
 }
 template <int H, int MT>

@@ -2147,7 +2147,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false, dropbwd = false; int sdt, xf; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false, dropbwd = false, headfuse = false; Ptr dyo, wo; int sdt, xf; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2372,6 +2372,8 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
           r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none(); r.gxdt = L.sdt;
           r.xin = r.wpk_x = r.bias = r.hd = r.seed = b.none();
           if (L.dropbwd) { r.seed = io_seed; r.keep = keep; r.drop_layer = L.lid; }
+          r.dyo = r.wo = b.none();
+          if (L.headfuse) { r.dyo = L.dyo; r.wo = L.wo; r.no = 2; }
         }
         b.push(R, OP_LSTM_BWD, tag).lstm = r;
       } else {
@@ -2417,10 +2419,11 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         b.push(R, OP_RUNGEMM, tag).g = g;
       }
     };
-    auto fc_backward = [&](FcRt& fc, Ptr dy, Ptr x, int64_t rows, int H, int O, int ld, Ptr dh, int tag, const std::string& nm) {
+    auto fc_backward = [&](FcRt& fc, Ptr dy, Ptr x, int64_t rows, int H, int O, int ld, Ptr dh, int tag, const std::string& nm, bool head_fused = false) {
       RunGemm fw = fc.g;
       fw.ydt = adt; fw.flags = 0;
       b.wgrad(R, fw, dy, fc.coef, tag, &fc.bias);
+      if (head_fused) return;                             // the row-block LSTM backward forms dh = dy . W_fc itself (O = 2: a rank-2 update)
       RunGemm g = seq_gemm(dy, adt, rows, ld, 0, O, H, DT_F32);
       const Builder::Coef cf = fc.coef;
       Builder::Coef coef = [=](int nn, int s, int j) -> int32_t { return cf(j, 0, nn); };
@@ -2441,7 +2444,11 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     Ptr d_sbo = b.ws("d_sbo", (int64_t)TP * rs * 2, adt);
     { Fsn f = fsn0(); f.in = io_gcrm; f.out = d_sbo; b.push(R, OP_FSN_OUT_BWD, 205).fsn = f; }
     Ptr dh3 = b.ws("dh3", (int64_t)TP * rs * Hs, DT_F32);
-    fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model");
+    // sub-band head: 2 outputs.  With the row-block kernels the [T x rows x H] fp32 gradient of h (4 GB written by a K = 2 GEMM, read back
+    // by the recurrence) is never materialised: the kernel computes dh = d_sbo[.., 0] W_fc[0] + d_sbo[.., 1] W_fc[1] as it needs it
+    Ls1.headfuse = Ls1.rowsk && !(getenv("SEFD_LSTM_HEADFUSE") && atoi(getenv("SEFD_LSTM_HEADFUSE")) == 0);
+    if (Ls1.headfuse) { Ls1.dyo = d_sbo; Ls1.wo = b.pptr("sb_model.fc_output_layer.weight"); }
+    fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model", Ls1.headfuse);
     Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, DT_F32);
     lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, DT_F32, 203);
     Ptr dh2 = dropout_bwd(Ls0, dh2d, 202);

@@ -185,6 +185,10 @@ struct LstmRec {
   Ptr hd, seed;
   float keep;
   int32_t drop_layer;
+  // impl 1, backward, no == 2: the upstream gradient is not read from `dh` but formed from the 2-output head that follows the layer:
+  // dh[t][row][u] = dyo[t][row][0] * wo[0][u] + dyo[t][row][1] * wo[1][u]   (dyo dtype gdt [T][rows][2], wo fp32 [2][H] in A_PARAM)
+  Ptr dyo, wo;
+  int32_t no, pad4_;
   int32_t gxdt, pad2_;          // impl 1 only: dtype of the gx / gates slabs (DT_BF16 halves the HBM traffic that bounds these layers; the cell
                                // update itself uses the unrounded fp32 gate values, the backward reads the stored ones)
 };

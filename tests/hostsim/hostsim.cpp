@@ -738,7 +738,13 @@ void run_op(const Op& op, const AB& ab) {
               const int64_t gq = (row * H + j) * 4;
               const double ig = ld(rp(ab, d.gates), sdt, gq), fg = ld(rp(ab, d.gates), sdt, gq + 1), gg = ld(rp(ab, d.gates), sdt, gq + 2), og = ld(rp(ab, d.gates), sdt, gq + 3);
               const double ct = cs[row * H + j], cp = t > 0 ? cs[rowp * H + j] : 0.0;
-              double dup = dh[row * H + j];
+              double dup;
+              if (d.impl == 1 && d.no == 2) {                 // rank-2 upstream gradient from the 2-output head
+                const float* wo = (const float*)rp(ab, d.wo);
+                dup = (float)(ld(rp(ab, d.dyo), d.gdt, row * 2) * wo[j] + ld(rp(ab, d.dyo), d.gdt, row * 2 + 1) * wo[H + j]);
+              } else {
+                dup = dh[row * H + j];
+              }
               if (d.impl == 1 && d.seed.arena >= 0 && d.keep < 1.f) {   // fused inter-layer dropout backward: dh is the gradient of the dropped h
                 const uint32_t* seed = (const uint32_t*)rp(ab, d.seed);
                 const int64_t i = row * H + j;
