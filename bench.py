@@ -173,12 +173,18 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") is the product path.  SEFD_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices):
+        # used only to exercise the bucketed exchange / callback path on a single-GPU box, never for a reported number.
+        backend = os.environ.get("SEFD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models
     from sefd_amd.ddp import GradientExchange
@@ -239,7 +245,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "bn": "per-rank statistics",
-                          "collective": (f"RCCL world {dist.get_world_size()}, flat fp32 gradient all-reduce in 2 buckets (decoder+LSTM under the encoder backward)"
+                          "collective": (f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (single-GPU smoke test, not a measurement)'} world {dist.get_world_size()}, flat fp32 gradient all-reduce in 2 buckets (decoder+LSTM under the encoder backward)"
                                          if world > 1 else "none"),
                           "per_rank_ms": per_rank_ms},
                "final_loss": round(lossv, 5)}
