@@ -1,0 +1,26 @@
+"""GPU: the data-parallel bench path (two gradient buckets, all-reduce of the first one started from the plan's callback under the
+encoder backward, Adam on the averaged gradient) with TWO ranks sharing the one GPU of the box.  RCCL refuses duplicate devices, so the
+ranks talk through gloo (SEFD_DIST_BACKEND): this checks the control flow on real kernels, not the collective's speed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bucketed_exchange_runs_on_one_gpu():
+    env = dict(os.environ, SEFD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and len(d["config"]["per_rank_ms"]) == 2
+    assert d["final_loss"] == d["final_loss"] and abs(d["final_loss"]) < 100      # finite
+    assert "2 buckets" in d["config"]["collective"]
