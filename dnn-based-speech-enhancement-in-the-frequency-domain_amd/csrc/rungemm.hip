@@ -750,7 +750,9 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const uint16_t* tile, int col0, in
 
 // TK x NTHR: 128 x 256 threads (tiles up to 128 x 128) or 256 x 512 threads (the 256 x 256 tile of the wide layers: half the operand
 // bytes through L2 -> LDS per MFMA, which is what bounds the 128 x 128 tile - 64 B/clk/CU at the MFMA rate, the DMA stream's ceiling)
-template <int TN, int S, int TK = kWgTK, int NTHR = 256>
+// DUAL (needs S == 4): two 32-row steps per barrier - stages i, i+1 are multiplied while i+2, i+3 fly; the barrier, the vmcnt wait and
+// the DMA issue burst are paid once per 64 rows (the row splits, i.e. the partial sums, stay those of the 32-row steps)
+template <int TN, int S, int TK = kWgTK, int NTHR = 256, bool DUAL = false>
 __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int RS = kWgRows, NW = NTHR / 64;
   // wave grid: 2 (n) x 2 (k) for the 128 / 64 / 32 wide n tiles, 1 x 4 for the 16 wide one (thin layers: N <= 16, e.g. the mask
@@ -923,6 +925,30 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
   // S-stage ring: DMA runs S-1 row steps ahead of the MFMAs; per step one vmcnt wait for the oldest stage + one LDS barrier
   const int nst = step1 - step0;
   int issued = 0, istage = 0;
+  if constexpr (DUAL) {
+    static_assert(S == 4, "two steps per barrier: ring of 4");
+    auto mul = [&](int slot) {
+      bf16x8 af[NT], bfr[KB];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) af[a] = tr_frag_swz<TN>(&dys[slot][0], wn + a * 16, lane);
+#pragma unroll
+      for (int b = 0; b < KB; ++b) bfr[b] = tr_frag_swz<TK>(&as[slot][0], wk + b * 16, lane);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    };
+    for (int i = 0; i < 2; ++i)
+      if (issued < nst) { dma(istage); istage = (istage + 1) & 3; ++issued; }
+    for (int i = 0; i < nst; i += 2) {
+      wait_vm<0>();                                  // stages i, i + 1 (everything issued so far) have landed
+      lds_barrier();                                 // ... for every wave; the slots of stages i - 2, i - 1 are free again
+      for (int u = 0; u < 2; ++u)
+        if (issued < nst) { dma(istage); istage = (istage + 1) & 3; ++issued; }
+      mul(i & 3);
+      if (i + 1 < nst) mul((i + 1) & 3);
+    }
+  } else {
   for (int i = 0; i < S - 1; ++i)
     if (issued < nst) { dma(istage); istage = istage + 1 == S ? 0 : istage + 1; ++issued; }
   int cstage = 0;
@@ -940,6 +966,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
 #pragma unroll
       for (int b = 0; b < KB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     cstage = cstage + 1 == S ? 0 : cstage + 1;
+  }
   }
 #pragma unroll
   for (int a = 0; a < NT; ++a)
@@ -999,7 +1026,9 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 // 256 x 256 tile, 8 waves, 4-stage ring of 32 KB = 128 KB: one workgroup per CU (wgrad_tn == 256)
 static void launch_wgrad_wide(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int stages = env_stages("SEFD_WG256_STAGES", 2);   // 2, 3 and 4 stages measure the same (+-1 %): 2 x 32 KB leaves LDS to the other stream's kernels
+  static const bool dual = !(getenv("SEFD_WG_DUAL") && atoi(getenv("SEFD_WG_DUAL")) == 0);
   dim3 grid(((d.Npad + 255) / 256) * ((d.ldw + 255) / 256) * d.nsplit);
+  if (dual) { hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 4, 256, 512, true>), grid, dim3(512), 0, st, d, ab); return; }
   if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 2, 256, 512>), grid, dim3(512), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 3, 256, 512>), grid, dim3(512), 0, st, d, ab);
   else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 4, 256, 512>), grid, dim3(512), 0, st, d, ab);
@@ -1008,6 +1037,8 @@ static void launch_wgrad_wide(const RunGemm& d, const ArenaBases& ab, hipStream_
 // 128 x 512 tile for the N = 128 layers (kRunWgWide with Npad == 128): same bytes per MFMA as 256 x 256 would need at N = 256
 static void launch_wgrad_wide128(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + 511) / 512) * d.nsplit);
+  static const bool dual = getenv("SEFD_WG_DUAL") && atoi(getenv("SEFD_WG_DUAL")) == 2;   // measured no gain at N = 128 (783 vs 774 TFLOP/s) for 160 KB of LDS: opt-in
+  if (dual) { hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 4, 512, 512, true>), grid, dim3(512), 0, st, d, ab); return; }
   hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 2, 512, 512>), grid, dim3(512), 0, st, d, ab);
 }
 
