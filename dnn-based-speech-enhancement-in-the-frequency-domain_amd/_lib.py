@@ -60,6 +60,10 @@ def lib():
         "sefd_lms_backward": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32), i32, i32, vp, vp, vp, vp]),
         "sefd_fsn_targets": (i32, [vp, vp, i64, vp, vp, vp, vp]),
         "sefd_mix_snr": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+        "sefd_pmsqe_table_floats": (i64, []),
+        "sefd_pmsqe_ws_floats": (i64, [i32, i32]),
+        "sefd_pmsqe_forward": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "sefd_pmsqe_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
         "sefd_adam_step": (i32, [vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     }
     for name, (res, args) in sig.items():
@@ -76,5 +80,5 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
             "sefd_plan_grad_bucket", "sefd_plan_run_cb",
-            "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr",
+            "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
             "sefd_adam_step"]

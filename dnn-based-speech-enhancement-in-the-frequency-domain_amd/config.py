@@ -3,7 +3,7 @@ module IS the flag system its callers read (`import config as cfg`).
 
 Like there, it is a module of plain constants; constructor defaults of the models are bound at import time and
 `cfg.loss` / `cfg.perceptual` / `cfg.lstm` / `cfg.skip_type` / `cfg.dccrn_kernel_num` are read at construction / call time.
-Differences: no banner print; one build-side knob (`act_dtype`); data-file paths for the loader (placeholders in the
+Differences: no banner print; build-side knobs (`act_dtype`, `pmsqe_power`); data-file paths for the loader (placeholders in the
 reference's dataloader.py).  Under DDP BatchNorm statistics are per rank unless `GradientExchange(sync_bn=True)`.
 """
 # paths (config.py:11-16)
@@ -67,6 +67,7 @@ num_groups_in_drop_band = 2
 
 # ---- build-side knobs (not in the reference)
 act_dtype = 'fp32'          # 'fp32' (parity mode) or 'bf16' (storage + MFMA operand dtype, fp32 accumulate)
+pmsqe_power = False         # PMSQE: False = the loss sees magnitudes (what the reference call chain feeds asteroid's loss), True = power spectra
 train_data_path = None      # [N, 2, L] .npy files of (noisy, clean) pairs; dataloader.py:63-71 has placeholder paths
 valid_data_path = None
 test_data_path = None

@@ -376,7 +376,9 @@ class DCCRN(_SefdModule):
             if cfg.perceptual == 'LMS':
                 clean_real, clean_imag = self._stft_ref(target)          # self.stft(target), models.py:306-308
                 return tfl.lms_from_spectra(clean_real, clean_imag, real_spec, img_spec)
-            raise NotImplementedError("PMSQE is third-party (asteroid) arithmetic: parity unpinned, not built")
+            if cfg.perceptual == 'PMSQE':
+                return tfl.get_array_pmsqe_loss(target, estimated)       # models.py:313-314 (third-party arithmetic: parity unpinned)
+            raise ValueError(f"unknown cfg.perceptual {cfg.perceptual!r}")
         return self._main_loss(estimated, target)
 
     def _stft_ref(self, wav):

@@ -182,3 +182,88 @@ def get_array_lms_loss(clean_array, est_array):
 def lms_from_spectra(clean_real, clean_imag, est_real, est_imag):
     """models.py:306-312 fused: mags = sqrt(re^2 + im^2 + 1e-7) on both sides, then get_array_lms_loss."""
     return _LMS.apply(clean_real, clean_imag, est_real, est_imag)
+
+
+# ------------------------------------------------------------------------------------------ PMSQE (tools_for_loss.py:253-269)
+# The arithmetic is third-party in the reference (asteroid SingleSrcPMSQE under PITLossWrapper('pw_pt') over asteroid_filterbanks'
+# STFTFB(512, 512, stride 256) magnitudes) and absent from its tree: parity unpinned; csrc/pmsqe.hip follows the published algorithm.
+_PMSQE_CACHE = {}
+
+
+def _pmsqe_tables(device):
+    """(float table, int table) of csrc/pmsqe.hip on `device`: P.862.2 wide-band constants (pmsqe_tables.py), the speech-band mask of
+    the SLL mean, and the sqrt-Hann DFT tables of the 512 / 256 analysis (filters scaled by 1 / (0.5 sqrt(512 * 512 / 256)) = 1 / 16)."""
+    key = str(device)
+    if key not in _PMSQE_CACHE:
+        from . import pmsqe_tables as pt
+        nfft, hop, nbins, nb = 512, 256, 257, 49
+        thr = np.array(pt.ABS_THRESH_POWER)
+        cb = np.array(pt.CENTRE_OF_BAND_BARK)
+        zp = 0.23 * np.minimum(2.0, np.where(cb >= 4, 1.0, 6.0 / (cb + 2.0))) ** 0.15          # P.862 modified Zwicker power
+        aterm = pt.SL_16K * (thr / 0.5) ** zp
+        mask = np.zeros(nbins)
+        mask[11], mask[12:104], mask[104] = 0.5 * 25.0 / 31.25, 1.0, 0.5                          # 350 .. 3250 Hz
+        mask *= 2.0 * (nfft + 2.0) / nfft ** 2                                                    # sqrt-Hann power correction 2.0
+        n = np.arange(nfft)
+        win = np.hanning(nfft + 1)[:-1] ** 0.5
+        ang = 2 * np.pi * np.outer(n, np.arange(nbins)) / nfft
+        scale = 0.5 * math.sqrt(nfft * nfft / hop)
+        Cm, Sm = np.cos(ang) * win[:, None] / scale, -np.sin(ang) * win[:, None] / scale          # [512][257]
+        tab = np.zeros(int(_lib.lib().sefd_pmsqe_table_floats()), np.float32)
+        for off, v in ((0, thr), (49, zp), (98, pt.WIDTH_OF_BAND_BARK), (147, pt.POW_DENS_CORRECTION), (196, aterm), (245, mask)):
+            tab[off:off + len(v)] = v
+        o = 512
+        for m in (Cm, Sm, Cm.T, Sm.T):
+            tab[o:o + m.size] = np.ascontiguousarray(m).ravel()
+            o += m.size
+        itab = np.full(64 + nbins, -1, np.int32)
+        lo = np.concatenate([[0], np.cumsum(pt.HZ_BINS_PER_BAND)])
+        itab[:nb + 1] = lo
+        itab[50:64] = 0
+        for k in range(nb):
+            itab[64 + lo[k]:64 + lo[k + 1]] = k
+        _PMSQE_CACHE[key] = (torch.from_numpy(tab).to(device), torch.from_numpy(itab).to(device))
+    return _PMSQE_CACHE[key]
+
+
+class _PMSQE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clean, est, power):
+        if not est.is_cuda:
+            raise RuntimeError("sefd PMSQE loss runs on the MI355X only (cuda tensors); there is no CPU fallback")
+        L_ = _lib.lib()
+        clean, est = clean.detach().float().contiguous(), est.detach().float().contiguous()
+        if est.dim() != 2 or clean.shape != est.shape:
+            raise ValueError("get_array_pmsqe_loss takes two [N, L] wave batches")
+        B, L = est.shape
+        n = L_.sefd_pmsqe_ws_floats(B, L)
+        if n < 0:
+            raise ValueError(f"PMSQE needs whole seconds of {cfg.fs} samples (the reference's view(N, -1, fs)), at most 6: got L = {L}")
+        tab, itab = _pmsqe_tables(est.device)
+        ws = torch.empty(n, dtype=torch.float32, device=est.device)
+        out = torch.empty((), dtype=torch.float32, device=est.device)
+        rc = L_.sefd_pmsqe_forward(_vp(est), _vp(clean), B, L, int(power), _vp(tab), _vp(itab), _vp(ws), _vp(out),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sefd_pmsqe_forward failed ({rc})")
+        ctx.t = (B, L, int(power), tab, itab, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, power, tab, itab, ws = ctx.t
+        ge = torch.empty(B, L, dtype=torch.float32, device=ws.device)
+        gs = g.float().contiguous().view(1)
+        rc = _lib.lib().sefd_pmsqe_backward(B, L, power, _vp(tab), _vp(itab), _vp(ws), _vp(gs), _vp(ge),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"sefd_pmsqe_backward failed ({rc})")
+        return None, ge, None
+
+
+def get_array_pmsqe_loss(clean_array, est_array):
+    """tools_for_loss.py:258-269: [N, L] (or [N, 1, L]) waves, L whole seconds -> scalar.  `cfg.pmsqe_power` (build-side knob, default
+    False) feeds the loss the power spectrum instead of the magnitude the reference call chain feeds it."""
+    if clean_array.dim() == 3:
+        clean_array, est_array = clean_array.flatten(1), est_array.flatten(1)
+    return _PMSQE.apply(clean_array, est_array, bool(getattr(cfg, "pmsqe_power", False)))

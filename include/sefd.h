@@ -113,6 +113,23 @@ int32_t sefd_lms_backward(const float* clean_r, const float* clean_i, const floa
                           const int32_t* bands, const float* weights, int32_t nbands, const int32_t* scale_sizes_host, int32_t nscales,
                           int32_t nfft, const float* grad_scale, float* grad_est_r, float* grad_est_i, void* stream);
 
+/* ---- PMSQE perceptual loss (call chain tools_for_loss.py:253-269 `get_array_pmsqe_loss`, models.py:313-314) ----------------------
+ * The arithmetic is third-party (asteroid SingleSrcPMSQE + PITLossWrapper('pw_pt') + asteroid_filterbanks STFTFB / Encoder / mag), absent
+ * from the reference tree and unversioned there: PARITY UNPINNED; this is the published algorithm as oracle/pmsqe.py restates it.
+ * est / clean: fp32 [B][L] device waves, L a whole number of seconds (the reference's view(N, -1, fs)), at most 6 seconds (PIT over
+ * the seconds enumerates the permutations).  power: 0 = the loss sees the magnitude spectrum sqrt(re^2 + im^2 + 1e-8) (transforms.mag,
+ * what the reference call chain feeds it), 1 = the power spectrum (the paper's definition).
+ * tab: fp32 [sefd_pmsqe_table_floats()] device = thr[49] zp[49] width[49] corr[49] aterm[49] mask[257] (at 245), then at 512 the
+ * windowed DFT tables cos [512][257], -sin [512][257] and their transposes [257][512] x 2;  itab: int32 [64 + 257] device = prefix sums
+ * of the FFT bins per Bark band [50] and, at 64, the band of every bin (-1: none).  ws: fp32 [sefd_pmsqe_ws_floats(B, L)] device, must
+ * stay untouched between forward and backward.  backward writes d loss / d est * *grad_scale into grad_est [B][L]. */
+int64_t sefd_pmsqe_table_floats(void);
+int64_t sefd_pmsqe_ws_floats(int32_t B, int32_t L);
+int32_t sefd_pmsqe_forward(const float* est, const float* clean, int32_t B, int32_t L, int32_t power, const float* tab, const int32_t* itab,
+                           float* ws, float* loss_out, void* stream);
+int32_t sefd_pmsqe_backward(int32_t B, int32_t L, int32_t power, const float* tab, const int32_t* itab, float* ws, const float* grad_scale,
+                            float* grad_est, void* stream);
+
 /* ---- FullSubNet training targets (trainer.py:100-104; tools_for_model.py:683-717) -------------------------------------
  * noisy_c64 / clean_c64: interleaved complex64 [n] (the torch.stft outputs).  Any of mag / phase / cirm may be NULL.
  * mag = |noisy| (mag_phase), phase = angle(noisy), cirm [n][2] = compress_cIRM(build_complex_ideal_ratio_mask(noisy, clean)). */
