@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--model", default="dccrn", choices=["dccrn", "dccrn_large", "fullsubnet"])
     ap.add_argument("--dtype", default=os.environ.get("SEFD_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"])
+    ap.add_argument("--perceptual", default=None, choices=["LMS", "PMSQE"], help="DCCRN: loss = (SI-SNR + perceptual) / 2 (BASELINE configs[3] per-GPU shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -193,7 +194,7 @@ def main():
     large = args.model == "dccrn_large"
     kn, ru = ((64, 128, 256, 512, 512, 512), 512) if large else ((32, 64, 128, 256, 256, 256), 256)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "dccrn":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "dccrn" and not args.perceptual:
         cpu = cpu_baseline(L, kn, ru)                    # first: the GPU legs then run back to back until the process ends
     torch.manual_seed(0)
     if args.model == "fullsubnet":
@@ -209,6 +210,9 @@ def main():
         workload = (f"DCCRN{'-large (2x channels, rnn_units 512; BASELINE configs[4] per-GPU shard)' if large else ''} mask C, SI-SNR, fwd+bwd+Adam, "
                     f"B={B}/GPU x {args.seconds:g}s@16kHz clips" + ("" if large else " (BASELINE configs[1])"))
         metric = "train utts/sec (3s@16kHz) DCCRN" + ("-large" if large else "")
+        if args.perceptual:
+            workload = workload.replace("SI-SNR,", f"(SI-SNR + {args.perceptual}) / 2,").replace(" (BASELINE configs[1])", " (BASELINE configs[3] per-GPU shard)")
+            metric += " + " + args.perceptual
     opt = Adam(model.parameters(), lr=1e-3)
     ex = GradientExchange() if world > 1 else None
     x, y = make_batch(B, L, rank, dev)
@@ -219,12 +223,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    kw = {"perceptual": args.perceptual} if args.perceptual else {}
+    if args.perceptual and args.model == "fullsubnet":
+        raise SystemExit("--perceptual applies to the DCCRN models")
     for _ in range(args.warmup):
-        loss = model.train_step(x, y, opt, exchange=ex)
+        loss = model.train_step(x, y, opt, exchange=ex, **kw)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = model.train_step(x, y, opt, exchange=ex)
+        loss = model.train_step(x, y, opt, exchange=ex, **kw)
     barrier()
     dt = time.perf_counter() - t0
     mine = torch.tensor([dt], device=dev)

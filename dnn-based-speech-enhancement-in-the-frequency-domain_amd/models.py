@@ -243,9 +243,15 @@ class _SefdModule(nn.Module):
         raise ValueError(cfg.loss)
 
     # ---- fused training step (what trainer.model_train does per batch, trainer.py:27-39) ---------------------
-    def train_step(self, inputs, targets, optimizer, loss_kind=None, exchange=None):
-        """forward -> loss -> backward -> Adam with no autograd bookkeeping; returns the loss as a 0-d device tensor."""
+    def train_step(self, inputs, targets, optimizer, loss_kind=None, exchange=None, perceptual=None):
+        """forward -> loss -> backward -> Adam with no autograd bookkeeping over the network; returns the loss as a 0-d device tensor.
+        perceptual = 'LMS' | 'PMSQE': the step of model_perceptual_train (trainer.py:45-82), loss = (main + perceptual) / 2 (DCCRN only:
+        CRN + perceptual crashes in the reference)."""
         from .optim import Adam
+        if perceptual and not hasattr(self, "_stft_ref"):
+            raise NotImplementedError("perceptual losses are defined for DCCRN only (models.py:303-314)")
+        if perceptual not in (None, False, "LMS", "PMSQE"):
+            raise ValueError(f"unknown perceptual loss {perceptual!r}")
         if not isinstance(optimizer, Adam):
             raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
@@ -273,7 +279,25 @@ class _SefdModule(nn.Module):
         ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
         rt.g_real.zero_()
         rt.g_imag.zero_()
-        tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)
+        if perceptual:
+            half = torch.full((1,), 0.5, dtype=torch.float32, device=inputs.device)
+            tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, half, rt.g_wav, stream)
+            with torch.enable_grad():                    # the loss kernels' own autograd wrappers on leaf copies of the outputs
+                if perceptual == "PMSQE":
+                    est = rt.out_wav.detach().requires_grad_()
+                    perc = tfl.get_array_pmsqe_loss(targets, est)
+                    (perc * 0.5).backward()
+                    rt.g_wav.add_(est.grad)
+                else:
+                    clean_real, clean_imag = self._stft_ref(targets)
+                    er, ei = rt.out_real.detach().requires_grad_(), rt.out_imag.detach().requires_grad_()
+                    perc = tfl.lms_from_spectra(clean_real, clean_imag, er, ei)
+                    (perc * 0.5).backward()
+                    rt.g_real.copy_(er.grad)
+                    rt.g_imag.copy_(ei.grad)
+            loss = (loss + perc.detach()) / 2
+        else:
+            tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)
         bucket = rt.plan.grad_bucket() if self._grad_buckets == 2 else None
         if sync:
             rt.plan.run_synced(PHASE_BWD, rt.arenas, stream, exchange.all_reduce_stats)

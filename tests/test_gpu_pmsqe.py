@@ -32,6 +32,7 @@ def test_pmsqe_loss_and_gradient_match_oracle(B, power):
     eo = n.clone().double().requires_grad_()
     lo = pmsqe.pmsqe_loss(c, eo, power)
     lo.backward()
+    lo = lo.detach()
     assert abs(loss - float(lo)) <= TOL_LOSS * abs(float(lo)), (loss, float(lo))
     rel = float((grad.double() - eo.grad).norm() / eo.grad.norm())
     assert rel < TOL_GRAD, rel
@@ -93,5 +94,38 @@ def test_dccrn_perceptual_step_with_pmsqe():
             opt.step()
             hist.append(float(loss))
         assert all(map(lambda v: v == v, hist)) and hist[-1] < hist[0], hist
+    finally:
+        cfg.perceptual, cfg.loss, cfg.masking_mode, cfg.dccrn_kernel_num, cfg.act_dtype = old
+
+
+@pytest.mark.parametrize("perceptual", ["PMSQE", "LMS"])
+def test_fused_train_step_with_perceptual_equals_autograd_route(perceptual):
+    """model.train_step(..., perceptual=...) == the model_perceptual_train loop (trainer.py:45-82) through autograd: same loss, same
+    parameters after the Adam step."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.optim import Adam
+    old = (cfg.perceptual, cfg.loss, cfg.masking_mode, list(cfg.dccrn_kernel_num), cfg.act_dtype)
+    cfg.perceptual, cfg.loss, cfg.masking_mode, cfg.dccrn_kernel_num, cfg.act_dtype = perceptual, "SI-SNR", "E", [16, 32, 32, 64, 64, 64], "fp32"
+    try:
+        c, n = speechlike(3, seed=31)
+        c, n = c.cuda(), n.cuda()
+        res = []
+        for fused in (False, True):
+            torch.manual_seed(0)
+            m = models.DCCRN(rnn_units=64, masking_mode="E").to("cuda").train()
+            opt = Adam(m.parameters(), lr=1e-3)
+            for _ in range(2):
+                if fused:
+                    loss = m.train_step(n, c, opt, perceptual=perceptual)
+                else:
+                    real, imag, out = m(n)
+                    loss = (m.loss(out, c) + m.loss(out, c, real, imag, perceptual=True)) / 2
+                    opt.zero_grad()
+                    loss.backward()
+                    opt.step()
+            res.append((float(loss.detach()), torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()))
+        assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[0][0])
+        assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 1e-5
     finally:
         cfg.perceptual, cfg.loss, cfg.masking_mode, cfg.dccrn_kernel_num, cfg.act_dtype = old
