@@ -5,6 +5,8 @@
 //   combine, mask, ola, specout  complex-LSTM glue, cRM application (E/C/R), overlap-add + clamp, layout conversion
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -809,6 +811,135 @@ static void launch_lstm(const Op& op, const ArenaBases& ab, hipStream_t st, bool
   }
 }
 
+// ---- two-level BatchNorm finalize (training, per-rank statistics; forward and backward) ------------------------------------------------
+// The one-workgroup-per-channel kernels above read one float per 128-byte line of the partial-sum rows (a channel's partials are Cpad
+// floats apart): 18-40 us per layer, 22 launches per step.  Here a workgroup owns 32 adjacent channels x one chunk of partial rows
+// (coalesced 128-byte reads, 8 row lanes), writes its fp64 chunk sums to a library-owned scratch, and the LAST workgroup of a channel
+// group to finish (self-resetting ticket counter) adds the chunk sums in chunk order - the result does not depend on the order in which
+// workgroups ran - and does the per-channel finalize.
+constexpr int kFinCG = 32, kFinMaxChunks = 64, kFinMaxC = 2048;
+struct FinScratch { double* sums; unsigned* tickets; };
+
+static FinScratch fin_scratch(hipStream_t st) {
+  // one scratch per stream: finalize launches on one stream are ordered, launches on different streams never share a buffer
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, FinScratch> map;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = map.find(st);
+  if (it != map.end()) return it->second;
+  FinScratch f{};
+  const size_t nsum = (size_t)(kFinMaxC / kFinCG) * kFinMaxChunks * 3 * kFinCG, ntick = kFinMaxC / kFinCG;
+  if (hipMalloc(reinterpret_cast<void**>(&f.sums), nsum * sizeof(double)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&f.tickets), ntick * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(f.tickets, 0, ntick * sizeof(unsigned)) != hipSuccess) {
+    f.sums = nullptr; f.tickets = nullptr;
+    return f;                                      // not cached: the caller falls back to the one-level kernel
+  }
+  map.emplace(st, f);
+  return f;
+}
+
+// rows [nblk][NS][ld] floats; sums NS (2 forward, 2 + slope backward) per channel
+template <int NS, bool BWD>
+__device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, int ld, int rowstride, FinScratch fs, double* out /* LDS [3][32] */) {
+  __shared__ double red[8][3][kFinCG];
+  __shared__ unsigned ticket;
+  const int g = blockIdx.x, k = blockIdx.y, nch = gridDim.y;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = g * kFinCG + cl;
+  const int per = (nblk + nch - 1) / nch, b0 = k * per, b1 = min(nblk, b0 + per);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int b = b0 + rl; b < b1; b += 8) {
+      const float* row = part + (int64_t)b * rowstride;
+      s0 += row[c];
+      s1 += row[ld + c];
+      if (BWD && c == 0) s2 += row[2 * ld];
+    }
+  }
+  red[rl][0][cl] = s0; red[rl][1][cl] = s1; red[rl][2][cl] = s2;
+  __syncthreads();
+  double* mine = fs.sums + ((int64_t)g * kFinMaxChunks + k) * 3 * kFinCG;
+  if (threadIdx.x < 3 * kFinCG) {
+    const int q = threadIdx.x / kFinCG, cc = threadIdx.x % kFinCG;
+    double v = 0.0;
+    for (int r = 0; r < 8; ++r) v += red[r][q][cc];
+    // write-through store (sc0 sc1) + wait: visible to every XCD before the ticket is taken.  No fence: an agent-scope fence writes back and
+    // invalidates this XCD's whole L2 (the GEMM output the next kernel is about to read) - measured +0.5 ms per step
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(mine + q * kFinCG + cc), "v"(v) : "memory");
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicInc(fs.tickets + g, (unsigned)nch - 1);     // wraps to 0 after the last one: ready for the next launch
+  __syncthreads();
+  if (ticket != (unsigned)nch - 1) return false;
+  if (threadIdx.x < 3 * kFinCG) {
+    // cache-bypassing loads (sc0 sc1: the other workgroups' sums come from memory, not from a stale line), all in flight before the first is used
+    const int q = threadIdx.x / kFinCG, cc = threadIdx.x % kFinCG;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(fs.sums + (int64_t)g * kFinMaxChunks * 3 * kFinCG, 0,
+                                                                       kFinMaxChunks * 3 * kFinCG * 8, 0x00020000);
+    double v = 0.0;
+    for (int k0 = 0; k0 < nch; k0 += 16) {
+      double x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int kk = k0 + u < nch ? k0 + u : nch - 1;
+        x[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)((kk * 3 * kFinCG + q * kFinCG + cc) * 8), 0, 17));
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (k0 + u < nch) v += x[u];
+    }
+    out[q * kFinCG + cc] = v;
+  }
+  __syncthreads();
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize2_kernel(const BnFinalize d, const ArenaBases ab, FinScratch fs) {
+  __shared__ double tot[3 * kFinCG];
+  if (!fin_stage1<2, false>(reinterpret_cast<const float*>(rp(ab, d.part)), d.nblk, d.C, d.Cpad, 2 * d.Cpad, fs, tot)) return;
+  const int c = blockIdx.x * kFinCG + threadIdx.x;
+  if (threadIdx.x < kFinCG && c < d.C) {
+    const double mean = tot[threadIdx.x] / d.count;
+    double var = tot[kFinCG + threadIdx.x] / d.count - mean * mean;
+    if (var < 0) var = 0;
+    float* mi = reinterpret_cast<float*>(rp(ab, d.mean_invstd));
+    mi[c] = (float)mean;
+    mi[d.C + c] = (float)(1.0 / sqrt(var + (double)d.eps));
+    if (d.running_mean.arena >= 0) {
+      float* rm = reinterpret_cast<float*>(rp(ab, d.running_mean));
+      float* rv = reinterpret_cast<float*>(rp(ab, d.running_var));
+      const double unb = var * (d.count / (d.count > 1 ? d.count - 1 : 1));
+      rm[c] = (float)((1.0 - d.momentum) * rm[c] + d.momentum * mean);
+      rv[c] = (float)((1.0 - d.momentum) * rv[c] + d.momentum * unb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const BnBwdApply d, const ArenaBases ab, FinScratch fs) {
+  __shared__ double tot[3 * kFinCG];
+  const int C = d.r.C;
+  if (!fin_stage1<3, true>(reinterpret_cast<const float*>(rp(ab, d.r.part)), d.r.nblk, C, C, 3 * C, fs, tot)) return;
+  const int c = blockIdx.x * kFinCG + threadIdx.x;
+  if (threadIdx.x < kFinCG && c < C) {
+    float* t = reinterpret_cast<float*>(rp(ab, d.totals));
+    t[c] = (float)tot[threadIdx.x];
+    t[C + c] = (float)tot[kFinCG + threadIdx.x];
+    reinterpret_cast<float*>(rp(ab, d.dbeta))[c] = (float)tot[threadIdx.x];
+    reinterpret_cast<float*>(rp(ab, d.dgamma))[c] = (float)tot[kFinCG + threadIdx.x];
+    if (c == 0) reinterpret_cast<float*>(rp(ab, d.dslope))[0] = (float)tot[2 * kFinCG];
+  }
+}
+
+static bool fin_two_level(int nblk, int C, hipStream_t st, FinScratch* fs, dim3* grid) {
+  static const bool on = !(getenv("SEFD_BN_FIN2") && atoi(getenv("SEFD_BN_FIN2")) == 0);
+  if (!on || nblk < 64 || C > kFinMaxC) return false;
+  *fs = fin_scratch(st);
+  if (!fs->sums) return false;
+  const int nch = std::min(kFinMaxChunks, (nblk + 31) / 32);
+  *grid = dim3((C + kFinCG - 1) / kFinCG, nch);
+  return true;
+}
+
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
   switch (op.kind) {
     case OP_PACK:
@@ -819,14 +950,26 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
       hipLaunchKernelGGL(splitsum_kernel, dim3((unsigned)std::min<int64_t>((op.unpack.n + 63) / 64, 8192)), dim3(256), 0, st, op.unpack, ab); break;
     case OP_UNPACK:
       hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(op.unpack.n)), dim3(256), 0, st, op.unpack, ab); break;
-    case OP_BN_FINALIZE:
-      hipLaunchKernelGGL(bn_finalize_kernel, dim3(op.bnf.C), dim3(256), 0, st, op.bnf, ab); break;
+    case OP_BN_FINALIZE: {
+      FinScratch fs; dim3 grid;
+      if (op.bnf.nblk >= 0 && op.bnf.mode == 0 && fin_two_level(op.bnf.nblk, op.bnf.C, st, &fs, &grid))
+        hipLaunchKernelGGL(bn_finalize2_kernel, grid, dim3(256), 0, st, op.bnf, ab, fs);
+      else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(op.bnf.C), dim3(256), 0, st, op.bnf, ab);
+      break;
+    }
     case OP_BN_APPLY:
     case OP_BN_BWD_REDUCE:
     case OP_BN_BWD_APPLY:
       launch_bn(op, ab, st); break;
-    case OP_BN_BWD_FINALIZE:
-      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op.bnb.r.C), dim3(256), 0, st, op.bnb, ab); break;
+    case OP_BN_BWD_FINALIZE: {
+      FinScratch fs; dim3 grid;
+      if (fin_two_level(op.bnb.r.nblk, op.bnb.r.C, st, &fs, &grid))
+        hipLaunchKernelGGL(bn_bwd_finalize2_kernel, grid, dim3(256), 0, st, op.bnb, ab, fs);
+      else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(op.bnb.r.C), dim3(256), 0, st, op.bnb, ab);
+      break;
+    }
     case OP_LSTM_FWD:
     case OP_LSTM_BWD: {
       const bool fwd = op.kind == OP_LSTM_FWD;
