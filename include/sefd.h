@@ -117,8 +117,8 @@ int32_t sefd_lms_backward(const float* clean_r, const float* clean_i, const floa
  * The arithmetic is third-party (asteroid SingleSrcPMSQE + PITLossWrapper('pw_pt') + asteroid_filterbanks STFTFB / Encoder / mag), absent
  * from the reference tree and unversioned there: PARITY UNPINNED; this is the published algorithm as oracle/pmsqe.py restates it.
  * est / clean: fp32 [B][L] device waves, L a whole number of seconds (the reference's view(N, -1, fs)), at most 6 seconds (PIT over
- * the seconds enumerates the permutations).  power: 0 = the loss sees the magnitude spectrum sqrt(re^2 + im^2 + 1e-8) (transforms.mag,
- * what the reference call chain feeds it), 1 = the power spectrum (the paper's definition).
+ * the seconds enumerates the permutations).  power: 1 = the loss works on the power spectrum re^2 + im^2 (the paper's definition; the host default),
+ * 0 = on the magnitude sqrt(re^2 + im^2 + 1e-8) that transforms.mag hands over in the reference call chain, taken literally.
  * tab: fp32 [sefd_pmsqe_table_floats()] device = thr[49] zp[49] width[49] corr[49] aterm[49] mask[257] (at 245), then at 512 the
  * windowed DFT tables cos [512][257], -sin [512][257] and their transposes [257][512] x 2;  itab: int32 [64 + 257] device = prefix sums
  * of the FFT bins per Bark band [50] and, at 64, the band of every bin (-1: none).  ws: fp32 [sefd_pmsqe_ws_floats(B, L)] device, must

@@ -21,7 +21,7 @@ def _loss_and_grad(c, e, power):
         loss.backward()
         return float(loss.detach()), ed.grad.cpu()
     finally:
-        cfg.pmsqe_power = False
+        cfg.pmsqe_power = True
 
 
 @pytest.mark.parametrize("power", [False, True])
@@ -43,8 +43,8 @@ def test_pmsqe_loss_and_gradient_match_oracle(B, power):
 def test_pit_picks_the_rotation():
     c, n = speechlike(3, seed=4)
     rot = n.reshape(3, 3, 16000)[:, [2, 0, 1]].reshape(3, -1).contiguous()
-    l0, _ = _loss_and_grad(c, n, False)
-    l1, g1 = _loss_and_grad(c, rot, False)
+    l0, _ = _loss_and_grad(c, n, True)
+    l1, g1 = _loss_and_grad(c, rot, True)
     assert abs(l0 - l1) <= 1e-5 * abs(l0)
     eo = rot.clone().double().requires_grad_()
     pmsqe.pmsqe_loss(c, eo).backward()

@@ -81,8 +81,12 @@ def train(args):
     res = {}
     init = None
     # third leg: fp32 again with another batch order - the run-to-run spread of the metric, against which the bf16 delta is read
-    for tag in ("fp32", "bf16", "fp32_rerun", "bf16_rerun"):
+    # last leg: bf16 with the perceptual step (SI-SNR + PMSQE) / 2 - PMSQE is built to track PESQ, so a PESQ gain on the held-out set
+    # is a consistency check of the (unpinned) loss and its hand-derived gradient
+    for tag in args.legs.split(","):
         dt = tag.split("_")[0]
+        perc = "PMSQE" if "pmsqe" in tag else None
+        cfg.pmsqe_power = tag.endswith("pmsqe_power")
         cfg.masking_mode, cfg.loss, cfg.act_dtype = "E", "SI-SNR", dt
         torch.manual_seed(0)
         m = models.DCCRN(rnn_units=cfg.rnn_units, masking_mode="E").to("cuda").train()
@@ -96,7 +100,7 @@ def train(args):
         for step in range(args.steps):
             idx = order.integers(0, args.pool, B)
             x, y = torch.from_numpy(pool_n[idx]).cuda(), torch.from_numpy(pool_c[idx]).cuda()
-            loss = m.train_step(x, y, opt)
+            loss = m.train_step(x, y, opt, perceptual=perc)
             if step % 20 == 0 or step == args.steps - 1:
                 losses.append((step, float(loss)))
         m.eval()
@@ -121,6 +125,8 @@ def score(args):
     ld = lambda n: np.load(os.path.join(args.dir, n)).astype(np.float64)
     clean, noisy, e32, e16, e32b = ld("clean.npy"), ld("noisy.npy"), ld("enhanced_fp32.npy"), ld("enhanced_bf16.npy"), ld("enhanced_fp32_rerun.npy")
     e16b = ld("enhanced_bf16_rerun.npy") if os.path.exists(os.path.join(args.dir, "enhanced_bf16_rerun.npy")) else None
+    e16p = ld("enhanced_bf16_pmsqe.npy") if os.path.exists(os.path.join(args.dir, "enhanced_bf16_pmsqe.npy")) else None
+    e16pp = ld("enhanced_bf16_pmsqe_power.npy") if os.path.exists(os.path.join(args.dir, "enhanced_bf16_pmsqe_power.npy")) else None
     pesq = None
     so = "/root/reference/PESQ.so"
     if os.path.exists(so):
@@ -133,7 +139,7 @@ def score(args):
     rows = []
     for i in range(len(clean)):
         r = dict(utt=i)
-        for name, sig in (("noisy", noisy), ("fp32", e32), ("bf16", e16), ("fp32_rerun", e32b)) + ((("bf16_rerun", e16b),) if e16b is not None else ()):
+        for name, sig in (("noisy", noisy), ("fp32", e32), ("bf16", e16), ("fp32_rerun", e32b)) + ((("bf16_rerun", e16b),) if e16b is not None else ()) + ((("bf16_pmsqe", e16p),) if e16p is not None else ()) + ((("bf16_pmsqe_power", e16pp),) if e16pp is not None else ()):
             r["stoi_" + name] = float(est.cal_stoi([sig[i] / 32768.0], [clean[i] / 32768.0])[0])
             if pesq:
                 r["pesq_" + name] = pesq(clean[i], sig[i])
@@ -146,10 +152,14 @@ def score(args):
                delta_fp32_rerun_minus_fp32={k: mean[k + "_fp32_rerun"] - mean[k + "_fp32"] for k in (("pesq", "stoi") if pesq else ("stoi",))},
                delta_bf16_mean_minus_fp32_mean={k: (mean[k + "_bf16"] + mean.get(k + "_bf16_rerun", mean[k + "_bf16"])) / 2 - (mean[k + "_fp32"] + mean[k + "_fp32_rerun"]) / 2
                                                 for k in (("pesq", "stoi") if pesq else ("stoi",))},
+               delta_bf16_pmsqe_minus_bf16_mean=({k: mean[k + "_bf16_pmsqe"] - (mean[k + "_bf16"] + mean.get(k + "_bf16_rerun", mean[k + "_bf16"])) / 2
+                                                  for k in (("pesq", "stoi") if pesq else ("stoi",))} if e16p is not None else None),
+               delta_bf16_pmsqe_power_minus_bf16_mean=({k: mean[k + "_bf16_pmsqe_power"] - (mean[k + "_bf16"] + mean.get(k + "_bf16_rerun", mean[k + "_bf16"])) / 2
+                                                        for k in (("pesq", "stoi") if pesq else ("stoi",))} if e16pp is not None else None),
                per_utt_abs_delta_max={k: float(max(abs(r[k + "_bf16"] - r[k + "_fp32"]) for r in rows)) for k in (("pesq", "stoi") if pesq else ("stoi",))},
                train=json.load(open(os.path.join(args.dir, "train_log.json"))), rows=rows)
     json.dump(out, open(args.json, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("mean", "delta_bf16_minus_fp32", "delta_fp32_rerun_minus_fp32", "delta_bf16_mean_minus_fp32_mean", "per_utt_abs_delta_max")}, indent=1))
+    print(json.dumps({k: out[k] for k in ("mean", "delta_bf16_minus_fp32", "delta_fp32_rerun_minus_fp32", "delta_bf16_mean_minus_fp32_mean", "delta_bf16_pmsqe_minus_bf16_mean", "delta_bf16_pmsqe_power_minus_bf16_mean", "per_utt_abs_delta_max")}, indent=1))
 
 
 if __name__ == "__main__":
@@ -161,6 +171,7 @@ if __name__ == "__main__":
     t.add_argument("--lr", type=float, default=1e-3)
     t.add_argument("--pool", type=int, default=96)
     t.add_argument("--heldout", type=int, default=16)
+    t.add_argument("--legs", default="fp32,bf16,fp32_rerun,bf16_rerun,bf16_pmsqe")
     t.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "heldout"))
     s = sub.add_parser("score")
     s.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out", "heldout"))
