@@ -67,7 +67,8 @@ num_groups_in_drop_band = 2
 
 # ---- build-side knobs (not in the reference)
 act_dtype = 'fp32'          # 'fp32' (parity mode) or 'bf16' (storage + MFMA operand dtype, fp32 accumulate)
-pmsqe_power = True          # PMSQE sees power spectra (the published definition; +0.29 PESQ on the held-out set, profiles/r02_heldout_eval.json); False = the magnitudes of transforms.mag taken literally (-0.10 PESQ)
+pmsqe_power = False         # False (default) = the reference's literal call chain: PMSQE is handed transforms.mag(...) magnitudes (tools_for_loss.py:267-269).
+                            # True = opt-in build-side variant on power spectra |X|^2 (the published loss's own definition; +0.29 PESQ on the synthetic held-out set, profiles/r02_heldout_eval.json)
 train_data_path = None      # [N, 2, L] .npy files of (noisy, clean) pairs; dataloader.py:63-71 has placeholder paths
 valid_data_path = None
 test_data_path = None

@@ -71,6 +71,46 @@ class GradientExchange:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
 
+    # ---- what the epoch driver needs besides the gradient exchange (train_interface.run)
+    def broadcast_model(self, model):
+        """Rank 0's parameters and BatchNorm buffers to every rank, once before the first step: each process builds its model with its
+        own RNG state, and the all-reduce only keeps replicas identical if they start identical."""
+        if self.world == 1:
+            return
+        tensors = [t for t in (getattr(model, "_flat_param", None), getattr(model, "_flat_state", None), getattr(model, "_flat_nbt", None))
+                   if t is not None]
+        if not tensors:                          # not flattened yet (model still on the CPU, or a plain nn.Module)
+            tensors = [p.data for p in model.parameters()] + [b for b in model.buffers()]
+        for t in tensors:
+            dist.broadcast(t, src=0, group=self.pg)
+
+    def all_reduce_autograd(self, params):
+        """The literal `loss.backward()` route under DDP (direct-mapping trainers, foreign optimizers): p.grad <- mean over ranks,
+        as one flat all-reduce.  No overlap with the backward - the fused `train_step` is the fast path."""
+        if self.world == 1:
+            return
+        ps = [p for p in params if p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        self.all_reduce(flat)
+        flat *= self.grad_scale
+        off = 0
+        for p in ps:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+    def mean_scalars(self, values):
+        """Mean over ranks of a few host / device scalars (validation losses: every rank scores its own shard)."""
+        if self.world == 1:
+            return [float(v) for v in values]
+        dev = next((v.device for v in values if torch.is_tensor(v)), torch.device("cpu"))
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return [float(v) / self.world for v in t]
+
+
 def shard_batch(n_items: int, rank: int, world: int):
     """Contiguous shard [lo, hi) of a global batch for `rank` (drop_last semantics of the reference loader per rank)."""
     per = n_items // world

@@ -255,6 +255,11 @@ class _SefdModule(nn.Module):
         if not isinstance(optimizer, Adam):
             raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
+        if exchange is not None and exchange.world > 1 and (loss_kind or cfg.loss) == 'SI-SDR':
+            # tools_for_loss.py:91-94 takes the batch mean of the ratios INSIDE the log: rank-averaged gradients of per-rank losses are not
+            # the gradient of the global-batch loss; every other loss is a mean of per-utterance terms and shards exactly
+            raise NotImplementedError("cfg.loss == 'SI-SDR' does not decompose over data-parallel ranks (mean of ratios inside the log); "
+                                      "train it on one GPU or use SI-SNR / SDR / MSE")
         inputs = inputs.float()
         targets = targets.float().contiguous()
         B, L = inputs.shape
@@ -295,6 +300,7 @@ class _SefdModule(nn.Module):
                     (perc * 0.5).backward()
                     rt.g_real.copy_(er.grad)
                     rt.g_imag.copy_(ei.grad)
+            self._last_loss_parts = (loss, perc.detach())       # (main, perceptual): what model_perceptual_train logs
             loss = (loss + perc.detach()) / 2
         else:
             tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, None, rt.g_wav, stream)

@@ -99,6 +99,8 @@ class Adam(torch.optim.Optimizer):
         return sd
 
     def _apply_state(self, sd):
+        if not sd["state"]:              # a checkpoint taken before the first step: back to a fresh optimizer
+            self._m.zero_(); self._v.zero_(); self._step = 0
         for i, (off, n, shape) in enumerate(self._model._param_slices):
             st = sd["state"].get(i, sd["state"].get(str(i)))
             if st is None:
@@ -113,9 +115,9 @@ class Adam(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         """train_interface.py:110: `optimizer.load_state_dict(checkpoint['optimizer'])` right after construction."""
-        try:
-            self.bind()
-        except RuntimeError:
-            self._pending = sd           # model not on the GPU yet: applied by the first bind
+        model = self._model if self._model is not None else self._owner()
+        if model is not None and next(model.parameters()).device.type != "cuda":
+            self._pending = sd           # model not on the GPU yet (the one deferrable case): applied by the first bind
             return
+        self.bind()                      # anything else that fails here (foreign parameters, allocation, ...) is a failed resume: raise
         self._apply_state(sd)

@@ -263,9 +263,9 @@ class _PMSQE(torch.autograd.Function):
 
 def get_array_pmsqe_loss(clean_array, est_array):
     """tools_for_loss.py:258-269: [N, L] (or [N, 1, L]) waves, L whole seconds -> scalar.  `cfg.pmsqe_power` (build-side knob, default
-    True): the loss works on the power spectrum |X|^2, the quantity the published algorithm and its P.862 constants are defined on; False
-    takes the `transforms.mag` output of the reference's call chain literally (which of the two asteroid's loss ends up with cannot be
-    checked here - asteroid is absent; with magnitudes the loss LOWERS held-out PESQ, with powers it raises it by 0.29)."""
+    False): False is the reference's literal call chain - the loss is handed the `transforms.mag` magnitudes (tools_for_loss.py:267-269); True is
+    an opt-in variant that works on the power spectrum |X|^2, the quantity the published algorithm and its P.862 constants are defined on
+    (+0.29 held-out PESQ on synthetic data; not the reference's behaviour)."""
     if clean_array.dim() == 3:
         clean_array, est_array = clean_array.flatten(1), est_array.flatten(1)
-    return _PMSQE.apply(clean_array, est_array, bool(getattr(cfg, "pmsqe_power", True)))
+    return _PMSQE.apply(clean_array, est_array, bool(getattr(cfg, "pmsqe_power", False)))

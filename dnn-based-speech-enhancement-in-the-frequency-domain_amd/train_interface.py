@@ -106,16 +106,25 @@ def run(train_loader, validation_loader, model=None, optimizer=None, writer=None
             write_status_to_log_file(fp, total_params)
     writer = writer if writer is not None else _NullWriter()
     perceptual = cfg.perceptual is not False
-    kw = {"exchange": exchange} if (exchange is not None and trainer in (tr.model_train, tr.fullsubnet_train)) else {}
+    kw = {"exchange": exchange} if exchange is not None else {}          # all five trainers take it
+    if exchange is not None and exchange.world > 1:
+        # replicas must START identical (each process built its model from its own RNG state, or loaded nothing): rank 0's parameters and
+        # BatchNorm buffers go to everyone; optimizer moments are zero / come from the same checkpoint file on every rank
+        if DEVICE.type == "cuda" and getattr(model, "_flat_param", 0) is None:
+            model._flatten(DEVICE)
+        exchange.broadcast_model(model)
     for epoch in range(epoch_start_idx, max_epochs + 1):
         start_time = time.time()
         if hasattr(train_loader, "set_epoch"):
             train_loader.set_epoch(epoch)
         res = trainer(model, optimizer, train_loader, DEVICE, **kw)
-        if master:                                                    # every rank holds identical parameters after the all-reduce
+        if master:                                                    # replicas are identical: same start (broadcast above), same averaged gradients
             save_checkpoint(str(dir_to_save + '/' + ('chkpt_%d.pt' % epoch)), model, optimizer, epoch)
-        # every rank validates its shard (no collective inside); rank 0's numbers are the logged ones
+        # every rank validates its shard; the losses (what picks chkpt_opt) are averaged over the ranks, PESQ / STOI are rank 0's shard
         val = estimator(model, validation_loader, writer if master else None, dir_to_save, epoch, DEVICE, scorers=scorers if master else None)
+        if exchange is not None and exchange.world > 1:
+            nl = len(val) - 2
+            val = tuple(exchange.mean_scalars(val[:nl])) + tuple(val[nl:])
         if perceptual:
             train_loss, train_main_loss, train_perceptual_loss = res
             vali_loss, validation_main_loss, validation_perceptual_loss, vali_pesq, vali_stoi = val

@@ -3,6 +3,8 @@
 `model_train(model, optimizer, train_loader, DEVICE)` has the reference's signature and epoch semantics (mean of the
 per-batch losses).  With `sefd_amd.optim.Adam` the whole batch step is the fused HIP path (`model.train_step`);
 with any other optimizer it is the literal reference loop (autograd Functions over the same HIP kernels)."""
+import os
+
 import torch
 
 from . import config as cfg
@@ -26,32 +28,49 @@ def model_train(model, optimizer, train_loader, DEVICE, exchange=None):
             loss = model.loss(outputs, targets)
             optimizer.zero_grad()
             loss.backward()
+            _exchange_grads(model, exchange)
             optimizer.step()
         train_loss += loss.detach()          # the reference accumulates the graph-attached tensor (trainer.py:39)
     return train_loss / max(batch_num, 1)
 
 
-def model_perceptual_train(model, optimizer, train_loader, DEVICE):
-    """trainer.py:45-82: loss = (main + perceptual) / 2, forward called without targets."""
+def model_perceptual_train(model, optimizer, train_loader, DEVICE, exchange=None):
+    """trainer.py:45-82: loss = (main + perceptual) / 2, forward called without targets.  With `sefd_amd.optim.Adam` the batch is the
+    fused `train_step(perceptual=cfg.perceptual)` (same numbers as the autograd route below, tests/test_gpu_validate.py), which is also
+    the data-parallel path (`exchange`)."""
     train_loss = train_main = train_perc = 0
     batch_num = 0
     model.train()
+    fused = isinstance(optimizer, Adam)
     for inputs, targets in train_loader:
         batch_num += 1
         inputs = inputs.float().to(DEVICE)
         targets = targets.float().to(DEVICE)
-        real_spec, img_spec, outputs = model(inputs)
-        main_loss = model.loss(outputs, targets)
-        perceptual_loss = model.loss(outputs, targets, real_spec, img_spec, perceptual=True)
-        loss = (main_loss + perceptual_loss) / 2
-        optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
+        if fused:
+            loss = model.train_step(inputs, targets, optimizer, exchange=exchange, perceptual=cfg.perceptual)
+            main_loss, perceptual_loss = model._last_loss_parts
+        else:
+            real_spec, img_spec, outputs = model(inputs)
+            main_loss = model.loss(outputs, targets)
+            perceptual_loss = model.loss(outputs, targets, real_spec, img_spec, perceptual=True)
+            loss = (main_loss + perceptual_loss) / 2
+            optimizer.zero_grad()
+            loss.backward()
+            _exchange_grads(model, exchange)
+            optimizer.step()
         train_loss += loss.detach()
         train_main += main_loss.detach()
         train_perc += perceptual_loss.detach()
     n = max(batch_num, 1)
     return train_loss / n, train_main / n, train_perc / n
+
+
+def _exchange_grads(model, exchange):
+    """Data-parallel step of the `loss.backward()` route: p.grad <- mean over ranks (ddp.GradientExchange.all_reduce_autograd)."""
+    if exchange is not None and exchange.world > 1:
+        if cfg.loss == 'SI-SDR':
+            raise NotImplementedError("cfg.loss == 'SI-SDR' does not decompose over data-parallel ranks (tools_for_loss.py:91-94)")
+        exchange.all_reduce_autograd(list(model.parameters()))
 
 
 def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
@@ -76,13 +95,15 @@ def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
             loss = model.loss(cIRM, cRM)
             optimizer.zero_grad()
             loss.backward()
+            _exchange_grads(model, exchange)
             optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
 
 
-def dccrn_direct_train(model, optimizer, train_loader, DEVICE):
-    """trainer.py:121-150 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra."""
+def dccrn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
+    """trainer.py:121-150 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra.  Autograd route (the loss is on the
+    spectra, not on the waveform the fused step differentiates); under `exchange` the gradients are averaged after the backward."""
     train_loss = torch.zeros((), device=DEVICE)
     batch_num = 0
     model.train()
@@ -96,12 +117,13 @@ def dccrn_direct_train(model, optimizer, train_loader, DEVICE):
         loss = (real_loss + imag_loss) / 2
         optimizer.zero_grad()
         loss.backward()
+        _exchange_grads(model, exchange)
         optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
 
 
-def crn_direct_train(model, optimizer, train_loader, DEVICE):
+def crn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:150-181: CRN spectral mapping ('Direct(None make)'): the loss compares the mapped magnitudes (first output
     of `CRN.forward`) with the target magnitudes; the waveform output carries no loss."""
     train_loss = torch.zeros((), device=DEVICE)
@@ -115,6 +137,7 @@ def crn_direct_train(model, optimizer, train_loader, DEVICE):
         loss = model.loss(output_mag, target_mag)
         optimizer.zero_grad()
         loss.backward()
+        _exchange_grads(model, exchange)
         optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
@@ -122,14 +145,15 @@ def crn_direct_train(model, optimizer, train_loader, DEVICE):
 
 # ------------------------------------------------------------------------------------------------ validation
 def _default_scorers():
-    """(cal_pesq, cal_stoi) of sefd_amd.tools_for_estimate: the C++ P.862 / STOI scorers (reference tools_for_estimate.py:68-99
-    calls a closed x86 PESQ.so and pystoi).  None when the scorer library has not been built."""
-    try:
-        from . import tools_for_estimate as te
-        te.lib()
-        return te.cal_pesq, te.cal_stoi
-    except Exception:
+    """(cal_pesq, cal_stoi) of sefd_amd.tools_for_estimate (reference tools_for_estimate.py:68-99 calls a closed x86 PESQ.so and
+    pystoi): the C++ scorers of libsefd_scorers.so.  A scorer the library does not export scores NaN (the other one still runs);
+    None only when the library itself has not been built."""
+    from . import tools_for_estimate as te
+    if not os.path.exists(te.LIB_PATH):
         return None
+    te.lib()                                     # a library that exists but does not load is an error, not "no scorers"
+    nan = lambda est, clean: [float("nan")] * len(est)      # noqa: E731
+    return getattr(te, "cal_pesq", nan), te.cal_stoi
 
 
 def _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch_fn, n_losses, scorers):

@@ -7,8 +7,8 @@ function based on the perceptual evaluation of the speech quality", IEEE SPL 201
 
   waves [N, L] -> view(N, L / 16000, 16000): every second of a clip is one "source"            (tools_for_loss.py:262-263)
   STFT: 512-point, hop 256, no padding, periodic sqrt-Hann analysis window, filters / 16         (Encoder(STFTFB(512, 512, stride 256)))
-  spectrum the loss works on: power re^2 + im^2 (the paper's definition; default)  [power=False: the magnitude sqrt(re^2 + im^2 + 1e-8) that
-  transforms.mag hands over, taken literally - which one asteroid's loss ends up with cannot be checked here]
+  spectrum the loss works on: the magnitude sqrt(re^2 + im^2 + 1e-8) that transforms.mag hands over (tools_for_loss.py:267-269; default,
+  the reference's literal chain)  [power=True: re^2 + im^2, the paper's own definition - the build's opt-in cfg.pmsqe_power]
   per (estimate second i, clean second j): SLL equalisation -> 49-band Bark spectrum (P.862.2 tables) -> Bark frequency equalisation ->
   gain equalisation -> Zwicker loudness -> symmetric / asymmetric disturbance -> per-frame norms / audible-power weight -> mean over frames
   PIT: minimum over the permutations of the seconds of the mean pair loss, then mean over the batch           (PITLossWrapper 'pw_pt')
@@ -60,7 +60,7 @@ def stft_filters():
     return torch.tensor(np.cos(ang) * win / scale), torch.tensor(-np.sin(ang) * win / scale)     # [257, 512] each
 
 
-def spectra(wav, power=True):
+def spectra(wav, power=False):
     """wav [N, L] float64 -> [N, S, T, 257] (S seconds, T = 61 frames per second)."""
     N, L = wav.shape
     if L % FS:
@@ -111,13 +111,13 @@ def single_src_pmsqe(deg, ref):
     return (ALPHA * wd + BETA * wda).sum((-1, -2)) / Tn
 
 
-def pairwise(est_wav, clean_wav, power=True):
+def pairwise(est_wav, clean_wav, power=False):
     """[N, S, S]: loss of estimate second i against clean second j."""
     e, c = spectra(est_wav, power), spectra(clean_wav, power)
     return single_src_pmsqe(e[:, :, None], c[:, None, :])
 
 
-def pmsqe_loss(clean_wav, est_wav, power=True):
+def pmsqe_loss(clean_wav, est_wav, power=False):
     """get_array_pmsqe_loss(clean_array, est_array) (tools_for_loss.py:258-269) -> scalar."""
     pw = pairwise(est_wav.double(), clean_wav.double(), power)
     S = pw.shape[1]

@@ -241,3 +241,66 @@ def test_world2_bucketed_exchange_equals_flat_gloo():
     res = [q.get(timeout=5) for _ in range(world)]
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] and res[0][2] > 0               # both ranks hold the same summed gradient
+
+
+# ------------------------------------------------------------------------------------------------ epoch-driver helpers (train_interface.run)
+def _driver_worker(rank, world, port, q):
+    """broadcast_model (replicas start identical), all_reduce_autograd (the loss.backward() route of the direct-mapping / perceptual
+    trainers under DDP == the global-batch gradient), mean_scalars (validation losses), and the SI-SDR refusal."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, trainer
+    from sefd_amd.ddp import GradientExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = GradientExchange()
+        torch.manual_seed(100 + rank)                               # every process builds its model from its own RNG state
+        net = torch.nn.Sequential(torch.nn.Linear(16, 8), torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 1))
+        ex.broadcast_model(net)
+        torch.manual_seed(100)
+        ref = torch.nn.Sequential(torch.nn.Linear(16, 8), torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 1))
+        same = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+        net.eval(); ref.eval()                                      # (BatchNorm batch statistics are per rank: take them out of the identity)
+        torch.manual_seed(3)
+        x, y = torch.randn(8, 16), torch.randn(8, 1)
+        lo, hi = rank * 4, rank * 4 + 4
+        torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+        cfg.loss = 'MSE'
+        trainer._exchange_grads(net, ex)                            # what the autograd trainers call between backward() and step()
+        torch.nn.functional.mse_loss(ref(x), y).backward()
+        err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
+        means = ex.mean_scalars([torch.tensor(float(rank + 1)), 10.0 * (rank + 1)])
+        cfg.loss = 'SI-SDR'
+        try:
+            trainer._exchange_grads(net, ex)
+            refused = False
+        except NotImplementedError:
+            refused = True
+        finally:
+            cfg.loss = 'SDR'
+        q.put((rank, same, err, means, refused))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_epoch_driver_helpers_gloo():
+    import inspect
+    import sefd_amd  # noqa: F401
+    from sefd_amd import trainer
+    for fn in (trainer.model_train, trainer.model_perceptual_train, trainer.fullsubnet_train, trainer.dccrn_direct_train, trainer.crn_direct_train):
+        assert "exchange" in inspect.signature(fn).parameters, fn.__name__       # all five take the DDP exchange
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(world)]
+    for rank, same, err, means, refused in res:
+        assert same and err < 1e-6 and refused, res
+        assert means == [1.5, 15.0], means

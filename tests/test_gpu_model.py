@@ -554,9 +554,15 @@ def test_bf16_crn_step_against_reference_golden():
     assert rec["grad_cosine"] > BF16_GRAD_COS, rec
 
 
-def test_bf16_fullsubnet_step_against_reference_golden():
+@pytest.mark.parametrize("row_block", [False, True])
+def test_bf16_fullsubnet_step_against_reference_golden(row_block, monkeypatch):
+    """row_block=True: the planner's row threshold is lowered (SEFD_LSTM_ROWS_MIN=64; the golden has B = 2 -> 514 sub-band rows, the bench
+    B = 64 -> 16 448) so that the sub-band model runs on the row-block kernels of lstm_rows.hip - fused input projections, bf16 gate slabs,
+    the 2-output head's gradient formed in the backward kernel - i.e. the kernels the FullSubNet bench line times, against the reference."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models, tools_for_model as tools
+    if row_block:
+        monkeypatch.setenv("SEFD_LSTM_ROWS_MIN", "64")
     g = load_golden("fsn_default_mse")
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     cfg.loss, cfg.act_dtype = "MSE", "bf16"
@@ -580,7 +586,9 @@ def test_bf16_fullsubnet_step_against_reference_golden():
     rec = dict(crm_rel_l2=rel_l2(crm, g["g/crm"]), crm_rel_max=rel_err(crm, g["g/crm"]), loss=float(lossv), loss_ref=float(g["g/loss"]),
                grad_rel_l2_worst=float(max(vals)), grad_rel_l2_median=float(np.median(vals)), B=B, L=L)
     rec["loss_rel"] = abs(rec["loss"] - rec["loss_ref"]) / abs(rec["loss_ref"])
-    _bf16_record("fsn_default_mse", rec)
+    plan = next(v for k, v in m._runtimes.items() if k[0] == "fsn")[0]
+    assert (plan.buffer("sb_model.l0.gates")[3] == 1) == row_block         # bf16 gate slabs <=> row-block kernels
+    _bf16_record("fsn_default_mse" + ("_rowblock" if row_block else ""), rec)
     assert rec["crm_rel_l2"] < BF16_OUT_L2 and rec["crm_rel_max"] < BF16_OUT_MAX and rec["loss_rel"] < BF16_LOSS, rec
     assert rec["grad_rel_l2_median"] < BF16_GRAD_L2 and rec["grad_rel_l2_worst"] < BF16_GRAD_WORST, rec
 
@@ -611,4 +619,61 @@ def test_bf16_full_shape_properties_at_bench_size():
     opt = Adam(m.parameters(), lr=1e-3)
     losses = [float(m.train_step(x, y, opt)) for _ in range(4)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert bool(torch.isfinite(m._flat_param).all())
+
+
+# ------------------------------------------------------------------------------------------------ every benched configuration at its bench size
+def _bench_batch(B, L=48000, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    clean = 0.1 * torch.randn(B, L, generator=g)
+    return (clean + 0.05 * torch.randn(B, L, generator=g)).cuda(), clean.cuda()
+
+
+def test_bf16_fullsubnet_at_bench_size():
+    """BASELINE configs[2]: FullSubNet, B = 64 x 3 s, bf16, dropout 0.8 active - finite, loss decreasing over the fused steps."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.optim import Adam
+    cfg.loss, cfg.act_dtype = "MSE", "bf16"
+    try:
+        torch.manual_seed(0)
+        m = models.FullSubNet().to("cuda").train()
+    finally:
+        cfg.act_dtype = "fp32"
+    x, y = _bench_batch(64)
+    opt = Adam(m.parameters(), lr=1e-3)
+    losses = [float(m.train_step(x, y, opt)) for _ in range(4)]
+    assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses
+    assert bool(torch.isfinite(m._flat_param).all()) and bool(torch.isfinite(m._flat_grad).all())
+    plan = next(v for k, v in m._runtimes.items() if k[0] == "fsn")[0]
+    assert plan.buffer("sb_model.l0.gates")[3] == 1                          # the row-block kernels ran
+
+
+def test_bf16_dccrn_large_at_bench_size():
+    """BASELINE configs[4] per-GPU shard as benched (B = 32): DCCRN-large, cluster LSTM kernels (H = 256)."""
+    from sefd_amd.optim import Adam
+    m = make_model((64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", dtype="bf16")
+    m.train()
+    x, y = _bench_batch(32)
+    opt = Adam(m.parameters(), lr=1e-3)
+    losses = [float(m.train_step(x, y, opt)) for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert bool(torch.isfinite(m._flat_param).all())
+
+
+@pytest.mark.parametrize("perceptual", ["PMSQE", "LMS"])
+def test_bf16_dccrn_perceptual_at_bench_size(perceptual):
+    """BASELINE configs[3] per-GPU shard (B = 32): loss = (SI-SNR + perceptual) / 2 through the fused step, reference-literal PMSQE."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg
+    from sefd_amd.optim import Adam
+    assert cfg.pmsqe_power is False
+    m = make_model((32, 64, 128, 256, 256, 256), 256, "C", "SI-SNR", dtype="bf16")
+    m.train()
+    x, y = _bench_batch(32)
+    opt = Adam(m.parameters(), lr=1e-3)
+    losses = [float(m.train_step(x, y, opt, perceptual=perceptual)) for _ in range(3)]
+    main, perc = m._last_loss_parts
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert np.isfinite(float(main)) and np.isfinite(float(perc)) and abs((float(main) + float(perc)) / 2 - losses[-1]) < 1e-4 * abs(losses[-1]) + 1e-5
     assert bool(torch.isfinite(m._flat_param).all())

@@ -21,7 +21,7 @@ def _loss_and_grad(c, e, power):
         loss.backward()
         return float(loss.detach()), ed.grad.cpu()
     finally:
-        cfg.pmsqe_power = True
+        cfg.pmsqe_power = False
 
 
 @pytest.mark.parametrize("power", [False, True])

@@ -65,3 +65,24 @@ def test_stoi_cpp_equals_oracle(n):
 def test_too_short_signal_returns_the_floor_value():
     clean = speechlike(1, 3000)
     assert te.cal_stoi(clean * 0.9, clean)[0] == pytest.approx(1e-5)       # fewer than 30 frames (pystoi warns and returns 1e-5)
+
+
+def test_default_scorers_of_the_validation_loop_score_for_real(tmp_path):
+    """trainer._validate with scorers="default" (what every *_validate and train_interface.run use): a finite STOI per utterance and a
+    written Epoch_N_SCORES file.  (A round-2 bug returned None here because a missing cal_pesq was swallowed; every other test passes fakes.)"""
+    import torch
+    from sefd_amd import trainer
+    sc = trainer._default_scorers()
+    assert sc is not None and sc[1] is te.cal_stoi
+    clean = torch.from_numpy(speechlike(2, 48000, seed=7))
+    noisy = clean + 0.02 * torch.randn(clean.shape, generator=torch.Generator().manual_seed(1))
+    model = torch.nn.Identity()
+
+    def batch(inputs, targets):
+        return (torch.mean((inputs - targets) ** 2),), inputs
+    loss, pesq, stoi = trainer._validate(model, [(noisy, clean)], None, str(tmp_path), 1, "cpu", batch, 1, "default")
+    assert np.isfinite(stoi) and 0.5 < stoi <= 1.0
+    if hasattr(te, "cal_pesq"):
+        assert np.isfinite(pesq) and 1.0 < pesq < 4.7
+    lines = open(tmp_path / "Epoch_1_SCORES").read().strip().splitlines()
+    assert len(lines) == 2 and all(l.startswith("PESQ ") and " | STOI 0." in l for l in lines)
