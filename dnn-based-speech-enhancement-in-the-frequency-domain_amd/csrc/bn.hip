@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce 
   if ((threadIdx.x & 63) == 0) red[512 * V + (threadIdx.x >> 6)] = sa;
   __syncthreads();
   if (threadIdx.x == 0) part[2 * C] = red[512 * V] + red[512 * V + 1] + red[512 * V + 2] + red[512 * V + 3];
+  for (int c = 1 + threadIdx.x; c < C; c += 256) part[2 * C + c] = 0.f;      // row 2 holds per-channel shares of the slope gradient: all in channel 0 here
 }
 
 // grid: x over the chunks of one batch item, y = batch item

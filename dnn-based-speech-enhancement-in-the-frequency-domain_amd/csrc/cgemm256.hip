@@ -57,6 +57,9 @@ __device__ __forceinline__ void wait_allow(int allow) {
 
 // dbg (tuning runs only, SEFD_CG256_DBG): 1 skip the MFMAs, 2 skip the DMAs, 4 skip the fragment reads, 8 skip the epilogue,
 // 32 every A chunk from the zero page (no activation traffic)
+// BNB: the kRunBnBwd epilogue as its own instantiation - the kernel sits at the 256-register cap of two waves per SIMD, and with the
+// extra epilogue state in the one body the allocator spilled inside the K loop of EVERY launch (15x slower)
+template <bool BNB>
 __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const ArenaBases ab, const int dbg) {
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int KT = 64;                                     // K tile of the A operand and of the loop (two 32-deep B tiles)
@@ -104,6 +107,8 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   char* yb = rp(ab, d.y);
   const bool want_stats = d.stats.arena >= 0;
   const bool staged = (d.flags & kRunYAligned) && !(d.flags & kRunAccum);
+  const uint16_t* ybn = BNB ? reinterpret_cast<const uint16_t*>(rp(ab, d.bnb_y)) : nullptr;   // the BatchNorm layer's forward output (bf16)
+  const float bslope = BNB ? *reinterpret_cast<const float*>(rp(ab, d.bnb_slope)) : 0.f;
 
   int gk = 0;                                                // K tiles finished by this workgroup so far (ring positions carry over)
   int nis = 0;                                               // DMA instructions issued so far by this thread
@@ -270,7 +275,100 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     }
     if (grp == 0) wg_barrier();
     gk += nkt;
-    if (t + (int)gridDim.x < total) begin_tile(t + gridDim.x);   // the next tile's first K tiles are in flight during this epilogue
+    // the next tile's first K tiles are in flight during this epilogue - except in the BNB instantiation, where the epilogue needs the
+    // registers of that DMA state (it starts the next tile after the epilogue instead)
+    if (!BNB && t + (int)gridDim.x < total) begin_tile(t + gridDim.x);
+    if constexpr (BNB) {
+      // ---- kRunBnBwd epilogue (bf16, 16-byte aligned rows - what the planner gives this kernel).  Every wave is past the last K tile and
+      // nothing is in flight: the whole LDS is free.  Phase 1: the wave's 128 x 64 tile goes to 16 KB of LDS as bf16 (the accumulators
+      // die here).  Phase 2: lane (chunk column ch = lane & 7, row lane >> 3 + 8k) moves 16-byte row chunks LDS -> global and, beside each,
+      // reads the same chunk of the BatchNorm layer's forward output (coalesced) and accumulates the three backward sums of its 8 columns.
+      if (!(dbg & 8)) {
+        char* wt = smem + wid * 16384;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int col = j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              *reinterpret_cast<uint16_t*>(wt + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = f2bf(acc[i][j][e] + bv[j]);
+            }
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int ch = lane & 7, n0 = ntile * BN + wn0 + ch * 8;
+        const bool cok = n0 < d.N;
+        float pm[8], pis[8], pg[8], pb[8], t0[8], t1[8], t2[8];
+        {
+          const float* mi = reinterpret_cast<const float*>(rp(ab, d.bnb_mi));
+          const float* ga = reinterpret_cast<const float*>(rp(ab, d.bnb_gamma));
+          const float* be = reinterpret_cast<const float*>(rp(ab, d.bnb_beta));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int n = cok ? n0 + e : 0;
+            pm[e] = mi[n]; pis[e] = mi[d.N + n]; pg[e] = ga[n]; pb[e] = be[n];
+            t0[e] = t1[e] = t2[e] = 0.f;
+          }
+        }
+        // two rounds of 8 rows: the 8 forward-output chunks of a round are all in flight before the first is used
+        for (int k8 = 0; k8 < 16; k8 += 8) {
+          uint4 ypre[8];
+          int64_t oo[8];
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const int m = mtile * BM + wm0 + (lane >> 3) + 8 * (k8 + kk);
+            oo[kk] = -1;
+            ypre[kk] = make_uint4(0, 0, 0, 0);
+            if (m < d.M && cok) {
+              const int b = fdiv2(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv2(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+              oo[kk] = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+              ypre[kk] = *reinterpret_cast<const uint4*>(ybn + (int64_t)b * d.bnb_bstride + (int64_t)u * d.bnb_tstride + (int64_t)fo * d.bnb_fstride + d.bnb_off + n0);
+            }
+          }
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+          const int row = (lane >> 3) + 8 * (k8 + kk);
+          const int64_t o = oo[kk];
+          if (o < 0) continue;
+          const uint4 dzv = *reinterpret_cast<const uint4*>(wt + row * 128 + ((ch ^ (row & 7)) << 4));
+          const uint4 yv = ypre[kk];
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = dzv;
+          const uint32_t dw[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dz = bf2f((uint16_t)(dw[e >> 1] >> (16 * (e & 1)))), yy = bf2f((uint16_t)(yw[e >> 1] >> (16 * (e & 1))));
+            const float xh = (yy - pm[e]) * pis[e];
+            const float bn = pg[e] * xh + pb[e];
+            const float dbn = bn > 0.f ? dz : bslope * dz;
+            t0[e] += dbn;
+            t1[e] += dbn * xh;
+            t2[e] += bn > 0.f ? 0.f : bn * dz;
+          }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 32; o >= 8; o >>= 1) { t0[e] += __shfl_xor(t0[e], o); t1[e] += __shfl_xor(t1[e], o); t2[e] += __shfl_xor(t2[e], o); }
+        }
+        const int srow = mtile * 2 + wid / WN_;
+        if (lane < 8 && srow < (d.M + kBM - 1) / kBM) {              // this wave's 128 rows are one 128-row block of partial sums
+          float* part = reinterpret_cast<float*>(rp(ab, d.stats));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            part[((int64_t)srow * 3 + 0) * d.Npad + n0 + e] = t0[e];
+            part[((int64_t)srow * 3 + 1) * d.Npad + n0 + e] = t1[e];
+            part[((int64_t)srow * 3 + 2) * d.Npad + n0 + e] = t2[e];
+          }
+        }
+      }
+      if (t + (int)gridDim.x < total) {
+        wg_barrier();                                          // every wave has left its 16 KB before the next tile's DMAs land in LDS
+        begin_tile(t + gridDim.x);
+      }
+      continue;
+    }
     if (dbg & 8) continue;
     // ---- epilogue, wave local.  Slot gk % 3 is where the next tile's A(0) goes, gk + 1 its A(1); slot gk + 2 held this tile's
     // last K tile (all reads done: every wave is past the barrier above) and is refilled only during the next tile's K tile 0,
@@ -343,6 +441,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
         }
       }
     }
+
   }
 }
 
@@ -352,7 +451,8 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int total = ((d.M + 255) / 256) * (d.Npad / 256);
-  hipLaunchKernelGGL(cgemm256_kernel, dim3(total < ncu ? total : ncu), dim3(512), 0, st, d, ab, dbg);
+  if (d.flags & kRunBnBwd) hipLaunchKernelGGL(cgemm256_kernel<true>, dim3(total < ncu ? total : ncu), dim3(512), 0, st, d, ab, dbg);
+  else hipLaunchKernelGGL(cgemm256_kernel<false>, dim3(total < ncu ? total : ncu), dim3(512), 0, st, d, ab, dbg);
   return true;
 }
 

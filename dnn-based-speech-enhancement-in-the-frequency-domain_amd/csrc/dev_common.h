@@ -108,9 +108,31 @@ __device__ __forceinline__ float drop_scale(uint32_t seed0, uint32_t seed1, int 
   return ((r >> 8) * (1.f / 16777216.f)) < keep ? 1.f / keep : 0.f;
 }
 
+// kRunBnBwd epilogue (sefd_desc.h RunGemm::bnb_*): one stored gradient element dz against the layer's forward output yf
+struct BnbCol { float mean, invstd, gamma, beta; };
+__device__ __forceinline__ BnbCol bnb_col(const RunGemm& d, const ArenaBases& ab, int n) {
+  BnbCol c{0.f, 0.f, 0.f, 0.f};
+  if (n < d.N) {
+    const float* mi = reinterpret_cast<const float*>(rp(ab, d.bnb_mi));
+    c.mean = mi[n]; c.invstd = mi[d.N + n];
+    c.gamma = reinterpret_cast<const float*>(rp(ab, d.bnb_gamma))[n];
+    c.beta = reinterpret_cast<const float*>(rp(ab, d.bnb_beta))[n];
+  }
+  return c;
+}
+__device__ __forceinline__ void bnb_accum(const BnbCol& c, float slope, float dz, float yf, float& s0, float& s1, float& s2) {
+  const float xh = (yf - c.mean) * c.invstd;
+  const float bn = c.gamma * xh + c.beta;
+  const float dbn = bn > 0.f ? dz : slope * dz;
+  s0 += dbn;
+  s1 += dbn * xh;
+  s2 += bn > 0.f ? 0.f : bn * dz;
+}
+
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
+bool launch_rundirect(const RunGemm& d, const ArenaBases& ab, hipStream_t st);       // thin layers, N <= 64 (thin.hip)
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);
 void launch_istft_fft(const IstftFft& d, const ArenaBases& ab, hipStream_t st);

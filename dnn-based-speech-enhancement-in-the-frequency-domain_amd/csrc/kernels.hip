@@ -261,17 +261,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdReduce d,
   if ((threadIdx.x & 63) == 0) red[2048 + (threadIdx.x >> 6)] = sa;
   __syncthreads();
   if (threadIdx.x == 0) part[2 * d.C] = red[2048] + red[2049] + red[2050] + red[2051];
+  for (int c = 1 + threadIdx.x; c < d.C; c += blockDim.x) part[2 * d.C + c] = 0.f;     // row 2 holds per-channel shares (all in channel 0 here)
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const BnBwdApply d, const ArenaBases ab) {
   const int c = blockIdx.x;
   const int C = d.r.C;
   const float* part = reinterpret_cast<const float*>(rp(ab, d.r.part));
+  const int ld = d.r.ldp > 0 ? d.r.ldp : C;
   double s0 = 0.0, s1 = 0.0, sa = 0.0;
   for (int b = threadIdx.x; b < d.r.nblk; b += 256) {
-    s0 += part[(int64_t)b * 3 * C + c];
-    s1 += part[(int64_t)b * 3 * C + C + c];
-    if (c == 0) sa += part[(int64_t)b * 3 * C + 2 * C];
+    s0 += part[((int64_t)b * 3 + 0) * ld + c];
+    s1 += part[((int64_t)b * 3 + 1) * ld + c];
+    if (c == 0)                                      // the slope gradient is one scalar: the first workgroup adds every channel's share
+      for (int cc = 0; cc < C; ++cc) sa += part[((int64_t)b * 3 + 2) * ld + cc];
   }
   __shared__ double r0[256], r1[256], r2[256];
   r0[threadIdx.x] = s0; r1[threadIdx.x] = s1; r2[threadIdx.x] = sa;
@@ -828,7 +831,8 @@ static FinScratch fin_scratch(hipStream_t st) {
   auto it = map.find(st);
   if (it != map.end()) return it->second;
   FinScratch f{};
-  const size_t nsum = (size_t)(kFinMaxC / kFinCG) * kFinMaxChunks * 3 * kFinCG, ntick = kFinMaxC / kFinCG;
+  // + one double per channel group and one ticket for the second level of the slope gradient (bn_bwd_finalize2_kernel)
+  const size_t nsum = (size_t)(kFinMaxC / kFinCG) * kFinMaxChunks * 3 * kFinCG + kFinMaxC / kFinCG, ntick = kFinMaxC / kFinCG + 1;
   if (hipMalloc(reinterpret_cast<void**>(&f.sums), nsum * sizeof(double)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&f.tickets), ntick * sizeof(unsigned)) != hipSuccess ||
       hipMemset(f.tickets, 0, ntick * sizeof(unsigned)) != hipSuccess) {
@@ -853,7 +857,7 @@ __device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, i
       const float* row = part + (int64_t)b * rowstride;
       s0 += row[c];
       s1 += row[ld + c];
-      if (BWD && c == 0) s2 += row[2 * ld];
+      if (BWD) s2 += row[2 * ld + c];
     }
   }
   red[rl][0][cl] = s0; red[rl][1][cl] = s1; red[rl][2][cl] = s2;
@@ -917,8 +921,9 @@ __global__ __launch_bounds__(256) void bn_finalize2_kernel(const BnFinalize d, c
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const BnBwdApply d, const ArenaBases ab, FinScratch fs) {
   __shared__ double tot[3 * kFinCG];
-  const int C = d.r.C;
-  if (!fin_stage1<3, true>(reinterpret_cast<const float*>(rp(ab, d.r.part)), d.r.nblk, C, C, 3 * C, fs, tot)) return;
+  __shared__ unsigned last;
+  const int C = d.r.C, ld = d.r.ldp > 0 ? d.r.ldp : C;
+  if (!fin_stage1<3, true>(reinterpret_cast<const float*>(rp(ab, d.r.part)), d.r.nblk, C, ld, 3 * ld, fs, tot)) return;
   const int c = blockIdx.x * kFinCG + threadIdx.x;
   if (threadIdx.x < kFinCG && c < C) {
     float* t = reinterpret_cast<float*>(rp(ab, d.totals));
@@ -926,7 +931,23 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const BnBwdApply 
     t[C + c] = (float)tot[kFinCG + threadIdx.x];
     reinterpret_cast<float*>(rp(ab, d.dbeta))[c] = (float)tot[threadIdx.x];
     reinterpret_cast<float*>(rp(ab, d.dgamma))[c] = (float)tot[kFinCG + threadIdx.x];
-    if (c == 0) reinterpret_cast<float*>(rp(ab, d.dslope))[0] = (float)tot[2 * kFinCG];
+  }
+  // PReLU slope gradient = sum over ALL channels: this group's share goes to the scratch (write-through), the last group to arrive
+  // (second-level ticket, self-resetting) adds the shares in group order
+  const int ng = gridDim.x;
+  double* gsl = fs.sums + (size_t)(kFinMaxC / kFinCG) * kFinMaxChunks * 3 * kFinCG;
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int cc = 0; cc < kFinCG; ++cc)
+      if (blockIdx.x * kFinCG + cc < C) v += tot[2 * kFinCG + cc];
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(gsl + blockIdx.x), "v"(v) : "memory");
+    last = atomicInc(fs.tickets + kFinMaxC / kFinCG, (unsigned)ng - 1) == (unsigned)ng - 1;
+    if (last) {
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(gsl, 0, (kFinMaxC / kFinCG) * 8, 0x00020000);
+      double s = 0.0;
+      for (int g = 0; g < ng; ++g) s += __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)(g * 8), 0, 17));
+      reinterpret_cast<float*>(rp(ab, d.dslope))[0] = (float)s;
+    }
   }
 }
 

@@ -1110,17 +1110,57 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       m2.dest = dest; m2.dmask = d_decy[n - 1];
       b.push(R, OP_MASK_BWD, 500).mask = m2;
     }
+    // BatchNorm backward reductions in the epilogues of the GEMMs that PRODUCE the upstream gradient (kRunBnBwd): every dgrad GEMM
+    // that writes (a component of) dz of a BatchNorm layer gets the layer's forward output and parameters and a range of partial rows;
+    // BN_BWD_FINALIZE then adds all of them.  The separate reduce pass (two or three tensor reads per layer) is gone.  Not fused: the
+    // last encoder layer (its dz arrives in channel slices from the LSTM input-gradient GEMMs).
+    // Which layers: measured on the default model (profiles/r03_tuning_notes.md) the extra epilogue read costs the wide-tile kernel
+    // (cgemm256, N % 256 == 0, compute-bound) 10-17 us per launch against 38-91 us for the pass it replaces, but it costs the thin
+    // GEMMs (N <= 128: latency-bound tiles that stream at ~2 TB/s) 45-85 us per launch - more than the pass, which streams at 4-5 TB/s.
+    // So by default only the layers whose producers all run on the wide-tile kernel are fused (bf16, C % 256 == 0).
+    // SEFD_BN_FUSE=0: none; SEFD_BN_FUSE=2: every layer (the per-op tests run the epilogue of all three GEMM kernels that way).
+    const int bn_fuse_mode = getenv("SEFD_BN_FUSE") ? atoi(getenv("SEFD_BN_FUSE")) : 1;
+    const bool bn_fuse = bn_fuse_mode != 0;
+    auto bn_fuse_layer = [&](int C, int64_t Rr) { return bn_fuse_mode == 2 || (adt == DT_BF16 && C % 256 == 0 && Rr >= 8192); };
+    struct BnbAcc { Ptr part; int rows = 0, cap = 0, ldp = 0; bool on = false; Ptr y, mi; std::string pp; };
+    std::vector<BnbAcc> bnb_dec(n), bnb_enc(n);
+    auto bnb_init = [&](BnbAcc& a, const std::string& nm, Ptr y, Ptr mi, const std::string& pp, int C, int64_t Rr) {
+      a.on = true; a.y = y; a.mi = mi; a.pp = pp;
+      a.ldp = (int)rup(C, bn_of(C));
+      a.cap = (int)(2 * ((Rr + kBM - 1) / kBM) + 16);
+      a.part = b.ws(nm + ".bnpart", (int64_t)a.cap * 3 * a.ldp, DT_F32);
+    };
+    if (bn_fuse) {
+      for (int d = 0; d + 1 < n; ++d) if (bn_fuse_layer(dec[d].C, dec[d].R)) bnb_init(bnb_dec[d], "dec" + std::to_string(d), decy[d], dec_mi[d], "decoder." + std::to_string(d), dec[d].C, dec[d].R);
+      for (int i = 0; i + 1 < n; ++i) if (bn_fuse_layer(enc[i].C, enc[i].R)) bnb_init(bnb_enc[i], "enc" + std::to_string(i), ency[i], enc_mi[i], "encoder." + std::to_string(i), enc[i].C, enc[i].R);
+    }
+    // the GEMM `g` writes dz rows (b, u, fo) of that layer; (bs, ts, fs, off) address the same rows of the layer's forward output y
+    auto bnb_attach = [&](RunGemm& g, BnbAcc& a, int64_t bs, int ts, int fs, int off) {
+      if (!a.on) return;
+      const int rows = (g.M + kBM - 1) / kBM;
+      if (a.rows + rows > a.cap || g.Npad != a.ldp) { P->error = "BatchNorm backward partial rows: capacity / pitch"; return; }
+      g.flags |= kRunBnBwd;
+      g.bnb_y = a.y; g.bnb_mi = a.mi;
+      g.bnb_gamma = b.pptr(a.pp + ".1.weight"); g.bnb_beta = b.pptr(a.pp + ".1.bias"); g.bnb_slope = b.pptr(a.pp + ".2.weight");
+      g.bnb_bstride = bs; g.bnb_tstride = ts; g.bnb_fstride = fs; g.bnb_off = off;
+      g.stats = b.mk(A_WS, a.part.off + (int64_t)a.rows * 3 * a.ldp * 4);
+      a.rows += rows;
+    };
     auto bn_bwd = [&](int tag, Ptr y, Ptr dz0, Ptr dz1, Ptr mi, const std::string& pp, int C, int64_t Rr, int64_t rpb, int skip, Ptr dy,
-                      const std::string& nm) {
+                      const std::string& nm, const BnbAcc* fused) {
       int64_t rpbk = std::max<int64_t>(64, (Rr + 2047) / 2048);
       const int nblk = (int)((Rr + rpbk - 1) / rpbk);
       BnBwdReduce r;
       std::memset(&r, 0, sizeof(r));
       r.y = y; r.dz0 = dz0; r.dz1 = dz1; r.mean_invstd = mi;
       r.gamma = b.pptr(pp + ".1.weight"); r.beta = b.pptr(pp + ".1.bias"); r.slope = b.pptr(pp + ".2.weight");
-      r.part = b.ws(nm + ".bnpart", (int64_t)nblk * 3 * C, DT_F32);
       r.R = Rr; r.C = C; r.dt = adt; r.nblk = nblk; r.rows_per_blk = (int)rpbk; r.rpb = rpb; r.skip = skip;
-      b.push(R, OP_BN_BWD_REDUCE, tag).bnr = r;
+      if (fused && fused->on) {                   // the producers' epilogues wrote the partial rows
+        r.part = fused->part; r.nblk = fused->rows; r.ldp = fused->ldp;
+      } else {
+        r.part = b.ws(nm + ".bnpart", (int64_t)nblk * 3 * C, DT_F32);
+        b.push(R, OP_BN_BWD_REDUCE, tag).bnr = r;
+      }
       BnBwdApply a;
       std::memset(&a, 0, sizeof(a));
       a.r = r; a.totals = b.ws(nm + ".bntot", 3 * C, DT_F32); a.dy = dy;
@@ -1140,7 +1180,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const std::string nm = "dec" + std::to_string(d);
       const std::string pp = "decoder." + std::to_string(d);
       if (!last)
-        bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm);
+        bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm, &bnb_dec[d]);
       // weight gradients of both sub-pixel phases; each phase also contributes its rows to the bias gradient (ones run)
       b.cur_lane = 1;                           // weight gradients of the decoder: nothing downstream needs them before UNPACK
       for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
@@ -1175,6 +1215,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
           g.y = d_skip[idx - 1];
         }
         g.y_bstride = (int64_t)T * Fi * Cs; g.y_tstride = Fi * Cs; g.y_fstride = Cs; g.y_off = 0;
+        // dz of the previous decoder layer (its y keeps the frame that `[..., 1:]` drops: rows start one frame in) / of encoder layer idx-1
+        if (s == 0 && d > 0) bnb_attach(g, bnb_dec[d - 1], (int64_t)(T + 1) * Fi * Cs, Fi * Cs, Cs, Fi * Cs);
+        else if (s == 1) bnb_attach(g, bnb_enc[idx - 1], (int64_t)T * Fi * Cs, Fi * Cs, Cs, 0);
         b.push(R, OP_RUNGEMM, 400 + d).g = g;
       }
     }
@@ -1411,7 +1454,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
       const std::string nm = "enc" + std::to_string(i);
       const std::string pp = "encoder." + std::to_string(i);
-      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm);
+      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm, &bnb_enc[i]);
       b.cur_lane = lane_all ? 1 : 0;             // encoder weight gradients next to the dgrad chain
       b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
       b.cur_lane = 0;
@@ -1436,6 +1479,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         };
         b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(par), 100 + i);
         g.y = d_encz[i - 1]; g.y_bstride = (int64_t)T * Fi * Ci; g.y_tstride = Fi * Ci; g.y_fstride = 2 * Ci; g.y_off = par * Ci;
+        bnb_attach(g, bnb_enc[i - 1], (int64_t)T * Fi * Ci, Fi * Ci, 2 * Ci, par * Ci);      // rows of encoder layer i-1's output, this phase's bins
         b.push(R, OP_RUNGEMM, 100 + i).g = g;
       }
     }

@@ -92,7 +92,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // GLDS = true: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass,
 // which otherwise costs more LDS cycles than the fragment reads); padding chunks are fetched from a zero page, and the
 // XOR swizzle is applied on the SOURCE chunk index because the DMA destination is lane-linear (wave base + lane*16).
-template <typename TA, int BN, bool GLDS, int S = 2, int BM = kBM, int NW = 4, bool ILV = false>
+// BNB: the kRunBnBwd epilogue as its own instantiation (its state costs ~25 VGPRs, which the plain kernel needs for occupancy)
+template <typename TA, int BN, bool GLDS, int S = 2, int BM = kBM, int NW = 4, bool ILV = false, bool BNB = false>
 __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int VEC = 16 / sizeof(TA);
   constexpr int BK = 8 * VEC;
@@ -342,21 +343,43 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
 
   // ---- epilogue: row address table in LDS, bias, store, BatchNorm partial statistics
   int64_t* rowoff = reinterpret_cast<int64_t*>(smem);              // [BM]
-  float* stat = reinterpret_cast<float*>(smem + BM * 8);           // [WM_][BN][2]
-  uint16_t* otile = reinterpret_cast<uint16_t*>(smem + BM * 8 + WM_ * BN * 8);   // [BM][OS] bf16 staging tile (kRunYAligned)
+  int64_t* rowoffb = rowoff + BM;                                  // [BM] row offsets into the BatchNorm layer's forward output (kRunBnBwd)
+  float* stat = reinterpret_cast<float*>(smem + BM * 16);          // [NW][BN][3]
+  uint16_t* otile = reinterpret_cast<uint16_t*>(smem + BM * 16 + NW * BN * 12);    // [BM][OS] bf16 staging tile (kRunYAligned)
   constexpr int OS = BN + 8;                                       // row stride in elements: 16-byte aligned rows, rotating banks
-  constexpr bool kCanStage = BM * 8 + WM_ * BN * 8 + BM * OS * 2 <= S * TILE_BYTES;
+  constexpr bool kCanStage = BM * 16 + NW * BN * 12 + BM * OS * 2 <= S * TILE_BYTES;
   const bool staged = kCanStage && (d.flags & kRunYAligned) && !(d.flags & kRunAccum);
+  constexpr bool bnb = BNB;
+  // kRunBnBwd on the staged path: the sums are formed in the CHUNK loop below (a thread meets the same 8 columns on every row it stores:
+  // the layer's forward output is read as coalesced 16-byte chunks beside the stores, not as 2-byte gathers in the accumulator layout)
+  const bool bnb_chunk = bnb && staged && BM == kBM;
   if (tid < BM) {
     const int m = mtile * BM + tid;
-    int64_t o = -1;
+    int64_t o = -1, ob = 0;
     if (m < d.M) {
       const int b = fdiv(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
       o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+      ob = (int64_t)b * d.bnb_bstride + (int64_t)u * d.bnb_tstride + (int64_t)fo * d.bnb_fstride + d.bnb_off;
     }
     rowoff[tid] = o;
+    rowoffb[tid] = ob;
   }
   __syncthreads();
+  const char* ybn = bnb ? rp(ab, d.bnb_y) : nullptr;
+  const float bslope = bnb ? *reinterpret_cast<const float*>(rp(ab, d.bnb_slope)) : 0.f;
+  // chunk loop geometry: thread -> chunk column cc (fixed), rows tid / CPR + k * (threads / CPR), k < KCH
+  constexpr int CPR = BN / 8;                                      // 16-byte chunks per tile row
+  constexpr int KCH = BM * CPR / (NW * 64);
+  uint4 ypre[BNB ? KCH : 1];                                                 // the forward-output chunks of this thread's rows, in flight while the tile is staged
+  if (bnb_chunk) {
+    const int cc = tid % CPR, n0 = ntile * BN + cc * 8;
+    const uint16_t* yf = reinterpret_cast<const uint16_t*>(ybn);
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+      const int row = tid / CPR + k * (NW * 64 / CPR);
+      ypre[k] = (rowoff[row] >= 0 && n0 < d.N) ? *reinterpret_cast<const uint4*>(yf + rowoffb[row] + n0) : make_uint4(0, 0, 0, 0);
+    }
+  }
   const float* bias = d.bias.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   char* yb = rp(ab, d.y);
   const bool want_stats = d.stats.arena >= 0;
@@ -365,7 +388,9 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
     const int nl = wn0 + j * 32 + (lane & 31);
     const int n = ntile * BN + nl;
     const float bv = (bias && n < d.N) ? bias[n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    BnbCol bc{0.f, 0.f, 0.f, 0.f};
+    if (bnb) bc = bnb_col(d, ab, n);
     if (staged) {
       // bf16 output through LDS: the 32x32 accumulator layout gives every lane ONE column, i.e. 2-byte global stores in
       // 64-byte pieces; staged, the tile leaves as whole 16-byte chunks of contiguous rows (8x fewer store instructions)
@@ -376,8 +401,12 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
           const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
           float v = acc[i][j][e] + bv;
           if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
-          otile[row * OS + nl] = f2bf(v);
-          if (mtile * BM + row < d.M && n < d.N) { s1 += v; s2 += v * v; }
+          const uint16_t hv = f2bf(v);
+          otile[row * OS + nl] = hv;
+          if (!bnb_chunk && mtile * BM + row < d.M && n < d.N) {
+            if (bnb) bnb_accum(bc, bslope, bf2f(hv), ld_elem(ybn, d.ydt, rowoffb[row] + n), s1, s2, s3);
+            else { s1 += v; s2 += v * v; }
+          }
         }
       }
     } else {
@@ -391,32 +420,84 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
           if (o >= 0 && n < d.N) {
             if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yb)[o + n];
             if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
-            if (d.ydt == DT_BF16) reinterpret_cast<uint16_t*>(yb)[o + n] = f2bf(v);
+            if (d.ydt == DT_BF16) { const uint16_t hv = f2bf(v); reinterpret_cast<uint16_t*>(yb)[o + n] = hv; if (bnb) v = bf2f(hv); }
             else reinterpret_cast<float*>(yb)[o + n] = v;
-            s1 += v;
-            s2 += v * v;
+            if (bnb) bnb_accum(bc, bslope, v, ld_elem(ybn, d.ydt, rowoffb[row] + n), s1, s2, s3);
+            else { s1 += v; s2 += v * v; }
           }
         }
       }
     }
-    if (want_stats) {
+    if (want_stats && !bnb_chunk) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
+      s3 += __shfl_xor(s3, 32);
       if (lane < 32) {
-        stat[((wid / WN_) * BN + nl) * 2 + 0] = s1;
-        stat[((wid / WN_) * BN + nl) * 2 + 1] = s2;
+        stat[((wid / WN_) * BN + nl) * 3 + 0] = s1;
+        stat[((wid / WN_) * BN + nl) * 3 + 1] = s2;
+        stat[((wid / WN_) * BN + nl) * 3 + 2] = s3;
       }
     }
   }
   if (staged) {
     __syncthreads();
-    constexpr int CPR = BN / 8;                                    // 16-byte chunks per tile row
-    for (int q = tid; q < BM * CPR; q += NW * 64) {
-      const int row = q / CPR, cc = q - row * CPR;
-      const int64_t o = rowoff[row];
-      const int n0 = ntile * BN + cc * 8;
-      if (o >= 0 && n0 < d.N)                                      // N % 8 == 0 here: a chunk is all valid or all padding
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
+    if (!bnb_chunk) {
+      for (int q = tid; q < BM * CPR; q += NW * 64) {
+        const int row = q / CPR, cc = q - row * CPR;
+        const int64_t o = rowoff[row];
+        const int n0 = ntile * BN + cc * 8;
+        if (o >= 0 && n0 < d.N)                                    // N % 8 == 0 here: a chunk is all valid or all padding
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
+      }
+    } else {
+      static_assert((NW * 64) % CPR == 0, "a thread keeps its chunk column");
+      const int cc = tid % CPR, n0 = ntile * BN + cc * 8;
+      const bool cok = n0 < d.N;
+      float pm[8], pis[8], pg[8], pb[8], t0[8], t1[8], t2[8];
+      {
+        const float* mi = reinterpret_cast<const float*>(rp(ab, d.bnb_mi));
+        const float* ga = reinterpret_cast<const float*>(rp(ab, d.bnb_gamma));
+        const float* be = reinterpret_cast<const float*>(rp(ab, d.bnb_beta));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = cok ? n0 + e : 0;
+          pm[e] = mi[n]; pis[e] = mi[d.N + n]; pg[e] = ga[n]; pb[e] = be[n];
+          t0[e] = t1[e] = t2[e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KCH; ++k) {
+        const int row = tid / CPR + k * (NW * 64 / CPR);
+        const int64_t o = rowoff[row];
+        if (o < 0 || !cok) continue;
+        const uint4 dzv = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
+        const uint4 yv = ypre[k];
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = dzv;
+        const uint32_t dw[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dz = bf2f((uint16_t)(dw[e >> 1] >> (16 * (e & 1)))), yy = bf2f((uint16_t)(yw[e >> 1] >> (16 * (e & 1))));
+          const float xh = (yy - pm[e]) * pis[e];
+          const float bn = pg[e] * xh + pb[e];
+          const float dbn = bn > 0.f ? dz : bslope * dz;
+          t0[e] += dbn;
+          t1[e] += dbn * xh;
+          t2[e] += bn > 0.f ? 0.f : bn * dz;
+        }
+      }
+      // lanes of a wave with the same chunk column, then the 4 waves through `stat`
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 32; o >= CPR; o >>= 1) { t0[e] += __shfl_xor(t0[e], o); t1[e] += __shfl_xor(t1[e], o); t2[e] += __shfl_xor(t2[e], o); }
+      }
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float* sp = stat + ((tid >> 6) * BN + cc * 8 + e) * 3;
+          sp[0] = t0[e]; sp[1] = t1[e]; sp[2] = t2[e];
+        }
+      }
     }
   }
   if (want_stats) {
@@ -426,18 +507,26 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
       constexpr int HALVES = BM / kBM, WMH = WM_ / HALVES;
       float* part = reinterpret_cast<float*>(rp(ab, d.stats));
       const int nrows = (d.M + kBM - 1) / kBM;
+      const int nst = bnb ? 3 : 2;                                   // partial rows per block: (sum, sum of squares) or the three backward sums
 #pragma unroll
       for (int h = 0; h < HALVES; ++h) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (bnb_chunk) {                                               // every wave holds a share of all columns
 #pragma unroll
-        for (int wmi = h * WMH; wmi < (h + 1) * WMH; ++wmi) {
-          s1 += stat[(wmi * BN + tid) * 2 + 0];
-          s2 += stat[(wmi * BN + tid) * 2 + 1];
+          for (int wv = 0; wv < NW; ++wv) { s1 += stat[(wv * BN + tid) * 3 + 0]; s2 += stat[(wv * BN + tid) * 3 + 1]; s3 += stat[(wv * BN + tid) * 3 + 2]; }
+        } else {
+#pragma unroll
+          for (int wmi = h * WMH; wmi < (h + 1) * WMH; ++wmi) {
+            s1 += stat[(wmi * BN + tid) * 3 + 0];
+            s2 += stat[(wmi * BN + tid) * 3 + 1];
+            s3 += stat[(wmi * BN + tid) * 3 + 2];
+          }
         }
         const int srow = mtile * HALVES + h;
         if (srow < nrows) {
-          part[((int64_t)srow * 2 + 0) * d.Npad + ntile * BN + tid] = s1;
-          part[((int64_t)srow * 2 + 1) * d.Npad + ntile * BN + tid] = s2;
+          part[((int64_t)srow * nst + 0) * d.Npad + ntile * BN + tid] = s1;
+          part[((int64_t)srow * nst + 1) * d.Npad + ntile * BN + tid] = s2;
+          if (bnb) part[((int64_t)srow * nst + 2) * d.Npad + ntile * BN + tid] = s3;
         }
       }
     }
@@ -996,6 +1085,7 @@ static int env_stages(const char* name, int dflt) {
 template <typename TA, int BN>
 static void launch_rungemm_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st, int grid) {
   static const int stages = env_stages("SEFD_RG_STAGES", 2);
+  if (d.flags & kRunBnBwd) { hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2, kBM, 4, false, true>), dim3(grid), dim3(256), 0, st, d, ab); return; }
   if (stages == 2) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2>), dim3(grid), dim3(256), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3>), dim3(grid), dim3(256), 0, st, d, ab);
   else hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 4>), dim3(grid), dim3(256), 0, st, d, ab);
@@ -1012,6 +1102,12 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
     else launch_rungemm_dma<TA, 32>(d, ab, st, grid);
     return;
   }
+  if (d.flags & kRunBnBwd) {
+    if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128, false, 2, kBM, 4, false, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64, false, 2, kBM, 4, false, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    else hipLaunchKernelGGL((rungemm_kernel<TA, 32, false, 2, kBM, 4, false, true>), dim3(grid), dim3(256), 0, st, d, ab);
+    return;
+  }
   if (bn == 128) hipLaunchKernelGGL((rungemm_kernel<TA, 128, false>), dim3(grid), dim3(256), 0, st, d, ab);
   else if (bn == 64) hipLaunchKernelGGL((rungemm_kernel<TA, 64, false>), dim3(grid), dim3(256), 0, st, d, ab);
   else hipLaunchKernelGGL((rungemm_kernel<TA, 32, false>), dim3(grid), dim3(256), 0, st, d, ab);
@@ -1019,6 +1115,7 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (launch_cgemm256(d, ab, st)) return;                  // wide-tile kernel for the N >= 128 bf16 layers (cgemm256.hip)
+  if (launch_rundirect(d, ab, st)) return;                 // direct-operand kernel for the thin bf16 layers (thin.hip)
   if (d.xdt == DT_BF16) launch_rungemm_t<bf16_t>(d, ab, st);
   else launch_rungemm_t<float>(d, ab, st);
 }

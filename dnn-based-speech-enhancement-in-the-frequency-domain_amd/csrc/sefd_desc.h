@@ -67,6 +67,16 @@ struct RunGemm {
   // (fastdiv_make): for 0 <= x < 2^31, x / d == umulhi(x, m) >> s ; m == 0 encodes d == 1.  The kernels decode 4-8 row
   // indices per thread in their prologue; with 15 000-workgroup launches on the thin layers that was a visible cost.
   uint32_t div_tf_m, div_tf_s, div_fo_m, div_fo_s;
+  // kRunBnBwd: this GEMM produces (a component of) the upstream gradient dz of a BatchNorm2d + PReLU layer, and its epilogue accumulates
+  // that component's share of the layer's backward reductions - the separate pass over y and dz (BN_BWD_REDUCE) disappears.  For every
+  // stored element dz[m][n] (the ROUNDED value the later passes read) with the layer's forward output yf = bnb_y[row(m) + n]:
+  //   xh = (yf - mean[n]) * invstd[n];  bn = gamma[n] * xh + beta[n];  dbn = bn > 0 ? dz : slope * dz
+  //   part[blk][0][n] += dbn;  part[blk][1][n] += dbn * xh;  part[blk][2][n] += bn > 0 ? 0 : bn * dz      (blk = m / kBM, `stats` = part)
+  // row(m) = b * bnb_bstride + u * bnb_tstride + fo * bnb_fstride + bnb_off  (the decoder's y keeps one more frame than dz).
+  // The sums are linear in dz: when dz = dz0 + dz1 (skip connection) each producer adds its own share.
+  Ptr bnb_y, bnb_mi, bnb_gamma, bnb_beta, bnb_slope;
+  int64_t bnb_bstride;
+  int32_t bnb_tstride, bnb_fstride, bnb_off, bnb_pad_;
 };
 static inline void fastdiv_make(uint32_t d, uint32_t* m, uint32_t* s) {
   if (d <= 1) { *m = 0; *s = 0; return; }
@@ -81,6 +91,7 @@ constexpr int kRunRelu = 4;      // y = max(result, 0)
 constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chunks: the tile is staged through LDS and stored wide
 constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw / 32][Npad][32]: the B operand of one 32-deep K tile is ONE
                                  // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
+constexpr int kRunBnBwd = 64;    // epilogue accumulates BatchNorm-backward partial sums against the layer's forward output (fields bnb_*); `stats` rows are [3][Npad]
 constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`
 static inline int64_t w_index(int flags, int ldw, int Npad, int n, int k) {
@@ -127,16 +138,17 @@ struct BnApply {               // z = prelu(gamma*(y-mean)*invstd + beta)
   int64_t R;
   int32_t C, dt;               // dt: DType of y and z
 };
-struct BnBwdReduce {           // per-channel partial sums of (dbn, dbn*xhat) and the PReLU slope gradient
+struct BnBwdReduce {           // per-channel partial sums of (dbn, dbn*xhat) and of the PReLU slope gradient (row 2: per channel, summed at finalize)
   Ptr y, dz0, dz1;             // dz1 optional second upstream gradient (skip connection): dz = dz0 + dz1
   Ptr mean_invstd, gamma, beta, slope;
-  Ptr part;                    // fp32 [nblk][3][C]  (sum dbn, sum dbn*xhat, [c==0]: sum slope-grad)
+  Ptr part;                    // fp32 [nblk][3][C]  (sum dbn, sum dbn*xhat, slope-gradient share of channel c)
   int64_t R;
   int32_t C, dt, nblk, rows_per_blk;
   // y has `rpb` rows per batch element of which the first `skip` (the decoder frame dropped by `[..., 1:]`) receive no
   // upstream gradient; dz0 holds only the remaining rows:  y row r -> b = r / rpb, q = r % rpb; dz row = b*(rpb-skip) + q-skip.
   int64_t rpb;
-  int32_t skip, pad_;
+  int32_t skip;
+  int32_t ldp;                 // row pitch of `part` in floats (0: C): partial rows written by GEMM epilogues (kRunBnBwd) are Npad wide
 };
 struct BnBwdApply {            // FINALIZE: partials -> totals [3][C] + parameter gradients ; APPLY: dy = gamma*invstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))
   BnBwdReduce r;

@@ -44,8 +44,13 @@ void rungemm(const RunGemm& d, const AB& ab) {
   char* y = rp(ab, d.y);
   const int TF = d.Tout * d.Fo;
   const int nblk = (d.M + kBM - 1) / kBM;
-  std::vector<double> s1, s2;
-  if (d.stats.arena >= 0) { s1.assign((size_t)nblk * d.Npad, 0.0); s2.assign((size_t)nblk * d.Npad, 0.0); }
+  std::vector<double> s1, s2, s3;
+  const bool bnb = (d.flags & kRunBnBwd) != 0;
+  if (d.stats.arena >= 0) { s1.assign((size_t)nblk * d.Npad, 0.0); s2.assign((size_t)nblk * d.Npad, 0.0); s3.assign((size_t)nblk * d.Npad, 0.0); }
+  const float* bmi = bnb ? (const float*)rp(ab, d.bnb_mi) : nullptr;
+  const float* bgamma = bnb ? (const float*)rp(ab, d.bnb_gamma) : nullptr;
+  const float* bbeta = bnb ? (const float*)rp(ab, d.bnb_beta) : nullptr;
+  const float bslope = bnb ? *(const float*)rp(ab, d.bnb_slope) : 0.f;
   std::vector<double> arow(d.ldw);
   for (int m = 0; m < d.M; ++m) {
     const int b = m / TF, rem = m % TF, u = rem / d.Fo, fo = rem % d.Fo;
@@ -60,15 +65,26 @@ void rungemm(const RunGemm& d, const AB& ab) {
       if (d.flags & kRunAccum) v += ((const float*)y)[o + n];
       if (d.flags & kRunRelu) v = v > 0.f ? v : 0.f;
       st(y, d.ydt, o + n, v);
+      if (d.stats.arena >= 0 && bnb) {             // BatchNorm-backward sums of the STORED gradient against the layer's forward output
+        const float dz = ld(y, d.ydt, o + n);
+        const int64_t ob = (int64_t)b * d.bnb_bstride + (int64_t)u * d.bnb_tstride + (int64_t)fo * d.bnb_fstride + d.bnb_off;
+        const float xh = (ld(rp(ab, d.bnb_y), d.ydt, ob + n) - bmi[n]) * bmi[d.N + n];
+        const float bn = bgamma[n] * xh + bbeta[n];
+        const double dbn = bn > 0.f ? dz : bslope * dz;
+        const size_t q = (size_t)(m / kBM) * d.Npad + n;
+        s1[q] += dbn; s2[q] += dbn * xh; if (!(bn > 0.f)) s3[q] += (double)bn * dz;
+      } else
       if (d.stats.arena >= 0) { s1[(size_t)(m / kBM) * d.Npad + n] += v; s2[(size_t)(m / kBM) * d.Npad + n] += (double)v * v; }
     }
   }
   if (d.stats.arena >= 0) {
     float* part = (float*)rp(ab, d.stats);
+    const int nst = bnb ? 3 : 2;
     for (int blk = 0; blk < nblk; ++blk)
       for (int n = 0; n < d.Npad; ++n) {
-        part[((int64_t)blk * 2 + 0) * d.Npad + n] = (float)s1[(size_t)blk * d.Npad + n];
-        part[((int64_t)blk * 2 + 1) * d.Npad + n] = (float)s2[(size_t)blk * d.Npad + n];
+        part[((int64_t)blk * nst + 0) * d.Npad + n] = (float)s1[(size_t)blk * d.Npad + n];
+        part[((int64_t)blk * nst + 1) * d.Npad + n] = (float)s2[(size_t)blk * d.Npad + n];
+        if (bnb) part[((int64_t)blk * nst + 2) * d.Npad + n] = (float)s3[(size_t)blk * d.Npad + n];
       }
   }
 }
@@ -617,6 +633,7 @@ void run_op(const Op& op, const AB& ab) {
           }
         for (int c = 0; c < d.C; ++c) { part[(int64_t)blk * 3 * d.C + c] = (float)s0[c]; part[(int64_t)blk * 3 * d.C + d.C + c] = (float)s1[c]; }
         part[(int64_t)blk * 3 * d.C + 2 * d.C] = (float)sa;
+        for (int c = 1; c < d.C; ++c) part[(int64_t)blk * 3 * d.C + 2 * d.C + c] = 0.f;
       }
       break;
     }
@@ -625,15 +642,15 @@ void run_op(const Op& op, const AB& ab) {
       const int C = d.r.C;
       const float* part = (const float*)rp(ab, d.r.part);
       float* tot = (float*)rp(ab, d.totals);
+      const int ldp = d.r.ldp > 0 ? d.r.ldp : C;
       double sa = 0;
       for (int c = 0; c < C; ++c) {
         double s0 = 0, s1 = 0;
-        for (int b = 0; b < d.r.nblk; ++b) { s0 += part[(int64_t)b * 3 * C + c]; s1 += part[(int64_t)b * 3 * C + C + c]; }
+        for (int b = 0; b < d.r.nblk; ++b) { s0 += part[((int64_t)b * 3 + 0) * ldp + c]; s1 += part[((int64_t)b * 3 + 1) * ldp + c]; sa += part[((int64_t)b * 3 + 2) * ldp + c]; }
         tot[c] = (float)s0; tot[C + c] = (float)s1;
         ((float*)rp(ab, d.dbeta))[c] = (float)s0;
         ((float*)rp(ab, d.dgamma))[c] = (float)s1;
       }
-      for (int b = 0; b < d.r.nblk; ++b) sa += part[(int64_t)b * 3 * C + 2 * C];
       ((float*)rp(ab, d.dslope))[0] = (float)sa;
       break;
     }

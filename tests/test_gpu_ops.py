@@ -35,6 +35,8 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "fp32"),
                                                         ("DCCRN", 3, 4000, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),
                                                         ("DCCRN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
+                                                        ("DCCRN", 3, 4001, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # L = 4001 marks the cases that send every N <= 64 conv GEMM through the direct-operand kernel (thin.hip)
+                                                        ("DCCRN", 1, 2403, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("DCCRN", 1, 2401, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L odd: marks the case that lowers SEFD_CG256_MINM -> wide-tile kernel on every N % 256 == 0 layer
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM (H = 256): cluster kernels, one partial row block
                                                         ("DCCRN", 18, 7000, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),    # the same, two row blocks, T = 71: chunked forward
@@ -64,6 +66,14 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     else:
         os.environ.pop("SEFD_CG256_MINM", None)
         os.environ.pop("SEFD_WG256_MINM", None)
+    os.environ.pop("SEFD_DIRECT_MINM", None)
+    os.environ.pop("SEFD_BN_FUSE", None)
+    if L in (4001, 2403):                  # the direct-operand kernel takes GEMMs with M >= 65536 by default
+        L -= 1 if L == 4001 else 3
+        os.environ["SEFD_DIRECT_MINM"] = "0"
+        os.environ["SEFD_BN_FUSE"] = "2"   # ... and every BatchNorm layer's backward sums come from its producers' epilogues (thin + tiled kernels)
+    if L == 2401 or (model == "DCCRN" and dtype == "fp32" and L == 2400):
+        os.environ["SEFD_BN_FUSE"] = "2"   # the same through the wide-tile kernel / in fp32
     os.environ.pop("SEFD_LSTM_MT", None)
     if model == "FullSubNet" and L == 10:
         os.environ["SEFD_LSTM_MT"] = "3"
@@ -82,6 +92,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)))
     if model != "FullSubNet":
         plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
+    os.environ.pop("SEFD_BN_FUSE", None)
     os.environ.pop("SEFD_CG256_MINM", None)        # the plan is built: later tests get the default thresholds again
     os.environ.pop("SEFD_WG256_MINM", None)
     os.environ.pop("SEFD_LSTM_ROWS_MIN", None)
@@ -164,6 +175,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
             if not (worst < 1.0) or stray:
                 bad.append(lines[-1])
     os.environ.pop("SEFD_LSTM_MT", None)
+    os.environ.pop("SEFD_DIRECT_MINM", None)
     with open(_report_path(f"ops_report_{model}_B{B}_{mode.replace('/', '-')}_{dtype}_{L}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])

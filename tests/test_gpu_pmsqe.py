@@ -47,7 +47,7 @@ def test_pit_picks_the_rotation():
     l1, g1 = _loss_and_grad(c, rot, True)
     assert abs(l0 - l1) <= 1e-5 * abs(l0)
     eo = rot.clone().double().requires_grad_()
-    pmsqe.pmsqe_loss(c, eo).backward()
+    pmsqe.pmsqe_loss(c, eo, True).backward()
     assert float((g1.double() - eo.grad).norm() / eo.grad.norm()) < TOL_GRAD
 
 
