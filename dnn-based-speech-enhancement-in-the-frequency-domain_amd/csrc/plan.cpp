@@ -11,6 +11,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <array>
 #include <cassert>
 #include <cmath>
 #include <cstring>
@@ -945,6 +946,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   std::vector<Ptr> decy(n), decz(n), dec_mi(n);
   struct DecSrc { Ptr p; int64_t bstride; int tstride, base, C; };
   DecSrc dprev{decin, (int64_t)T * D * Cl, D * Cl, 0, Cl};
+  std::vector<std::array<DecSrc, 2>> dec_src(n);
   for (int d = 0; d < n; ++d) {
     const int idx = n - d;
     const int C0 = ch[idx], C1 = cfg.skip ? ch[idx] : 0, Co = ch[idx - 1];
@@ -991,6 +993,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       g.xdt = adt; g.ydt = adt;
       const int nsrc = cfg.skip ? 2 : 1;
       DecSrc src[2] = {dprev, DecSrc{encz[idx - 1], (int64_t)T * Fi * C1, Fi * C1, 0, C1}};
+      dec_src[d] = {src[0], src[1]};
       g.nseg = 0;
       const int ntap = par == 0 ? 3 : 2;
       for (int s = 0; s < nsrc; ++s) {
@@ -1181,9 +1184,26 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const std::string pp = "decoder." + std::to_string(d);
       if (!last)
         bn_bwd(400 + d, decy[d], d_decz[d], b.none(), dec_mi[d], pp, Co, dec[d].R, (int64_t)(T + 1) * Fo, Fo, d_decy[d], nm, &bnb_dec[d]);
-      // weight gradients of both sub-pixel phases; each phase also contributes its rows to the bias gradient (ones run)
+      // Weight gradients.  Forward form (SEFD_WG_SWAP=0): one WGRAD per sub-pixel phase, A = the forward runs (3 or 2 taps x C channels of
+      // both sources, two frames: every input element is streamed through LDS ~5 times per phase pair), dense operand = dy.
+      // Swapped form (default): the SAME tensor, contracted over INPUT pixels - dense operand = the source activation x_s (each element
+      // read once), A = the runs of the input-gradient GEMM over dy (5 taps x Co channels, two frames): the tap expansion moves to the
+      // operand with the FEWER channels (Co <= C_in / 2 in every decoder layer).  Mask layer: 3.0 GB -> 1.3 GB through LDS-DMA.
+      // The bias gradient needs its own pass over dy then (ones run only) - planned for the mask layer; a conv bias in front of
+      // BatchNorm has an identically zero gradient (the sum over all rows of the BatchNorm input gradient vanishes), which the reference
+      // computes as rounding noise and this plan leaves at exactly 0.
+      const bool wg_swap = !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
       b.cur_lane = 1;                           // weight gradients of the decoder: nothing downstream needs them before UNPACK
-      for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
+      if (!wg_swap) for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
+      else if (last) {
+        RunGemm fb = Builder::gemm0();           // all output rows (both phases), no activation run: wgrad() appends the ones run
+        fb.xdt = adt; fb.ydt = adt;
+        fb.M = B * (T + 1) * Fo; fb.Tout = T + 1; fb.Fo = Fo;
+        fb.nseg = 0; fb.N = Co;
+        fb.y_bstride = (int64_t)(T + 1) * Fo * Co; fb.y_tstride = Fo * Co; fb.y_fstride = Co; fb.y_off = 0;
+        Builder::Coef none_coef = [](int, int, int) -> int32_t { return 0; };
+        b.wgrad(R, fb, d_decy[d], none_coef, 400 + d, &dec[d].bias);
+      }
       b.cur_lane = 0;
       // input gradients: conv-form over dy [B][T+1][Fo][Co]; dx[ci,f,t] = sum W[ci,co,kh,kw] dy[co, 2f+kh-2, t+kw]
       const int nsrc = cfg.skip ? 2 : 1;
@@ -1219,6 +1239,15 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         if (s == 0 && d > 0) bnb_attach(g, bnb_dec[d - 1], (int64_t)(T + 1) * Fi * Cs, Fi * Cs, Cs, Fi * Cs);
         else if (s == 1) bnb_attach(g, bnb_enc[idx - 1], (int64_t)T * Fi * Cs, Fi * Cs, Cs, 0);
         b.push(R, OP_RUNGEMM, 400 + d).g = g;
+        if (wg_swap) {                           // weight gradient, swapped form: the runs of this GEMM against the source activation
+          RunGemm fw = g;
+          fw.flags = 0; fw.stats = b.none(); fw.bias = b.none(); fw.ydt = adt;
+          const DecSrc& xs = dec_src[d][s];
+          fw.y_bstride = xs.bstride; fw.y_tstride = xs.tstride; fw.y_fstride = xs.C; fw.y_off = xs.base;
+          b.cur_lane = 1;
+          b.wgrad(R, fw, xs.p, coef, 400 + d, nullptr);
+          b.cur_lane = 0;
+        }
       }
     }
     // ---- cfg.lstm == 'real': tranform, then the two LSTM layers last to first, then the gradient into the encoder output
