@@ -27,7 +27,8 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI3
 PEAK_HBM_GBS = 8000.0
 K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
 F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+ALGO_GB_PER_UTT = 0.28                   # minimal fused activation traffic of one bf16 training step
 
 
 def parse():
@@ -75,10 +76,35 @@ def pmc_traffic(kernel_prefixes):
     return round(tot / n) if n else None
 
 
-def roofline(plan, arenas, pmc_ok=True):
-    """Every MFMA GEMM, LSTM recurrence and STFT launch of one step is timed with HIP events on the launch stream while the
-    whole phase runs in program order on that ONE stream (each op sees the cache state its predecessors left; the two-stream
-    overlap of the real step is off, so these are per-kernel rates, not a decomposition of ms_per_step).
+def pmc_step_total():
+    """Fabric-side bytes of ALL kernels of one training step from the committed PMC summary (entry "_step_total"), or None."""
+    try:
+        return int(json.load(open(PMC_SUMMARY))["_step_total"]["hbm_bytes_per_step"])
+    except Exception:
+        return None
+
+
+def _op_class(info):
+    k = info["kind"]
+    if k == K_RUNGEMM:
+        return ("cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
+    if k == K_WGRAD:
+        return ("wgrad", info["dtype"])
+    if k in (K_LSTM_FWD, K_LSTM_BWD):
+        return ("lstm_gate_gemm", info["dtype"])
+    if k == K_STFT:
+        return ("stft_fft", 0)
+    if k == K_ISTFT:
+        return ("istft_fft", 0)
+    return None
+
+
+def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100):
+    """Two timing legs over every MFMA GEMM, LSTM recurrence and STFT launch of one step:
+      in situ  (the headline `frac`): sefd_plan_run_timed - each phase in its REAL two-stream schedule with a HIP event pair around every
+               op on the stream it runs on, i.e. the kernel's duration while the other lane's kernels share the chip (what a rocprofv3
+               kernel trace of the bench command shows; profiles/r03_kernel_stats_default.csv);
+      isolated (`frac_isolated`): the phase in program order on ONE stream, event pair per op - per-kernel rates without contention.
     achieved = algorithmic FLOPs (2*M*N*K, true unpadded N and K; sefd_plan_op_info) / measured duration."""
     from sefd_amd.plan import PHASE_BWD, PHASE_FWD
     stream = torch.cuda.current_stream().cuda_stream
@@ -86,9 +112,8 @@ def roofline(plan, arenas, pmc_ok=True):
     for phase in (PHASE_FWD, PHASE_BWD):
         n = plan.num_ops(phase)
         infos = [plan.op_info(phase, i) for i in range(n)]
-        timed = [i for i in range(n) if infos[i]["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT)]
+        timed = [i for i in range(n) if _op_class(infos[i]) is not None]
         acc = {i: 0.0 for i in timed}
-        reps = 3
         for rep in range(reps + 1):                                  # first pass warms
             cur = 0
             evs = []
@@ -107,44 +132,51 @@ def roofline(plan, arenas, pmc_ok=True):
             if rep:
                 for i, e0, e1 in evs:
                     acc[i] += e0.elapsed_time(e1) / reps
+        situ = [0.0] * n
+        plan.run_timed(phase, arenas, stream)                        # warm
+        for rep in range(insitu_reps):
+            ms = plan.run_timed(phase, arenas, stream)
+            for i in timed:
+                situ[i] += ms[i] / insitu_reps
         for i in timed:
             info = infos[i]
-            k = info["kind"]
-            if k == K_RUNGEMM:
-                key = ("cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
-            elif k == K_WGRAD:
-                key = ("wgrad", info["dtype"])
-            elif k in (K_LSTM_FWD, K_LSTM_BWD):
-                key = ("lstm_gate_gemm", info["dtype"])
-            else:
-                key = ("stft_fft" if k == K_STFT else "istft_fft", 0)
-            a = agg.setdefault(key, dict(flops=0, bytes=0, ms=0.0, launches=0))
+            a = agg.setdefault(_op_class(info), dict(flops=0, bytes=0, ms=0.0, ms_situ=0.0, launches=0))
             a["flops"] += info["flops"]
             a["bytes"] += info["bytes"]
             a["ms"] += acc[i]
+            a["ms_situ"] += situ[i]
             a["launches"] += 1
     detail = {}
     for (name, dt), v in agg.items():
         label = f"{name}_{'bf16' if dt else 'f32'}" if name not in ("stft_fft", "istft_fft") else name
         if name in ("stft_fft", "istft_fft"):
-            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
-            detail[label] = dict(bound="hbm", gb_s=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4), ms=round(v["ms"], 4), launches=v["launches"],
-                                 bytes_per_launch=int(v["bytes"] / max(v["launches"], 1)))
+            gbs = v["bytes"] / (v["ms_situ"] * 1e-3) / 1e9 if v["ms_situ"] > 0 else 0.0
+            gbi = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
+            detail[label] = dict(bound="hbm", gb_s=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4), gb_s_isolated=round(gbi, 1),
+                                 frac_isolated=round(gbi / PEAK_HBM_GBS, 4), ms=round(v["ms_situ"], 4), ms_isolated=round(v["ms"], 4),
+                                 launches=v["launches"], bytes_per_launch=int(v["bytes"] / max(v["launches"], 1)))
         else:
-            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
-            detail[label] = dict(bound="mfma", tflops=round(tf, 2), frac=round(tf / PEAK_TFLOPS[dt], 4), ms=round(v["ms"], 3), launches=v["launches"])
+            tf = v["flops"] / (v["ms_situ"] * 1e-3) / 1e12 if v["ms_situ"] > 0 else 0.0
+            tfi = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            detail[label] = dict(bound="mfma", tflops=round(tf, 2), frac=round(tf / PEAK_TFLOPS[dt], 4), tflops_isolated=round(tfi, 2),
+                                 frac_isolated=round(tfi / PEAK_TFLOPS[dt], 4), ms=round(v["ms_situ"], 3), ms_isolated=round(v["ms"], 3),
+                                 launches=v["launches"])
     gemm_keys = [k for k in agg if k[0] in ("rungemm", "cgemm256", "wgrad")]
-    key = max(gemm_keys, key=lambda k: agg[k]["ms"])
+    key = max(gemm_keys, key=lambda k: agg[k]["ms_situ"])
     a = agg[key]
-    achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    achieved = a["flops"] / (a["ms_situ"] * 1e-3) / 1e12
+    isolated = a["flops"] / (a["ms"] * 1e-3) / 1e12
     peak = PEAK_TFLOPS[key[1]]
     # kernel names as tools/pmc_traffic.py stores them ("void sefd::" / "sefd::" stripped, template arguments kept)
     prefixes = {"rungemm": ["rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float"],
                 "cgemm256": ["cgemm256_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
     return dict(bound="mfma", kernel=f"{key[0]}<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                frac=round(achieved / peak, 4), traffic=pmc_traffic(prefixes) if pmc_ok else None, launches_per_step=a["launches"],
-                avg_launch_ms=round(a["ms"] / a["launches"], 4),
-                timing="per-launch HIP events, whole phase in program order on one stream (no two-stream overlap)", kernels=detail)
+                frac=round(achieved / peak, 4), frac_isolated=round(isolated / peak, 4),
+                traffic=pmc_traffic(prefixes) if pmc_ok else None, launches_per_step=a["launches"],
+                avg_launch_ms=round(a["ms_situ"] / a["launches"], 4), avg_launch_ms_isolated=round(a["ms"] / a["launches"], 4),
+                timing="in situ: HIP event pair around every op inside the real two-stream schedule (sefd_plan_run_timed); "
+                       "isolated: whole phase in program order on one stream",
+                kernels=detail)
 
 
 def cpu_baseline(L, kn, ru):
@@ -155,6 +187,9 @@ def cpu_baseline(L, kn, ru):
     from oracle.step import dccrn_train_step
     from oracle.weights import formula_state_dict
     Bc, nsteps = 4, 5
+    # a 128-thread GPU host runs this small step ~5x slower with every core than with 16 threads (oversubscription: 0.3 vs 1.5 utt/s
+    # against the real reference on 8 cores, profiles/r02_reference_cpu_timing.json)
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
     cfgo = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode="C")
     P = formula_state_dict(dccrn_state_shapes(cfgo))
     x, y = make_batch(Bc, L, 0, "cpu")
@@ -269,6 +304,11 @@ def main():
             peak = PEAK_TFLOPS[1 if args.dtype == "bf16" else 0]
             out["roofline"]["step"] = dict(mfma_tflops=round(mf / (ms * 1e-3) / 1e12, 1), frac=round(mf / (ms * 1e-3) / 1e12 / peak, 4),
                                            note="all MFMA FLOPs of the step / ms_per_step (two-stream overlap on)")
+            if args.model == "dccrn" and B == 32 and not args.perceptual:
+                tot = pmc_step_total()
+                if tot is not None:                          # every kernel's fabric-side bytes of one step (same PMC passes) vs the algorithmic minimum
+                    out["roofline"]["step"].update(traffic_bytes=tot, algorithmic_bytes=int(ALGO_GB_PER_UTT * 1e9 * B),
+                                                   traffic_over_algorithmic=round(tot / (ALGO_GB_PER_UTT * 1e9 * B), 2))
         if cpu is not None:
             out["cpu_baseline"] = cpu
     if world > 1:

@@ -108,7 +108,8 @@ int32_t sefd_plan_grad_bucket(const sefd_plan* h, int32_t* op, int64_t* elem) {
   return 0;
 }
 
-static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx);
+static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
+                        std::vector<hipEvent_t>* tev = nullptr);
 
 int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream) {
   return plan_run(h, phase, first, last, arenas, stream, -1, nullptr, nullptr);
@@ -116,10 +117,29 @@ int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* 
 int32_t sefd_plan_run_cb(const sefd_plan* h, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx) {
   return plan_run(h, phase, 0, -1, arenas, stream, at, cb, ctx);
 }
+// Measurement: the whole phase in its REAL two-lane schedule, with a HIP event recorded before and after every op on the stream the op
+// is launched on; synchronises, then ms[i] = duration of op i in situ (next to whatever the other lane runs).  n = number of ops.
+int32_t sefd_plan_run_timed(const sefd_plan* h, int phase, void* const* arenas, void* stream, float* ms, int32_t n) {
+  const int nops = sefd_plan_num_ops(h, phase);
+  if (n < nops) return -1;
+  std::vector<hipEvent_t> ev(2 * (size_t)nops, nullptr);
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -3;
+  const int32_t rc = plan_run(h, phase, 0, -1, arenas, stream, -1, nullptr, nullptr, &ev);
+  (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
+  if (h->side) (void)hipStreamSynchronize(h->side);
+  for (int i = 0; i < nops; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) != hipSuccess) t = -1.f;
+    ms[i] = t;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
 
 }  // extern "C"
 
-static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx) {
+static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
+                        std::vector<hipEvent_t>* tev) {
   if (!h || !h->p->error.empty()) return -1;
   const std::vector<Op>& ops = phase == 0 ? h->p->fwd : h->p->bwd;
   if (first < 0) first = 0;
@@ -128,9 +148,12 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   for (int a = 0; a < A_COUNT; ++a) ab.p[a] = reinterpret_cast<char*>(arenas[a]);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   auto launch = [&](const Op& op, hipStream_t s) {
+    const size_t idx = (size_t)(&op - ops.data());
+    if (tev) (void)hipEventRecord((*tev)[2 * idx], s);
     if (op.kind == OP_RUNGEMM) launch_rungemm(op.g, ab, s);
     else if (op.kind == OP_WGRAD) launch_wgrad(op.g, ab, s);
     else launch_misc(op, ab, s);
+    if (tev) (void)hipEventRecord((*tev)[2 * idx + 1], s);
   };
   // Two-lane execution of a whole phase: lane-1 ops (decoder weight gradients + their split sums) are held back until the
   // first LSTM backward, then issued on the side stream right after that kernel, so they fill the ~248 CUs the recurrence

@@ -1444,7 +1444,34 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // input gradient of the layer
       Ptr dx_full;
       if (l > 0) dx_full = b.ws("dhc" + std::to_string(l - 1), BT * 2 * H, DT_F32);
-      for (int p = 0; p < 2; ++p) {
+      // Layer 0 in bf16: ONE GEMM over both gate halves (two sources, K = 2 x 8H) with block weights - the half of the K range that
+      // does not feed an output column is zero - writing the whole [D][Cl] row of d_encz contiguously, instead of 2 x D launches of
+      // N = Cl / 2 (M = B*T rows only: 8 x 24 us of latency-bound tiles vs one wide-tile launch; twice the MACs, 65 GFLOP).
+      const bool dx_merge = l == 0 && adt == DT_BF16 && (D * Cl) % 256 == 0 && (8 * H) % 64 == 0 &&
+                            !(getenv("SEFD_DX_MERGE") && atoi(getenv("SEFD_DX_MERGE")) == 0);
+      if (dx_merge) {
+        RunGemm g = Builder::gemm0();
+        g.xdt = adt; g.ydt = adt;
+        for (int p = 0; p < 2; ++p) {
+          g.x[p] = b.mk(A_WS, dgates.off + (int64_t)p * dg_half);
+          g.bstride[p] = (int64_t)T * 8 * H; g.tstride[p] = 8 * H; g.rowlen[p] = 8 * H; g.Tin[p] = T;
+        }
+        g.M = (int)BT; g.Tout = T; g.Fo = 1;
+        g.nseg = 2; g.seg[0] = Seg{0, 0, 0, 8 * H, 0}; g.seg[1] = Seg{1, 0, 0, 8 * H, 0};
+        g.N = D * Cl;
+        Builder::layout_segs(g);
+        const Builder::Coef cf0 = ls[l].cgx[0], cf1 = ls[l].cgx[1];
+        const int Ch = Cl / 2;
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+          const int q = nn / Cl, rem = nn % Cl, p = rem / Ch, c = rem % Ch;
+          if (sg != p) return 0;
+          return (p == 0 ? cf0 : cf1)(j, q, c);
+        };
+        b.pack_weights(R, g, coef, nm + ".dxm", 200 + l);
+        g.y = d_encz[n - 1]; g.y_bstride = (int64_t)T * D * Cl; g.y_tstride = D * Cl; g.y_off = 0;
+        b.push(R, OP_RUNGEMM, 200 + l).g = g;
+      }
+      for (int p = 0; p < (dx_merge ? 0 : 2); ++p) {
         const int nout = l == 0 ? D : 1;
         for (int q = 0; q < nout; ++q) {
           RunGemm g = Builder::gemm0();

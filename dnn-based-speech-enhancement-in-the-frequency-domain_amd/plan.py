@@ -176,6 +176,16 @@ class Plan:
         if rc != 0:
             raise RuntimeError(f"sefd_plan_run_cb failed ({rc})")
 
+    def run_timed(self, phase, arenas, stream=0):
+        """Whole phase in the real two-lane schedule with HIP events around every op (measurement): list of per-op milliseconds."""
+        n = self.num_ops(phase)
+        ms = (C.c_float * n)()
+        ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
+        rc = self.lib.sefd_plan_run_timed(self.h, phase, ptrs, C.c_void_p(stream), ms, n)
+        if rc != 0:
+            raise RuntimeError(f"sefd_plan_run_timed failed ({rc})")
+        return list(ms)
+
     def run(self, phase, arenas, stream=0, first=0, last=-1):
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         rc = self.lib.sefd_plan_run(self.h, phase, first, last, ptrs, C.c_void_p(stream))

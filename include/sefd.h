@@ -92,6 +92,9 @@ int32_t sefd_plan_grad_bucket(const sefd_plan* p, int32_t* op, int64_t* elem);
 /* Whole phase as sefd_plan_run(first = 0, last = -1), and `cb(ctx)` is called on the host right after op `at` has been enqueued on
    `stream` (everything up to and including that op is ordered before whatever the callback enqueues behind an event on `stream`). */
 int32_t sefd_plan_run_cb(const sefd_plan* p, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx);
+/* Measurement only (bench.py's in-situ roofline leg): the whole phase in its real two-stream schedule with a HIP event pair around every
+   op on the stream it is launched on; synchronises; ms[i] = duration of op i while the other lane runs beside it.  n >= number of ops. */
+int32_t sefd_plan_run_timed(const sefd_plan* p, int phase, void* const* arenas, void* stream, float* ms, int32_t n);
 
 /* ---- losses (tools_for_loss.py:17-94, models.py:315-323) ---------------------------------------
  * est, tgt: fp32 [B][L] device.  ws: fp32 device scratch of sefd_loss_ws_floats(B) floats.
