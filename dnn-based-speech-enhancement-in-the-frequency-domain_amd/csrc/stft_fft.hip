@@ -63,49 +63,68 @@ __device__ __forceinline__ void fft512_wave(cf* x, cf* X, float2* buf, const flo
   dft8(x, X);
 }
 
+// FPW frames per wave: the samples of ALL of a wave's frames are requested before the twiddle table is staged and before the first
+// transform starts (FPW x 8 loads in flight per lane instead of 8, the table staging hidden behind them): at 15 456 frames the
+// kernel is bound by the latency of one load -> transform -> store chain per frame, not by bandwidth (1.3 TB/s with FPW = 1).
+constexpr int kStftFPW = 2;
+
 __global__ __launch_bounds__(256) void stft_fft_kernel(const StftFft d, const ArenaBases ab) {
+  constexpr int FPW = kStftFPW;
   __shared__ float2 lds[4][512];
   __shared__ float2 twl[512];
   const float* src = reinterpret_cast<const float*>(rp(ab, d.src));
   const float* win = reinterpret_cast<const float*>(rp(ab, d.win));
   const float2* tw = reinterpret_cast<const float2*>(rp(ab, d.tw));
   float2* spec = reinterpret_cast<float2*>(rp(ab, d.spec));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t nfr = (int64_t)d.B * d.T;
+  const int64_t fr0 = ((int64_t)blockIdx.x * 4 + wv) * FPW;
+  float raw[FPW][8], wn[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wn[j] = win[lane + 64 * j];
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    const int64_t fr = fr0 + f;
+    const int64_t b = fr < nfr ? fr / d.T : 0;
+    const int t = fr < nfr ? (int)(fr - b * d.T) : 0;
+    const int p0 = t * d.hop - d.off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = p0 + lane + 64 * j;
+      raw[f][j] = (fr < nfr && p >= 0 && p < d.L) ? src[b * d.L + p] : 0.f;
+    }
+  }
   for (int i = threadIdx.x; i < 512; i += 256) twl[i] = tw[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t fr = (int64_t)blockIdx.x * 4 + wv;
-  if (fr >= (int64_t)d.B * d.T) return;                      // wave-uniform
-  const int64_t b = fr / d.T;
-  const int t = (int)(fr - b * d.T);
-  cf x[8], X[8];
-  const int p0 = t * d.hop - d.off;
-  float vs = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = lane + 64 * j, p = p0 + n;
-    const float v = (p >= 0 && p < d.L) ? src[b * d.L + p] * win[n] : 0.f;
-    x[j] = {v, 0.f};
-    vs += v;
-  }
-  fft512_wave(x, X, lds[wv], twl, lane);
   const int k0 = lane >> 3, ma = lane & 7;
-  float2* out = spec + fr * 258;
-  if (d.corr.arena >= 0) {                                   // backward of the pinv synthesis (see sefd_desc.h)
-    const float* cr = reinterpret_cast<const float*>(rp(ab, d.corr));
-    const float ge = wave_sum((lane & 1) ? 0.f : vs), go = wave_sum((lane & 1) ? vs : 0.f);   // n = lane + 64 j has the parity of lane
 #pragma unroll
-    for (int mb = 0; mb < 5; ++mb) {
-      const int k = k0 + 8 * ma + 64 * mb;
-      if (k <= 256)
-        out[1 + k] = make_float2(d.scale * (X[mb].x - cr[k] * ge - cr[2 * 257 + k] * go),
-                                 d.scale * (X[mb].y - cr[257 + k] * ge - cr[3 * 257 + k] * go));
+  for (int f = 0; f < FPW; ++f) {
+    const int64_t fr = fr0 + f;
+    if (fr >= nfr) break;                                    // wave-uniform
+    cf x[8], X[8];
+    float vs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = raw[f][j] * wn[j]; x[j] = {v, 0.f}; vs += v; }
+    fft512_wave(x, X, lds[wv], twl, lane);
+    float2* out = spec + fr * 258;
+    if (d.corr.arena >= 0) {                                 // backward of the pinv synthesis (see sefd_desc.h)
+      const float* cr = reinterpret_cast<const float*>(rp(ab, d.corr));
+      const float ge = wave_sum((lane & 1) ? 0.f : vs), go = wave_sum((lane & 1) ? vs : 0.f);   // n = lane + 64 j has the parity of lane
+#pragma unroll
+      for (int mb = 0; mb < 5; ++mb) {
+        const int k = k0 + 8 * ma + 64 * mb;
+        if (k <= 256)
+          out[1 + k] = make_float2(d.scale * (X[mb].x - cr[k] * ge - cr[2 * 257 + k] * go),
+                                   d.scale * (X[mb].y - cr[257 + k] * ge - cr[3 * 257 + k] * go));
+      }
+      if (lane == 0) out[0] = make_float2(0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) out[1 + k0 + 8 * ma + 64 * mb] = make_float2(X[mb].x, X[mb].y);
+      if (lane == 0) { out[1 + 256] = make_float2(X[4].x, X[4].y); out[0] = make_float2(0.f, 0.f); }
     }
-    if (lane == 0) out[0] = make_float2(0.f, 0.f);
-    return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's LDS slice is reused by its next frame
   }
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) out[1 + k0 + 8 * ma + 64 * mb] = make_float2(X[mb].x, X[mb].y);
-  if (lane == 0) { out[1 + 256] = make_float2(X[4].x, X[4].y); out[0] = make_float2(0.f, 0.f); }
 }
 
 __global__ __launch_bounds__(256) void istft_fft_kernel(const IstftFft d, const ArenaBases ab) {
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(256) void istft_fft_kernel(const IstftFft d, const 
 
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st) {
   const int64_t frames = (int64_t)d.B * d.T;
-  hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, st, d, ab);
+  hipLaunchKernelGGL(stft_fft_kernel, dim3((unsigned)((frames + 4 * kStftFPW - 1) / (4 * kStftFPW))), dim3(256), 0, st, d, ab);
 }
 void launch_istft_fft(const IstftFft& d, const ArenaBases& ab, hipStream_t st) {
   hipLaunchKernelGGL(istft_fft_kernel, dim3((unsigned)((d.nframes + 3) / 4)), dim3(256), 0, st, d, ab);
