@@ -53,6 +53,7 @@ struct Builder {
   struct Fix { int op; int64_t rel; int which; };         // which: 0 -> op.g.w, 1 -> op.unpack.part
   std::vector<Fix> fixes;
   std::vector<std::vector<int32_t>> inv;                  // per trainable element: signed (gp-relative position + 1)
+  std::vector<char> zero_grad;                            // elements without any contribution that UNPACK still writes (an exact 0)
 
   Ptr mk(int arena, int64_t off) { Ptr p; p.arena = arena; p.pad_ = 0; p.off = off; return p; }
   Ptr none() { return mk(A_NONE, 0); }
@@ -295,6 +296,7 @@ struct Builder {
     for (int64_t j = 0; j < n; ++j) {
       start[j] = (int32_t)ent.size();
       for (auto e : inv[lo + j]) ent.push_back(e);
+      if (inv[lo + j].empty() && (size_t)(lo + j) < zero_grad.size() && zero_grad[lo + j]) ent.push_back(0);   // entry 0 adds nothing: writes 0
     }
     start[n] = (int32_t)ent.size();
     if (ent.empty()) ent.push_back(0);
@@ -1195,7 +1197,13 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const bool wg_swap = !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
       b.cur_lane = 1;                           // weight gradients of the decoder: nothing downstream needs them before UNPACK
       if (!wg_swap) for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
-      else if (last) {
+      else if (!last) {                          // conv biases in front of BatchNorm: UNPACK writes their exact zero
+        b.zero_grad.resize(nparam, 0);
+        for (const char* part : {".0.real_conv.bias", ".0.imag_conv.bias"}) {
+          const ParamInfo& pb = b.par(pp + part);
+          for (int64_t e = 0; e < pb.numel; ++e) b.zero_grad[pb.off + e] = 1;
+        }
+      } else {
         RunGemm fb = Builder::gemm0();           // all output rows (both phases), no activation run: wgrad() appends the ones run
         fb.xdt = adt; fb.ydt = adt;
         fb.M = B * (T + 1) * Fo; fb.Tout = T + 1; fb.Fo = Fo;

@@ -67,10 +67,14 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         os.environ.pop("SEFD_CG256_MINM", None)
         os.environ.pop("SEFD_WG256_MINM", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
+    os.environ.pop("SEFD_WINCONV_MINM", None)
+    os.environ.pop("SEFD_WINCONV", None)
     os.environ.pop("SEFD_BN_FUSE", None)
     if L in (4001, 2403):                  # the direct-operand kernel takes GEMMs with M >= 65536 by default
         L -= 1 if L == 4001 else 3
         os.environ["SEFD_DIRECT_MINM"] = "0"
+        os.environ["SEFD_WINCONV_MINM"] = "0"  # ... the (opt-in) LDS-window kernel takes the thin GEMMs with K of a few hundred (winconv.hip)
+        os.environ["SEFD_WINCONV"] = "1"
         os.environ["SEFD_BN_FUSE"] = "2"   # ... and every BatchNorm layer's backward sums come from its producers' epilogues (thin + tiled kernels)
     if L == 2401 or (model == "DCCRN" and dtype == "fp32" and L == 2400):
         os.environ["SEFD_BN_FUSE"] = "2"   # the same through the wide-tile kernel / in fp32
@@ -158,6 +162,10 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
                         if not np.isfinite(err):
                             err = float("inf")
                         tol = 1.6e-2 if dt == 1 else 1e-3
+                        if dt != 1 and dtype == "bf16" and int(kinds[i]) == 1 and name.endswith(".bnpart"):
+                            tol = 4e-3     # fp32 partial sums of the bf16 gradient tile this launch ALSO stores: where kernel and simulator round an
+                                           # element of that tile to different bf16 neighbours (allowed above: 2 ulps), a 128-row sum with cancellation
+                                           # moves by up to that ulp (seen 1.06e-3 of the region's largest sum)
                         if dt != 1 and dtype == "bf16" and int(kinds[i]) in (9, 10):
                             tol = 4e-3     # fp32 state of a bf16 recurrence (cell state, dh): h_t is rounded to bf16 every frame, and a
                                            # rounding flip (one bf16 ulp = 4e-3 of h) between kernel and simulator feeds back into c
@@ -176,6 +184,8 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
                 bad.append(lines[-1])
     os.environ.pop("SEFD_LSTM_MT", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
+    os.environ.pop("SEFD_WINCONV_MINM", None)
+    os.environ.pop("SEFD_WINCONV", None)
     with open(_report_path(f"ops_report_{model}_B{B}_{mode.replace('/', '-')}_{dtype}_{L}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])
@@ -237,6 +247,13 @@ def test_syncbn_plans_two_ranks_emulated_on_one_gpu():
     from sefd_amd.plan import ARENA_GRAD, ARENA_STATE
     kn, ru, B, L = (16, 32, 32, 64, 64, 64), 128, 4, 3000
     P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode="C", kernel_num=kn, rnn_units=ru)))
+    # PReLU slopes = 1 (identity): the two runs sum their statistics in different orders, so activations differ by ~1e-7, and ONE element
+    # whose pre-activation lies that close to zero then takes different PReLU branches in the backward - which moves a whole layer's sums
+    # by (1 - slope) * dz of that element (seen: 3e-3 of a layer's sum(dbn), one flip among 1.1 M elements; expected ~0.5 flips per run).
+    # That discontinuity is not what this test is about (the SyncBN plumbing is); the kernels' PReLU branches are pinned by the per-op test.
+    for k in P:
+        if k.endswith(".2.weight"):
+            P[k] = torch.ones_like(P[k])
     x, _ = make_signals(B, L)
     torch.manual_seed(7)
     gw = torch.randn(B, L)
