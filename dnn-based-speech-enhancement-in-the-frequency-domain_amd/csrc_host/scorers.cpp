@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+namespace sefd_pesq { double pesq_wb_mos_lqo(const double* ref, const double* deg, long n, double in_scale); }
+
 namespace {
 
 constexpr int kFs = 10000, kFrame = 256, kNfft = 512, kBands = 15, kSeg = 30;
@@ -199,6 +201,19 @@ extern "C" {
 int32_t sefd_stoi_batch(const float* clean, const float* est, int32_t B, int32_t n, int32_t fs, double* out, int32_t nthreads) {
   if (!clean || !est || !out || B < 1 || n < 1 || fs < 1) return -1;
   parallel_for(B, nthreads, [&](int b) { out[b] = stoi_one(clean + (int64_t)b * n, est + (int64_t)b * n, n, fs); });
+  return 0;
+}
+
+// Wide-band PESQ MOS-LQO (pesq.cpp: P.862 + P.862.2) of B pairs; fs must be 16000 (the reference's PESQ.so is a 16 kHz build).  The score
+// does not depend on the input scale (both signals are level-aligned first), so waveforms in [-1, 1] are taken as they are.
+int32_t sefd_pesq_batch(const float* clean, const float* deg, int32_t B, int32_t n, int32_t fs, double* out, int32_t nthreads) {
+  const double scale = 1.0;
+  if (!clean || !deg || !out || B < 1 || n < 512 || fs != 16000) return -1;
+  parallel_for(B, nthreads, [&](int b) {
+    std::vector<double> r(n), d(n);
+    for (int i = 0; i < n; ++i) { r[i] = clean[(int64_t)b * n + i]; d[i] = deg[(int64_t)b * n + i]; }
+    out[b] = sefd_pesq::pesq_wb_mos_lqo(r.data(), d.data(), n, scale);
+  });
   return 0;
 }
 

@@ -146,14 +146,12 @@ def crn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
 # ------------------------------------------------------------------------------------------------ validation
 def _default_scorers():
     """(cal_pesq, cal_stoi) of sefd_amd.tools_for_estimate (reference tools_for_estimate.py:68-99 calls a closed x86 PESQ.so and
-    pystoi): the C++ scorers of libsefd_scorers.so.  A scorer the library does not export scores NaN (the other one still runs);
-    None only when the library itself has not been built."""
+    pystoi): the C++ scorers of libsefd_scorers.so (wide-band P.862 PESQ, STOI).  None only when the library has not been built."""
     from . import tools_for_estimate as te
     if not os.path.exists(te.LIB_PATH):
         return None
     te.lib()                                     # a library that exists but does not load is an error, not "no scorers"
-    nan = lambda est, clean: [float("nan")] * len(est)      # noqa: E731
-    return getattr(te, "cal_pesq", nan), te.cal_stoi
+    return te.cal_pesq, te.cal_stoi
 
 
 def _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batch_fn, n_losses, scorers):

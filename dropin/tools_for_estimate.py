@@ -1,4 +1,4 @@
-"""`tools_for_estimate` under the reference's top-level module name (see dropin/models.py): cal_stoi / cal_snr (cal_pesq once the C++ P.862 scorer is exported)."""
+"""`tools_for_estimate` under the reference's top-level module name (see dropin/models.py): cal_pesq / cal_stoi / cal_snr."""
 import os
 import sys
 

@@ -143,6 +143,7 @@ def score(args):
             r["stoi_" + name] = float(est.cal_stoi([sig[i] / 32768.0], [clean[i] / 32768.0])[0])
             if pesq:
                 r["pesq_" + name] = pesq(clean[i], sig[i])
+            r["pesq_cpp_" + name] = float(est.cal_pesq([sig[i] / 32768.0], [clean[i] / 32768.0])[0])   # the shipped C++ scorer beside it
         rows.append(r)
     mean = {k: float(np.mean([r[k] for r in rows])) for k in rows[0] if k != "utt"}
     out = dict(scorer_pesq="reference PESQ.so (WB MOS-LQO), run in the build container" if pesq else None,
