@@ -27,7 +27,8 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI3
 PEAK_HBM_GBS = 8000.0
 K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
 F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")       # default workload; main() switches to r03_pmc_traffic_<model>.json
+PMC_DEFAULT_BATCH = {"dccrn": 32, "dccrn_large": 32, "fullsubnet": 64}       # the batch each committed summary was collected at
 ALGO_GB_PER_UTT = 0.28                   # minimal fused activation traffic of one bf16 training step
 
 
@@ -297,8 +298,11 @@ def main():
             else:
                 rt = next(v for k, v in model._runtimes.items() if isinstance(k[0], int))
                 plan, arenas = rt.plan, rt.arenas
-            # the committed PMC summary was collected on the default workload (DCCRN, B = 32): other workloads report traffic null
-            out["roofline"] = roofline(plan, arenas, pmc_ok=(args.model == "dccrn" and B == 32))
+            # committed PMC summaries: one per model at its default batch; anything else reports traffic null
+            global PMC_SUMMARY
+            if args.model != "dccrn":
+                PMC_SUMMARY = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{args.model}.json")
+            out["roofline"] = roofline(plan, arenas, pmc_ok=(B == PMC_DEFAULT_BATCH[args.model] and not args.perceptual and args.dtype == "bf16"))
             info = [plan.op_info(ph, i) for ph in (0, 1) for i in range(plan.num_ops(ph))]
             mf = sum(o["flops"] for o in info if o["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD))
             peak = PEAK_TFLOPS[1 if args.dtype == "bf16" else 0]

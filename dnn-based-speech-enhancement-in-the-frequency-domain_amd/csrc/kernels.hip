@@ -123,10 +123,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalize d, co
     }
   } else {
     double s1 = 0.0, s2 = 0.0;
-    for (int b = threadIdx.x; b < d.nblk; b += 256) {
-      s1 += part[((int64_t)b * 2 + 0) * d.Cpad + c];
-      s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c];
-    }
+    const int nsub = d.nsub > 1 ? d.nsub : 1;
+    for (int b = threadIdx.x; b < d.nblk; b += 256)
+      for (int u = 0; u < nsub; ++u) {
+        s1 += part[((int64_t)b * 2 + 0) * d.Cpad + u * d.substride + c];
+        s2 += part[((int64_t)b * 2 + 1) * d.Cpad + u * d.substride + c];
+      }
     r1[threadIdx.x] = s1;
     r2[threadIdx.x] = s2;
     __syncthreads();
@@ -845,7 +847,8 @@ static FinScratch fin_scratch(hipStream_t st) {
 
 // rows [nblk][NS][ld] floats; sums NS (2 forward, 2 + slope backward) per channel
 template <int NS, bool BWD>
-__device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, int ld, int rowstride, FinScratch fs, double* out /* LDS [3][32] */) {
+__device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, int ld, int rowstride, FinScratch fs, double* out /* LDS [3][32] */,
+                                           int nsub = 1, int substride = 0) {
   __shared__ double red[8][3][kFinCG];
   __shared__ unsigned ticket;
   const int g = blockIdx.x, k = blockIdx.y, nch = gridDim.y;
@@ -853,12 +856,13 @@ __device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, i
   const int per = (nblk + nch - 1) / nch, b0 = k * per, b1 = min(nblk, b0 + per);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int b = b0 + rl; b < b1; b += 8) {
-      const float* row = part + (int64_t)b * rowstride;
-      s0 += row[c];
-      s1 += row[ld + c];
-      if (BWD) s2 += row[2 * ld + c];
-    }
+    for (int b = b0 + rl; b < b1; b += 8)
+      for (int u = 0; u < nsub; ++u) {
+        const float* row = part + (int64_t)b * rowstride + u * substride;
+        s0 += row[c];
+        s1 += row[ld + c];
+        if (BWD) s2 += row[2 * ld + c];
+      }
   }
   red[rl][0][cl] = s0; red[rl][1][cl] = s1; red[rl][2][cl] = s2;
   __syncthreads();
@@ -900,7 +904,7 @@ __device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, i
 
 __global__ __launch_bounds__(256) void bn_finalize2_kernel(const BnFinalize d, const ArenaBases ab, FinScratch fs) {
   __shared__ double tot[3 * kFinCG];
-  if (!fin_stage1<2, false>(reinterpret_cast<const float*>(rp(ab, d.part)), d.nblk, d.C, d.Cpad, 2 * d.Cpad, fs, tot)) return;
+  if (!fin_stage1<2, false>(reinterpret_cast<const float*>(rp(ab, d.part)), d.nblk, d.C, d.Cpad, 2 * d.Cpad, fs, tot, d.nsub > 1 ? d.nsub : 1, d.substride)) return;
   const int c = blockIdx.x * kFinCG + threadIdx.x;
   if (threadIdx.x < kFinCG && c < d.C) {
     const double mean = tot[threadIdx.x] / d.count;

@@ -3,6 +3,7 @@
 // Arithmetic contract of bf16 mode: the recurrent operands (h_{t-1}, W_hh, and dgates_t in the backward) are rounded to
 // bf16; gate pre-activations from the input GEMM, the cell state and all gate math stay fp32.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -27,13 +28,19 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 x) { return fma2(rcp_2(exp2_2(x * 2
 
 // H is a compile-time constant (32 / 64 / 96 / 128): with run-time trip counts hipcc guards every MFMA with a branch and
 // drains the software-prefetched loads before the matrix section, which serialises the 483-step loop.
-template <int HMAX>
+// RPW = sequences per workgroup.  16: every row of the 16-row MFMA tile is a sequence, a lane owns 4 cells (rows 4*kq .. 4*kq+3).
+// 4: the sequences sit in tile rows 0, 4, 8, 12 and a lane owns ONE cell (row 4*kq): the step loop is bound by the gate math a lane
+// issues (5 exp + 5 rcp per cell at quarter rate), not by the MFMAs, and the recurrence of a DCCRN step (B = 32, 4 groups) fills 8 of
+// 256 CUs - four times the workgroups, a quarter of the per-step issue (forward LSTM of the default step: 1.03 -> ~0.4 ms exposed).
+// The per-element arithmetic is the same in both variants (same operations in the same order), only the packing differs.
+template <int HMAX, int RPW>
 __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d, const ArenaBases ab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];
   constexpr int H = HMAX;
   const int T = d.T;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int g = blockIdx.y, b0 = blockIdx.x * 16;
+  const int g = blockIdx.y, b0 = blockIdx.x * RPW;
+  constexpr int NR = RPW == 16 ? 4 : 1;            // cells per lane
   const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
   const float* gx = reinterpret_cast<const float*>(rp(ab, d.gx)) + d.gx_goff[g];
   uint16_t* hout = reinterpret_cast<uint16_t*>(rp(ab, d.h));
@@ -61,23 +68,23 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
   __syncthreads();
   const int tb = d.t0, te = d.t1 > 0 ? d.t1 : T;         // this launch covers frames [tb, te); tb > 0 resumes from the saved state
 
-  bool rvalid[4];
-  int64_t rowbt[4];
+  bool rvalid[NR];
+  int64_t rowbt[NR];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * kq + r;
+  for (int r = 0; r < NR; ++r) {
+    const int b = RPW == 16 ? b0 + 4 * kq + r : b0 + kq;
     rvalid[r] = b < d.B;
     rowbt[r] = (int64_t)(rvalid[r] ? b : 0) * T;
   }
-  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  float c[NR] = {};
   // The step loop is issue-bound (two waves per SIMD, ~300 instructions per step before this layout): the four gates of a
   // (row, unit) cell are adjacent in gx and in the saved gates (sefd_desc.h gate_col), so a lane moves a cell with ONE 16-byte
   // load and ONE 16-byte store, addresses advance by constants, and the two-step prefetch ring is unrolled (no copies).
   const int64_t GBT = (int64_t)d.B * T;
-  const float* gxp[4];                          // gx of (row r, this unit), current prefetch position
-  int64_t so[4];                                // (g*GBT + row*T + t) * H + unit : element offset of the cell in h / c, x4 in gates
+  const float* gxp[NR];                          // gx of (row r, this unit), current prefetch position
+  int64_t so[NR];                               // (g*GBT + row*T + t) * H + unit : element offset of the cell in h / c, x4 in gates
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < NR; ++r) {
     gxp[r] = gx + (rowbt[r] + tb) * d.gx_ld + gate_col(0, unit);     // rows >= B alias row 0, never stored
     so[r] = ((int64_t)g * GBT + rowbt[r] + tb) * H + unit;
     if (tb > 0) {                                                    // h[tb-1] into the LDS buffer step tb reads, c[tb-1] into registers
@@ -87,15 +94,17 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
   }
   if (tb > 0) __syncthreads();
   const int64_t gx_ld = d.gx_ld;
-  auto load_gx = [&](int t, float4 (&dst)[4]) {                        // t is clamped: the last two prefetches re-read step T-1
+  auto load_gx = [&](int t, float4 (&dst)[NR]) {                        // t is clamped: the last two prefetches re-read step T-1
     const int64_t inc = t < T - 1 ? gx_ld : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { dst[r] = *reinterpret_cast<const float4*>(gxp[r]); gxp[r] += inc; }
+    for (int r = 0; r < NR; ++r) { dst[r] = *reinterpret_cast<const float4*>(gxp[r]); gxp[r] += inc; }
   };
-  auto step = [&](int t, const float4 (&cur)[4], float4 (&pre)[4]) {
+  auto step = [&](int t, const float4 (&cur)[NR], float4 (&pre)[NR]) {
     f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc[0][r] = cur[r].x; acc[1][r] = cur[r].y; acc[2][r] = cur[r].z; acc[3][r] = cur[r].w; }
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { acc[0][r] = cur[r].x; acc[1][r] = cur[r].y; acc[2][r] = cur[r].z; acc[3][r] = cur[r].w; }
     load_gx(t + 2, pre);                        // gate pre-activations two steps ahead: one step does not cover an HBM round trip
     const int hp = (t & 1) * 16 * hs;           // LDS offsets, not pointers: keeps the accesses in the LDS address space (ds_*, not flat_*)
     if (t > 0) {
@@ -110,6 +119,7 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
       }
     }
     const int hn = ((t + 1) & 1) * 16 * hs;
+    if constexpr (RPW == 16) {
 #pragma unroll
     for (int rp2 = 0; rp2 < 4; rp2 += 2) {
       const f32x2 ig = sigmoid2(f32x2{acc[0][rp2], acc[0][rp2 + 1]}), fg = sigmoid2(f32x2{acc[1][rp2], acc[1][rp2 + 1]});
@@ -130,9 +140,25 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
         so[r] += H;
       }
     }
+    } else {
+      const f32x2 s = sigmoid2(f32x2{acc[0][0], acc[1][0]});                                                   // i, f
+      const f32x2 v = rcp_2(exp2_2(f32x2{acc[2][0], acc[3][0]} * f32x2{2.8853900817779268f, -1.4426950408889634f}) + 1.f);
+      const float gg = __builtin_fmaf(v.x, -2.f, 1.f), og = v.y;                                               // tanh(g), sigmoid(o): tanh2 / sigmoid2 written out
+      const float cn = __builtin_fmaf(s.y, c[0], s.x * gg);
+      const float hv = og * __builtin_fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(cn * 2.8853900817779268f) + 1.f), -2.f, 1.f);
+      c[0] = cn;
+      const uint16_t hb = f2bf(hv);
+      ldsh[hn + 4 * kq * hs + unit] = hb;
+      if (rvalid[0]) {
+        hout[so[0]] = hb;
+        *reinterpret_cast<float4*>(gates + so[0] * 4) = make_float4(s.x, s.y, gg, og);
+        cs[so[0]] = cn;
+      }
+      so[0] += H;
+    }
     lds_barrier();
   };
-  float4 b0v[4], b1v[4], b2v[4];
+  float4 b0v[NR], b1v[NR], b2v[NR];
   load_gx(tb, b0v);
   load_gx(tb + 1, b1v);
   int t = tb;
@@ -279,7 +305,10 @@ template <int HMAX>
 static void launch_t(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
   dim3 grid((d.B + 15) / 16, d.G);
   dim3 block(64 * (d.H / 16));
-  if (fwd) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX>), grid, block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);
+  static const int rpw_env = getenv("SEFD_LSTM_RPW") ? atoi(getenv("SEFD_LSTM_RPW")) : 0;
+  const bool spread = rpw_env ? rpw_env == 4 : (int64_t)((d.B + 3) / 4) * d.G <= 1024;      // one cell per lane while the chip has CUs to spare
+  if (fwd && spread) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX, 4>), dim3((d.B + 3) / 4, d.G), block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);
+  else if (fwd) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX, 16>), grid, block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);
   else hipLaunchKernelGGL((lstm_bwd_bf16_kernel<HMAX>), grid, block, 16 * (4 * d.H + 8) * sizeof(uint16_t), st, d, ab);
 }
 

@@ -399,6 +399,26 @@ void finalize_rungemms(Builder& b, Plan* P) {
     rest.insert(rest.begin(), m);
     ops->swap(rest);
   }
+  // Training plans: BOTH phases' packs in one launch at the head of the forward phase, on the second stream (they read only
+  // parameters; the backward's 57 us pass sat in the serial loss section, the forward's in front of the STFT): the first op that reads
+  // a packed matrix joins.  SEFD_PACK_EARLY=0 keeps one launch per phase at its head.
+  if (!(getenv("SEFD_PACK_EARLY") && atoi(getenv("SEFD_PACK_EARLY")) == 0) && !P->fwd.empty() && !P->bwd.empty() &&
+      P->fwd[0].kind == OP_PACKMULTI && P->bwd[0].kind == OP_PACKMULTI) {
+    const Pack* pf = reinterpret_cast<const Pack*>(P->consts.data() + P->fwd[0].packm.entries.off);
+    const Pack* pb = reinterpret_cast<const Pack*>(P->consts.data() + P->bwd[0].packm.entries.off);
+    std::vector<Pack> all(pf, pf + P->fwd[0].packm.count);
+    all.insert(all.end(), pb, pb + P->bwd[0].packm.count);
+    Op& m = P->fwd[0];
+    m.packm.entries = b.cst(all.data(), (int64_t)all.size() * sizeof(Pack));
+    m.packm.count = (int32_t)all.size();
+    m.lane = 2;
+    P->bwd.erase(P->bwd.begin());
+    for (size_t i = 1; i < P->fwd.size(); ++i) {
+      Op& op = P->fwd[i];
+      if (op.lane != 0) continue;
+      if (op.kind == OP_RUNGEMM || op.kind == OP_LSTM_FWD || op.kind == OP_WGRAD) { op.join = 1; break; }
+    }
+  }
   // SyncBN (cfg.bn_world > 1): every training-mode BN_FINALIZE becomes "publish this rank's sums" + "statistics from the
   // all-reduced sums" with a sync point in between; every BN_BWD_FINALIZE is followed by a sync point on its totals.
   // Counts become global.  The caller (models.py / hostsim tests) runs the op ranges between sync points and all-reduces.
@@ -783,6 +803,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       o[0] = pe(*bih[set], gq, 1); o[1] = pe(*bhh[set], gq, 1);
     };
     ls[l].bgx = bias;
+    const bool gx_merge = !(getenv("SEFD_GX_MERGE") && atoi(getenv("SEFD_GX_MERGE")) == 0) && BT * 8 * H < (1LL << 31);
     for (int p = 0; p < 2; ++p) {
       RunGemm g = Builder::gemm0();
       g.x[0] = lin; g.xdt = adt; g.ydt = DT_F32;
@@ -806,8 +827,18 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       if (p == 1) g.bias = ls[l].gx[0].bias;
       g.y = b.mk(A_WS, ls[l].gxb.off + (int64_t)p * BT * 8 * H * 4);
       g.y_bstride = (int64_t)T * 8 * H; g.y_tstride = 8 * H; g.y_fstride = 0; g.y_off = 0;
-      if (pipe && l == 1) pipe_gx1[p] = g; else b.push(F, OP_RUNGEMM, 200 + l).g = g;
       ls[l].gx[p] = g; ls[l].cgx[p] = coef;
+      if (gx_merge) continue;
+      if (pipe && l == 1) pipe_gx1[p] = g; else b.push(F, OP_RUNGEMM, 200 + l).g = g;
+    }
+    if (gx_merge) {
+      // both parts in ONE launch: the two GEMMs share their weights (W_ih of the real and the imag LSTM side by side) and differ only in the
+      // input columns (part p) and the output slab - the part becomes the row index f of the run descriptor (rows (b, t, p))
+      RunGemm g = ls[l].gx[0];
+      g.Fo = 2; g.M = (int)(2 * BT);
+      g.fstride[0] = l == 0 ? Cl / 2 : H;
+      g.y_fstride = (int)(BT * 8 * H);
+      if (pipe && l == 1) pipe_gx1[0] = g; else b.push(F, OP_RUNGEMM, 200 + l).g = g;
     }
     if (!stepped) {
       LstmRec r;
@@ -880,9 +911,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         op.comb.h = ls[0].h; op.comb.out = ls[0].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt;
         op.comb.T = T; op.comb.t0 = t0; op.comb.t1 = t1;
       }
-      for (int p = 0; p < 2; ++p) {                        // input GEMM of layer 1 for the frames of this chunk
+      const bool gxm = pipe_gx1[0].Fo == 2;               // both parts in one launch (gx_merge)
+      for (int p = 0; p < (gxm ? 1 : 2); ++p) {           // input GEMM of layer 1 for the frames of this chunk
         RunGemm g = pipe_gx1[p];
-        g.M = B * Tc; g.Tout = Tc; g.Tin[0] = Tc;
+        g.M = B * Tc * (gxm ? 2 : 1); g.Tout = Tc; g.Tin[0] = Tc;
         g.base[0] += t0 * g.tstride[0];
         g.y_off += t0 * g.y_tstride;
         b.push(F, OP_RUNGEMM, 201).g = g;
@@ -990,6 +1022,13 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     Ptr part = b.none();
     int npad_stat = (int)rup(Co, bn_of(Co));
     if (!last) part = b.ws(nm + ".stat", (int64_t)2 * nblk1 * 2 * npad_stat, DT_F32);
+    // Thin layers (Cob <= SEFD_PHASE_MERGE_MAXN, default 32: dec4 and the mask layer): ONE GEMM for both sub-pixel phases - the even
+    // phase's runs (input bins f-1, f, f+1, two frames), 2 * Cob output columns [phase][channel] (= bins 2f and 2f+1 of the output row:
+    // contiguous in the channels-last buffer), zero weights where the odd phase has no tap.  These layers are bound by streaming the
+    // tap-expanded activation operand through L2 -> LDS, not by MFMAs: 20 % more MACs, the operand streamed once instead of twice.
+    // The backward reads only the per-phase coefficient functions.
+    const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 32;
+    const bool merge = Cob <= merge_maxn && !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
     for (int par = 0; par < 2; ++par) {
       RunGemm g = Builder::gemm0();
       g.xdt = adt; g.ydt = adt;
@@ -1014,6 +1053,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         const int kh = par == 0 ? 4 - 2 * jj : 3 - 2 * jj;
         return wcoef(nn, s, cc, kh, kw);
       };
+      if (merge) { dec[d].f[par] = g; dec[d].coef[par] = coef; continue; }     // descriptor only (no packed weights): see below
       b.pack_weights(F, g, coef, nm + ".p" + std::to_string(par), 400 + d, par == 0 ? &bias : nullptr);
       if (par == 1) g.bias = dec[d].f[0].bias;
       g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Cob; g.y_tstride = Fo * Cob; g.y_fstride = 2 * Cob; g.y_off = par * Cob;
@@ -1021,12 +1061,36 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.push(F, OP_RUNGEMM, 400 + d).g = g;
       dec[d].f[par] = g; dec[d].coef[par] = coef;
     }
+    int fin_nblk = 2 * nblk1, fin_cpad = npad_stat, fin_nsub = 0;
+    if (merge) {
+      RunGemm g = dec[d].f[0];                  // the even phase's runs
+      g.N = 2 * Cob;
+      Builder::layout_segs(g);
+      const Builder::Coef f0 = dec[d].coef[0], f1 = dec[d].coef[1];
+      const int c0 = C0, c1 = C1, cob = Cob;
+      Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+        if (nn >= 2 * cob) return 0;
+        if (nn < cob) return f0(nn, sg, j);
+        const int Cs = sg / 2 == 0 ? c0 : c1;
+        return j < Cs ? 0 : f1(nn - cob, sg, j - Cs);          // the odd phase's taps are bins f, f+1: one bin into the even phase's run
+      };
+      std::function<void(int, int32_t*)> bias2 = [=](int nn, int32_t* o) { if (nn >= 2 * cob) { o[0] = o[1] = 0; } else bias(nn % cob, o); };
+      b.pack_weights(F, g, coef, nm + ".pm", 400 + d, &bias2);
+      g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Cob; g.y_tstride = Fo * Cob; g.y_fstride = 2 * Cob; g.y_off = 0;
+      if (!last && cfg.training) {
+        if ((int64_t)nblk1 * 2 * g.Npad > (int64_t)2 * nblk1 * 2 * npad_stat) { P->error = "merged sub-pixel GEMM: statistics pitch"; return P; }
+        g.stats = part;
+        fin_nblk = nblk1; fin_cpad = g.Npad; fin_nsub = 2;
+      }
+      b.push(F, OP_RUNGEMM, 400 + d).g = g;
+    }
     dec[d].bias = bias; dec[d].C = Co; dec[d].Fq = Fo; dec[d].R = Rr;
     if (!last) {
       Op& op = b.push(F, OP_BN_FINALIZE, 400 + d);
       op.bnf.part = part; op.bnf.mean_invstd = dec_mi[d];
       op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
-      op.bnf.nblk = cfg.training ? 2 * nblk1 : -1; op.bnf.C = Co; op.bnf.Cpad = npad_stat; op.bnf.count = (double)Rr;
+      op.bnf.nblk = cfg.training ? fin_nblk : -1; op.bnf.C = Co; op.bnf.Cpad = fin_cpad; op.bnf.count = (double)Rr;
+      op.bnf.nsub = fin_nsub; op.bnf.substride = Cob;
       op.bnf.eps = 1e-5f; op.bnf.momentum = 0.1f;
       Op& oa = b.push(F, OP_BN_APPLY, 400 + d);
       oa.bna.y = decy[d]; oa.bna.z = decz[d]; oa.bna.mean_invstd = dec_mi[d];
@@ -1524,6 +1588,31 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.cur_lane = 0;
       if (i == 0) continue;
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]
+      // thin layers: both phases in one GEMM over the even phase's runs (see the decoder forward), unless this layer's BatchNorm sums
+      // ride in the epilogue (their partial rows have one column per channel)
+      const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 32;
+      if (Ci <= merge_maxn && !bnb_enc[i - 1].on) {
+        RunGemm g = Builder::gemm0();
+        g.x[0] = d_ency[i]; g.xdt = adt; g.ydt = adt;
+        g.bstride[0] = (int64_t)T * Fo * Co; g.tstride[0] = Fo * Co; g.rowlen[0] = Fo * Co; g.fstride[0] = Co; g.Tin[0] = T;
+        g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;
+        g.nseg = 2;
+        g.seg[0] = Seg{0, 1, -Co, 3 * Co, 0};
+        g.seg[1] = Seg{0, 0, -Co, 3 * Co, 0};
+        g.N = 2 * Ci;
+        Builder::layout_segs(g);
+        const Builder::Coef cf = enc[i].coef[0];
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t {
+          const int kw = sg, jj = j / Co, co = j % Co, par = nn / Ci;
+          if (par > 1 || (par == 1 && jj == 0)) return 0;
+          const int kh = par == 0 ? 4 - 2 * jj : 5 - 2 * jj;
+          return cf(co, kw, kh * Ci + nn % Ci);
+        };
+        b.pack_weights(R, g, coef, nm + ".dgm", 100 + i);
+        g.y = d_encz[i - 1]; g.y_bstride = (int64_t)T * Fi * Ci; g.y_tstride = Fi * Ci; g.y_fstride = 2 * Ci; g.y_off = 0;
+        b.push(R, OP_RUNGEMM, 100 + i).g = g;
+        continue;
+      }
       for (int par = 0; par < 2; ++par) {
         RunGemm g = Builder::gemm0();
         g.x[0] = d_ency[i]; g.xdt = adt; g.ydt = adt;

@@ -132,6 +132,8 @@ struct BnFinalize {            // partial sums -> mean, invstd ; running stats m
   double count;                // rows contributing (all ranks in mode 2)
   float eps, momentum;
   Ptr totals;                  // fp64 [2][C] (modes 1, 2)
+  int32_t nsub, substride;     // nsub > 1: a partial row holds nsub column groups of the same channels (the two sub-pixel phases of a merged
+                               // transposed-conv GEMM, columns phase * substride + c): channel c sums all of them
 };
 struct BnApply {               // z = prelu(gamma*(y-mean)*invstd + beta)
   Ptr y, z, mean_invstd, gamma, beta, slope;

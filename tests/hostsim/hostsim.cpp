@@ -575,7 +575,11 @@ void run_op(const Op& op, const AB& ab) {
           const double* tot = (const double*)rp(ab, d.totals);
           s1 = tot[c]; s2 = tot[d.C + c];
         } else {
-          for (int b = 0; b < d.nblk; ++b) { s1 += part[((int64_t)b * 2) * d.Cpad + c]; s2 += part[((int64_t)b * 2 + 1) * d.Cpad + c]; }
+          for (int b = 0; b < d.nblk; ++b)
+            for (int u = 0; u < (d.nsub > 1 ? d.nsub : 1); ++u) {
+              s1 += part[((int64_t)b * 2) * d.Cpad + u * d.substride + c];
+              s2 += part[((int64_t)b * 2 + 1) * d.Cpad + u * d.substride + c];
+            }
           if (d.mode == 1) {
             double* tot = (double*)rp(ab, d.totals);
             tot[c] = s1; tot[d.C + c] = s2;

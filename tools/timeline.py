@@ -1,37 +1,33 @@
 #!/usr/bin/env python3
-"""Per-step stream timeline from a rocprofv3 kernel trace CSV: busy time per stream, idle gaps of the main stream, the kernels around them.
-usage: timeline.py <kernel_trace.csv> [marker kernel name that starts a step: default stft_fft_kernel]"""
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-mark = sys.argv[2] if len(sys.argv) > 2 else "stft_fft_kernel"
-ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void sefd::", "").replace("sefd::", "")[:48], r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows), key=lambda e: e[0])
-starts = [i for i, e in enumerate(ev) if mark in e[2]]
-# a training step = two STFT launches (noisy, clean): take every second marker
-starts = starts[::2]
-if len(starts) < 3:
-    print("not enough steps", len(starts)); sys.exit()
-a, b = starts[-2], starts[-1]
-step = ev[a:b]
-t0, t1 = step[0][0], ev[b][0]
-print(f"step wall {(t1 - t0) / 1e3:.1f} us, {len(step)} launches")
-by = collections.defaultdict(list)
-for e in step: by[e[3]].append(e)
-for sid, es in by.items():
-    busy = sum(e[1] - e[0] for e in es)
-    print(f" stream/queue {sid}: {len(es)} launches, busy {busy / 1e3:.1f} us, span {(max(e[1] for e in es) - min(e[0] for e in es)) / 1e3:.1f} us")
-main = max(by.values(), key=len)
-gaps = []
-for p, q in zip(main, main[1:]):
-    g = q[0] - p[1]
-    if g > 3000: gaps.append((g, p[2], q[2], (p[1] - t0) / 1e3))
-print(f" main-stream idle gaps > 3 us: {len(gaps)}, total {sum(g[0] for g in gaps) / 1e3:.1f} us")
-for g in sorted(gaps, reverse=True)[:14]:
-    print(f"   {g[0] / 1e3:7.1f} us at +{g[3]:8.1f} us  after {g[1]}  before {g[2]}")
-# union busy time of all streams
-iv = sorted((e[0], e[1]) for e in step)
-cur_s, cur_e, tot = iv[0][0], iv[0][1], 0
-for s_, e_ in iv[1:]:
-    if s_ > cur_e: tot += cur_e - cur_s; cur_s, cur_e = s_, e_
-    else: cur_e = max(cur_e, e_)
-tot += cur_e - cur_s
-print(f" GPU busy (any stream) {tot / 1e3:.1f} us of {(t1 - t0) / 1e3:.1f}")
+"""Timeline of ONE training step from a rocprofv3 kernel trace: per kernel start / duration / queue, the time each kernel class runs
+ALONE (nothing else in flight on the other queue) and the idle gaps.  usage: timeline.py kernel_trace.csv [step_index_from_end]"""
+import csv, sys, re, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "sefd::" in r["Kernel_Name"]]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+verbose = len(sys.argv) > 3
+def short(n):
+    n = re.sub(r"\(.*", "", n.replace("void ", "").replace("sefd::", ""))
+    return n
+ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) for r in rows]
+ks.sort()
+starts = [i for i, k in enumerate(ks) if k[2].startswith("stft_fft")]           # two STFTs open each step
+steps = [starts[i] for i in range(0, len(starts), 2)]
+a = steps[-1 - back]; b = steps[-back] if back > 0 else len(ks)
+ks = ks[a:b]
+t0 = ks[0][0]; t1 = max(k[1] for k in ks)
+print(f"step: {len(ks)} kernels, {(t1 - t0) / 1e3:.1f} us wall")
+ev = sorted([(k[0], 1, i) for i, k in enumerate(ks)] + [(k[1], -1, i) for i, k in enumerate(ks)])
+alone = collections.Counter(); busy2 = 0; idle = 0; active = set(); last = t0
+for t, d, i in ev:
+    dt = t - last
+    if dt > 0:
+        if not active: idle += dt
+        elif len(active) == 1: alone[ks[next(iter(active))][2]] += dt
+        else: busy2 += dt
+    last = t
+    if d == 1: active.add(i)
+    else: active.discard(i)
+print(f"idle {idle / 1e3:.1f} us, two or more kernels in flight {busy2 / 1e3:.1f} us, exactly one in flight {sum(alone.values()) / 1e3:.1f} us:")
+for n, v in alone.most_common(25): print(f"  {v / 1e3:9.1f} us  {n}")
+if verbose:
+    for k in ks: print(f"{(k[0] - t0) / 1e3:9.1f} +{(k[1] - k[0]) / 1e3:7.1f} q{k[3]} wg{k[4]:6d} {k[2]}")
