@@ -609,6 +609,7 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
   const int TT = d.T + lead;
   const int64_t B = d.frames / d.T;
   const int64_t n = B * TT * NB;
+  float cr = 0.f, ci = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % NB);
     const int64_t bu = i / NB;
@@ -663,6 +664,22 @@ __global__ void mask_bwd_kernel(const Mask d, const ArenaBases ab) {
     }
     st_elem(dmask, d.mdt, mo, gr);
     if (d.mch >= 2) st_elem(dmask, d.mdt, mo + 1, gi);
+    if (d.mdt == DT_BF16) { gr = bf2f(f2bf(gr)); gi = bf2f(f2bf(gi)); }     // the sums are those of the stored values
+    cr += gr;
+    if (d.mch >= 2) ci += gi;
+  }
+  if (d.colsum_rows > 0) {                       // fixed-order reduction: lanes of a wave, then the waves
+    __shared__ float red[2][16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cr += __shfl_xor(cr, o); ci += __shfl_xor(ci, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cr; red[1][threadIdx.x >> 6] = ci; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      float v = 0.f;
+      if (threadIdx.x < 2)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[threadIdx.x][w];
+      reinterpret_cast<float*>(rp(ab, d.colsum))[(int64_t)blockIdx.x * 8 + threadIdx.x] = v;
+    }
   }
 }
 
@@ -1012,7 +1029,7 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_MASK_FWD:
       hipLaunchKernelGGL(mask_fwd_kernel, dim3(grid_for(op.mask.frames * (op.mask.NF + 1))), dim3(256), 0, st, op.mask, ab); break;
     case OP_MASK_BWD:
-      hipLaunchKernelGGL(mask_bwd_kernel, dim3(grid_for(op.mask.frames * 2 * op.mask.NF)), dim3(256), 0, st, op.mask, ab); break;
+      hipLaunchKernelGGL(mask_bwd_kernel, dim3(op.mask.colsum_rows > 0 ? op.mask.colsum_rows : grid_for(op.mask.frames * 2 * op.mask.NF)), dim3(256), 0, st, op.mask, ab); break;
     case OP_OLA_FWD:
       hipLaunchKernelGGL(ola_fwd_kernel, dim3(grid_for((int64_t)op.ola.B * op.ola.L)), dim3(256), 0, st, op.ola, ab); break;
     case OP_OLA_BWD:

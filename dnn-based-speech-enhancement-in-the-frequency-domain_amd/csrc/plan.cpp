@@ -50,7 +50,7 @@ struct Builder {
 
   // gradient partial region (allocated at the end) and the inverse (unpack) table
   int64_t gp_off = 0;                                     // floats
-  struct Fix { int op; int64_t rel; int which; };         // which: 0 -> op.g.w, 1 -> op.unpack.part
+  struct Fix { int op; int64_t rel; int which; };         // which: 0 -> op.g.w, 1 -> op.unpack.part, 2 -> op.mask.colsum
   std::vector<Fix> fixes;
   std::vector<std::vector<int32_t>> inv;                  // per trainable element: signed (gp-relative position + 1)
   std::vector<char> zero_grad;                            // elements without any contribution that UNPACK still writes (an exact 0)
@@ -111,7 +111,7 @@ struct Builder {
   static RunGemm gemm0() {
     RunGemm g;
     std::memset(&g, 0, sizeof(g));
-    g.x[0].arena = g.x[1].arena = g.w.arena = g.bias.arena = g.y.arena = g.stats.arena = A_NONE;
+    g.x[0].arena = g.x[1].arena = g.w.arena = g.bias.arena = g.y.arena = g.stats.arena = g.y2.arena = A_NONE;
     g.nsplit = 1;
     return g;
   }
@@ -316,7 +316,7 @@ struct Builder {
     Ptr base = ws("gradpart", std::max<int64_t>(gp_off, 1), DT_F32);
     for (auto& f : fixes) {
       Ptr p = mk(A_WS, base.off + f.rel * 4);
-      if (f.which == 0) ops[f.op].g.w = p; else ops[f.op].unpack.part = p;
+      if (f.which == 0) ops[f.op].g.w = p; else if (f.which == 1) ops[f.op].unpack.part = p; else ops[f.op].mask.colsum = p;
     }
   }
 };
@@ -359,7 +359,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
     for (Op* op : all) {
       if (op->kind != OP_RUNGEMM || op->g.w.arena != A_WS) continue;
       const RunGemm& g = op->g;
-      const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm;
+      const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm && g.n2 == 0;
       auto it = elig.find(g.w.off);
       if (it == elig.end()) elig[g.w.off] = e; else it->second = it->second && e;
     }
@@ -399,24 +399,26 @@ void finalize_rungemms(Builder& b, Plan* P) {
     rest.insert(rest.begin(), m);
     ops->swap(rest);
   }
-  // Training plans: BOTH phases' packs in one launch at the head of the forward phase, on the second stream (they read only
-  // parameters; the backward's 57 us pass sat in the serial loss section, the forward's in front of the STFT): the first op that reads
-  // a packed matrix joins.  SEFD_PACK_EARLY=0 keeps one launch per phase at its head.
+  // Training plans: both phases' packs ride the second stream during the forward phase (they read only parameters; the backward's 57 us
+  // pass sat in the serial loss section, the forward's in front of the STFT).  The forward packs are issued first and joined by the first
+  // op that reads a packed matrix; the backward packs are issued right after that op (one launch of both slowed the STFT / spectrum
+  // kernels next to it and delayed the first GEMM by 55 us).  SEFD_PACK_EARLY=0 keeps one launch per phase at its head.
   if (!(getenv("SEFD_PACK_EARLY") && atoi(getenv("SEFD_PACK_EARLY")) == 0) && !P->fwd.empty() && !P->bwd.empty() &&
       P->fwd[0].kind == OP_PACKMULTI && P->bwd[0].kind == OP_PACKMULTI) {
-    const Pack* pf = reinterpret_cast<const Pack*>(P->consts.data() + P->fwd[0].packm.entries.off);
-    const Pack* pb = reinterpret_cast<const Pack*>(P->consts.data() + P->bwd[0].packm.entries.off);
-    std::vector<Pack> all(pf, pf + P->fwd[0].packm.count);
-    all.insert(all.end(), pb, pb + P->bwd[0].packm.count);
-    Op& m = P->fwd[0];
-    m.packm.entries = b.cst(all.data(), (int64_t)all.size() * sizeof(Pack));
-    m.packm.count = (int32_t)all.size();
-    m.lane = 2;
-    P->bwd.erase(P->bwd.begin());
+    P->fwd[0].lane = 2;
+    size_t first = 0;
     for (size_t i = 1; i < P->fwd.size(); ++i) {
       Op& op = P->fwd[i];
       if (op.lane != 0) continue;
-      if (op.kind == OP_RUNGEMM || op.kind == OP_LSTM_FWD || op.kind == OP_WGRAD) { op.join = 1; break; }
+      if (op.kind == OP_RUNGEMM || op.kind == OP_LSTM_FWD || op.kind == OP_WGRAD) { op.join = 1; first = i; break; }
+    }
+    if (first > 0) {
+      Op m = P->bwd[0];
+      m.lane = 2;
+      P->bwd.erase(P->bwd.begin());
+      P->fwd.insert(P->fwd.begin() + first + 1, m);
+    } else {
+      P->fwd[0].lane = 0;
     }
   }
   // SyncBN (cfg.bn_world > 1): every training-mode BN_FINALIZE becomes "publish this rank's sums" + "statistics from the
@@ -1027,7 +1029,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // contiguous in the channels-last buffer), zero weights where the odd phase has no tap.  These layers are bound by streaming the
     // tap-expanded activation operand through L2 -> LDS, not by MFMAs: 20 % more MACs, the operand streamed once instead of twice.
     // The backward reads only the per-phase coefficient functions.
-    const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 32;
+    const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 64;
     const bool merge = Cob <= merge_maxn && !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
     for (int par = 0; par < 2; ++par) {
       RunGemm g = Builder::gemm0();
@@ -1173,10 +1175,15 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       d_encz[i] = b.ws("enc" + std::to_string(i) + ".dz", e, adt);
       if (cfg.skip) d_skip[i] = b.ws("enc" + std::to_string(i) + ".dskip", e, adt);
     }
+    constexpr int kCsRows = 2048;                // workgroups of MASK_BWD when it also leaves the mask layer's bias-gradient shares
+    const bool mask_colsum = !(getenv("SEFD_MASK_COLSUM") && atoi(getenv("SEFD_MASK_COLSUM")) == 0) && CP >= 2 && CP <= 8 &&
+                             !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
+    int mask_colsum_op = -1;
     Ptr d_decin = b.ws("decin.d", BT * D * Cl, adt);
     {
       Mask m2 = mk;
       m2.dest = dest; m2.dmask = d_decy[n - 1];
+      if (mask_colsum) { m2.colsum_rows = kCsRows; mask_colsum_op = (int)R.size(); }
       b.push(R, OP_MASK_BWD, 500).mask = m2;
     }
     // BatchNorm backward reductions in the epilogues of the GEMMs that PRODUCE the upstream gradient (kRunBnBwd): every dgrad GEMM
@@ -1267,6 +1274,25 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
           const ParamInfo& pb = b.par(pp + part);
           for (int64_t e = 0; e < pb.numel; ++e) b.zero_grad[pb.off + e] = 1;
         }
+      } else if (mask_colsum_op >= 0) {
+        // the mask layer's bias gradient = column sums of dmask: MASK_BWD's workgroups leave their shares in the partial-sum buffer
+        // ([kCsRows][8] fp32), a SPLITSUM folds them to 128 rows and UNPACK adds those (a 110 us bias-only WGRAD pass over dmask before)
+        const int64_t rel = b.gp_off;
+        b.gp_off += (int64_t)kCsRows * 8;
+        b.fixes.push_back(Builder::Fix{mask_colsum_op, rel, 2});
+        Op& os = b.push(R, OP_SPLITSUM, 400 + d);
+        os.unpack.n = 128 * 8; os.unpack.sstride = 128 * 8; os.unpack.nsplit = kCsRows / 128;
+        os.unpack.start = os.unpack.ent = os.unpack.dst = b.none();
+        b.fixes.push_back(Builder::Fix{(int)R.size() - 1, rel, 1});
+        for (int nn = 0; nn < Co; ++nn) {
+          int32_t bt[2] = {0, 0};
+          dec[d].bias(nn, bt);
+          for (int r = 0; r < 128; ++r) {
+            const int64_t pos = rel + (int64_t)r * 8 + nn + 1;
+            for (int e = 0; e < 2; ++e)
+              if (bt[e] != 0) b.inv[std::abs(bt[e]) - 1].push_back((int32_t)(bt[e] > 0 ? pos : -pos));
+          }
+        }
       } else {
         RunGemm fb = Builder::gemm0();           // all output rows (both phases), no activation run: wgrad() appends the ones run
         fb.xdt = adt; fb.ydt = adt;
@@ -1279,6 +1305,13 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.cur_lane = 0;
       // input gradients: conv-form over dy [B][T+1][Fo][Co]; dx[ci,f,t] = sum W[ci,co,kh,kw] dy[co, 2f+kh-2, t+kw]
       const int nsrc = cfg.skip ? 2 : 1;
+      // Thin layers: ONE GEMM over dy for the input gradients of both sources (previous layer's output | skip connection): the same runs
+      // of dy, C0 + C1 output columns, the second half stored to the second destination (RunGemm::y2 / n2).  The A operand - what bounds
+      // these layers - is streamed once instead of twice.  Not when a destination's BatchNorm sums ride in the epilogue (one layer per GEMM).
+      const int dg_maxn = getenv("SEFD_DGRAD_MERGE_MAXN") ? atoi(getenv("SEFD_DGRAD_MERGE_MAXN")) : 128;
+      const bool dg_merge = nsrc == 2 && C0 == C1 && C0 % 8 == 0 && C0 + C1 <= dg_maxn && !(d > 0 && bnb_dec[d - 1].on) && !bnb_enc[idx - 1].on;
+      RunGemm dg_g[2];
+      Builder::Coef dg_coef[2];
       for (int s = 0; s < nsrc; ++s) {
         const int Cs = s == 0 ? C0 : C1;
         RunGemm g = Builder::gemm0();
@@ -1299,7 +1332,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
           const int jj = par == 0 ? (4 - kh) / 2 : (3 - kh) / 2;
           return (par == 0 ? f0 : f1)(co, s * 2 + kw, jj * Csx + nn);
         };
-        b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(s), 400 + d);
+        if (!dg_merge) b.pack_weights(R, g, coef, nm + ".dg" + std::to_string(s), 400 + d);
         if (s == 0) {
           if (d > 0) { g.y = d_decz[d - 1]; }
           else g.y = d_decin;
@@ -1310,7 +1343,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         // dz of the previous decoder layer (its y keeps the frame that `[..., 1:]` drops: rows start one frame in) / of encoder layer idx-1
         if (s == 0 && d > 0) bnb_attach(g, bnb_dec[d - 1], (int64_t)(T + 1) * Fi * Cs, Fi * Cs, Cs, Fi * Cs);
         else if (s == 1) bnb_attach(g, bnb_enc[idx - 1], (int64_t)T * Fi * Cs, Fi * Cs, Cs, 0);
-        b.push(R, OP_RUNGEMM, 400 + d).g = g;
+        if (!dg_merge) b.push(R, OP_RUNGEMM, 400 + d).g = g;
+        dg_g[s] = g; dg_coef[s] = coef;
         if (wg_swap) {                           // weight gradient, swapped form: the runs of this GEMM against the source activation
           RunGemm fw = g;
           fw.flags = 0; fw.stats = b.none(); fw.bias = b.none(); fw.ydt = adt;
@@ -1320,6 +1354,17 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
           b.wgrad(R, fw, xs.p, coef, 400 + d, nullptr);
           b.cur_lane = 0;
         }
+      }
+      if (dg_merge) {
+        RunGemm g = dg_g[0];
+        g.N = C0 + C1;
+        Builder::layout_segs(g);
+        const Builder::Coef f0 = dg_coef[0], f1 = dg_coef[1];
+        const int c0 = C0;
+        Builder::Coef coef = [=](int nn, int sg, int j) -> int32_t { return nn < c0 ? f0(nn, sg, j) : f1(nn - c0, sg, j); };
+        b.pack_weights(R, g, coef, nm + ".dgm", 400 + d);
+        g.y2 = dg_g[1].y; g.n2 = C0;
+        b.push(R, OP_RUNGEMM, 400 + d).g = g;
       }
     }
     // ---- cfg.lstm == 'real': tranform, then the two LSTM layers last to first, then the gradient into the encoder output
@@ -1590,7 +1635,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]
       // thin layers: both phases in one GEMM over the even phase's runs (see the decoder forward), unless this layer's BatchNorm sums
       // ride in the epilogue (their partial rows have one column per channel)
-      const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 32;
+      const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 64;
       if (Ci <= merge_maxn && !bnb_enc[i - 1].on) {
         RunGemm g = Builder::gemm0();
         g.x[0] = d_ency[i]; g.xdt = adt; g.ydt = adt;

@@ -382,6 +382,8 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
   }
   const float* bias = d.bias.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   char* yb = rp(ab, d.y);
+  const int n2 = d.n2 > 0 ? d.n2 : 0x7fffffff;                    // columns >= n2 leave for the second destination
+  char* yb2 = d.n2 > 0 ? rp(ab, d.y2) - (int64_t)d.n2 * (d.ydt == DT_BF16 ? 2 : 4) : yb;
   const bool want_stats = d.stats.arena >= 0;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -418,10 +420,11 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
           const int64_t o = rowoff[row];
           float v = acc[i][j][e] + bv;
           if (o >= 0 && n < d.N) {
-            if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yb)[o + n];
+            char* yd = n >= n2 ? yb2 : yb;
+            if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yd)[o + n];
             if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
-            if (d.ydt == DT_BF16) { const uint16_t hv = f2bf(v); reinterpret_cast<uint16_t*>(yb)[o + n] = hv; if (bnb) v = bf2f(hv); }
-            else reinterpret_cast<float*>(yb)[o + n] = v;
+            if (d.ydt == DT_BF16) { const uint16_t hv = f2bf(v); reinterpret_cast<uint16_t*>(yd)[o + n] = hv; if (bnb) v = bf2f(hv); }
+            else reinterpret_cast<float*>(yd)[o + n] = v;
             if (bnb) bnb_accum(bc, bslope, v, ld_elem(ybn, d.ydt, rowoffb[row] + n), s1, s2, s3);
             else { s1 += v; s2 += v * v; }
           }
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
         const int64_t o = rowoff[row];
         const int n0 = ntile * BN + cc * 8;
         if (o >= 0 && n0 < d.N)                                    // N % 8 == 0 here: a chunk is all valid or all padding
-          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(n0 >= n2 ? yb2 : yb) + o + n0) = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
       }
     } else {
       static_assert((NW * 64) % CPR == 0, "a thread keeps its chunk column");
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
         if (o < 0 || !cok) continue;
         const uint4 dzv = *reinterpret_cast<const uint4*>(otile + row * OS + cc * 8);
         const uint4 yv = ypre[k];
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = dzv;
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(n0 >= n2 ? yb2 : yb) + o + n0) = dzv;
         const uint32_t dw[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

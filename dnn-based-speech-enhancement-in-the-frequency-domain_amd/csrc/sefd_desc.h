@@ -76,7 +76,11 @@ struct RunGemm {
   // The sums are linear in dz: when dz = dz0 + dz1 (skip connection) each producer adds its own share.
   Ptr bnb_y, bnb_mi, bnb_gamma, bnb_beta, bnb_slope;
   int64_t bnb_bstride;
-  int32_t bnb_tstride, bnb_fstride, bnb_off, bnb_pad_;
+  int32_t bnb_tstride, bnb_fstride, bnb_off;
+  // n2 > 0: two destinations - output columns n >= n2 are stored to y2 at column n - n2 with the same row offsets (one GEMM over the
+  // upstream gradient produces the input gradients of BOTH sources of a decoder layer: previous layer's output and the skip connection)
+  int32_t n2;
+  Ptr y2;
 };
 static inline void fastdiv_make(uint32_t d, uint32_t* m, uint32_t* s) {
   if (d <= 1) { *m = 0; *s = 0; return; }
@@ -231,6 +235,10 @@ struct Mask {
   Ptr estm;                    // modes 3 / 5: CRN.forward's first output as [B*T][NF] fp32 (mode 3: tanh(mask) * |spec| ; mode 5, CRN
                                // 'Direct(None make)' models.py:506-517: the decoder output itself, bin 0 = 0, noisy phase re-attached)
   Ptr destm;                   // backward, modes 3 / 5, optional: gradient w.r.t. that first output (crn_direct_train's loss, trainer.py:169-170)
+  // backward, colsum_rows > 0: the launch has exactly colsum_rows workgroups and workgroup w also writes colsum[w][8] (fp32): its share of
+  // the column sums of the STORED dmask (channels 0 / 1, the rest 0) - the mask layer's conv-bias gradient without a pass over dmask
+  Ptr colsum;
+  int32_t colsum_rows, pad1_;
 };
 
 // |spec| for the CRN encoder (ConvSTFT 'real', tools_for_model.py:62-68: no eps): mags[f][MO + k] = sqrt(re^2 + im^2), k < NF;

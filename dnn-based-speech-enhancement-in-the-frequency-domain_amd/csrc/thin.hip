@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kThinWaves * 64) void rundirect_kernel(const RunGem
   const uint16_t* zp = reinterpret_cast<const uint16_t*>(rp(ab, d.zero));
   const float* biasp = d.bias.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   uint16_t* yb = reinterpret_cast<uint16_t*>(rp(ab, d.y));
+  uint16_t* yb2 = d.n2 > 0 ? reinterpret_cast<uint16_t*>(rp(ab, d.y2)) - d.n2 : yb;      // second destination of the columns n >= n2
   const bool want_stats = d.stats.arena >= 0;
   const int TF = d.Tout * d.Fo;
   const int Tin0 = d.Tin[0], Tin1 = d.Tin[1], fs0 = d.fstride[0], fs1 = d.fstride[1], rl0 = d.rowlen[0], rl1 = d.rowlen[1];
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(kThinWaves * 64) void rundirect_kernel(const RunGem
         if (mo < d.M && n0 < d.N) {
           const int bb = fdiv3(mo, d.div_tf_m, d.div_tf_s), rem2 = mo - bb * TF, uu = fdiv3(rem2, d.div_fo_m, d.div_fo_s), ff = rem2 - uu * d.Fo;
           const int64_t o = (int64_t)bb * d.y_bstride + (int64_t)uu * d.y_tstride + (int64_t)ff * d.y_fstride + d.y_off;
-          *reinterpret_cast<uint4*>(yb + o + n0) = v;
+          *reinterpret_cast<uint4*>((d.n2 > 0 && n0 >= d.n2 ? yb2 : yb) + o + n0) = v;
           if constexpr (BNB) {
             const uint4 yv = *reinterpret_cast<const uint4*>(ybn + (int64_t)bb * d.bnb_bstride + (int64_t)uu * d.bnb_tstride + (int64_t)ff * d.bnb_fstride + d.bnb_off + n0);
             const uint32_t dw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};

@@ -280,7 +280,7 @@ bool launch_winconv(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   const char* em = getenv("SEFD_WINCONV_MINM");
   const int minm = em ? atoi(em) : 65536;
   if (!on || d.xdt != DT_BF16 || d.ydt != DT_BF16 || !(d.flags & kRunAligned) || !(d.flags & kRunYAligned)) return false;
-  if ((d.flags & (kRunAccum | kRunRelu | kRunWTile32 | kRunBnBwd)) || d.Npad > 64 || d.M < minm) return false;
+  if ((d.flags & (kRunAccum | kRunRelu | kRunWTile32 | kRunBnBwd)) || d.n2 > 0 || d.Npad > 64 || d.M < minm) return false;
   if (d.Fo != 64 && d.Fo != 128) return false;
   if (d.Npad == 64 && d.Fo != 64) return false;              // (the address table of the two-row-block variant assumes identical halves)
   if (d.M % d.Fo != 0 || d.ldw % 8 != 0) return false;

@@ -41,7 +41,7 @@ inline double a_elem(const RunGemm& d, const AB& ab, const Seg& sg, int b, int u
 void rungemm(const RunGemm& d, const AB& ab) {
   const char* w = rp(ab, d.w);
   const float* bias = d.bias.arena >= 0 ? (const float*)rp(ab, d.bias) : nullptr;
-  char* y = rp(ab, d.y);
+  char* y1 = rp(ab, d.y);
   const int TF = d.Tout * d.Fo;
   const int nblk = (d.M + kBM - 1) / kBM;
   std::vector<double> s1, s2, s3;
@@ -58,10 +58,13 @@ void rungemm(const RunGemm& d, const AB& ab) {
     for (int s = 0; s < d.nseg; ++s)
       for (int j = 0; j < d.seg[s].len; ++j) arow[d.seg[s].koff + j] = a_elem(d, ab, d.seg[s], b, u, fo, j);
     const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
-    for (int n = 0; n < d.N; ++n) {
+    for (int nn = 0; nn < d.N; ++nn) {
       double acc = 0.0;
-      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, w_index(d.flags, d.ldw, d.Npad, n, k));
-      float v = (float)acc + (bias ? bias[n] : 0.f);
+      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, w_index(d.flags, d.ldw, d.Npad, nn, k));
+      float v = (float)acc + (bias ? bias[nn] : 0.f);
+      const bool second = d.n2 > 0 && nn >= d.n2;             // two destinations: columns >= n2 go to y2 at column n - n2
+      char* y = second ? rp(ab, d.y2) : y1;
+      const int n = second ? nn - d.n2 : nn;
       if (d.flags & kRunAccum) v += ((const float*)y)[o + n];
       if (d.flags & kRunRelu) v = v > 0.f ? v : 0.f;
       st(y, d.ydt, o + n, v);
@@ -860,6 +863,7 @@ void run_op(const Op& op, const AB& ab) {
       const int NB = d.NF - 1, NS = d.NF + 1;
       const int lead = (int)(d.mask_base / d.mask_fstride), TT = d.T + lead;
       const int64_t B = d.frames / d.T;
+      double csum[2] = {0, 0};
       for (int64_t b = 0; b < B; ++b)
         for (int u = 0; u < TT; ++u)
           for (int k = 0; k < NB; ++k) {
@@ -893,7 +897,14 @@ void run_op(const Op& op, const AB& ab) {
             }
             st(rp(ab, d.dmask), d.mdt, mo, (float)gr);
             if (d.mch >= 2) st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
+            csum[0] += ld(rp(ab, d.dmask), d.mdt, mo);
+            if (d.mch >= 2) csum[1] += ld(rp(ab, d.dmask), d.mdt, mo + 1);
           }
+      if (d.colsum_rows > 0) {                   // the kernel spreads the column sums over its workgroups; any split with the same total will do
+        float* cs = (float*)rp(ab, d.colsum);
+        std::fill(cs, cs + (int64_t)d.colsum_rows * 8, 0.f);
+        cs[0] = (float)csum[0]; cs[1] = (float)csum[1];
+      }
       break;
     }
     case OP_OLA_FWD: {

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -x -q -m gpu -k "DCCRN or dccrn" > $O/n_tests.log 2>&1; echo "rc=$?" >> $O/n_tests.log; tail -3 $O/n_tests.log
+run() { echo "== $1"; env $1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c60-175; }
+run A=1
+run SEFD_GX_MERGE=0
+run SEFD_LSTM_CHUNKS=6
+run SEFD_LSTM_CHUNKS=8
+run SEFD_PHASE_MERGE_MAXN=64
+run SEFD_PHASE_MERGE_MAXN=128
+run A=2
+cd /tmp && export TMPDIR=/tmp
+B="python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_n -o n -- $B > $O/n_prof.log 2>&1
+cd $GRAFT_REPO_ROOT; python tools/timeline.py $O/prof_n/n_kernel_trace.csv 1 v > $O/n_timeline.txt 2>&1; head -3 $O/n_timeline.txt
