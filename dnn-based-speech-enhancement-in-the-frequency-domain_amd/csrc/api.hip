@@ -95,6 +95,7 @@ int32_t sefd_plan_op_info(const sefd_plan* h, int phase, int i, int64_t* o) {
     const StftFft& f = op.fft;
     o[2] = (int64_t)f.B * f.T; o[3] = 257; o[4] = 512;
     o[7] = (int64_t)f.B * f.L * 4 + (int64_t)f.B * f.T * 258 * 8;
+    if (f.lp.arena >= 0) o[7] += (int64_t)f.B * f.T * 258 * 8 * esize(f.lp_dt);     // + the channel-padded copy for the first encoder layer (8 channels per bin)
   } else if (op.kind == OP_ISTFT_FFT) {
     o[2] = op.ifft.nframes; o[3] = op.ifft.W; o[4] = 512;
     o[7] = op.ifft.nframes * (258 * 8 + (int64_t)op.ifft.W * 4);
@@ -141,6 +142,7 @@ int32_t sefd_plan_run_timed(const sefd_plan* h, int phase, void* const* arenas, 
 static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
                         std::vector<hipEvent_t>* tev) {
   if (!h || !h->p->error.empty()) return -1;
+  if (sefd::lstm_cluster_take_status() != 0) return -5;  // an earlier cluster-LSTM launch gave up waiting for a peer: its results (and everything after) are garbage
   const std::vector<Op>& ops = phase == 0 ? h->p->fwd : h->p->bwd;
   if (first < 0) first = 0;
   if (last < 0 || last > (int)ops.size()) last = (int)ops.size();

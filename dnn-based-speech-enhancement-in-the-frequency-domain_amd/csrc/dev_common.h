@@ -141,6 +141,7 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);
 void launch_lstm_cluster(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);   // H > 128 (lstm_cluster.hip)
+int lstm_cluster_take_status();  // 1 once after a cluster launch whose hand-over wait ran out of budget (host-mapped word, read and cleared)
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);      // impl == 1 (lstm_rows.hip)
 
 }  // namespace sefd

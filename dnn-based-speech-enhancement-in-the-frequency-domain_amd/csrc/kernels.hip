@@ -53,9 +53,15 @@ __global__ void packmulti_kernel(const PackMulti m, const ArenaBases ab) {
 // Sum of the nsplit row-split partials of a WGRAD (deterministic order).  A workgroup owns 64 consecutive elements:
 // 16 lanes x float4 along the elements, 16 lanes along the splits (thin layers have 768 splits of only 8 K elements, so
 // parallelism has to come from the split axis), then a fixed-order 16-way combine through LDS.
-__global__ __launch_bounds__(256) void splitsum_kernel(const Unpack d, const ArenaBases ab) {
+__global__ __launch_bounds__(256) void splitsum_kernel(Unpack d, const ArenaBases ab) {
   __shared__ float4 red[16][16];
   float* part = reinterpret_cast<float*>(rp(ab, d.part));
+  if (d.nseg > 0) {                                  // table form: blockIdx.y picks the segment (wave-uniform)
+    const int64_t* seg = reinterpret_cast<const int64_t*>(rp(ab, d.start)) + 3 * (int64_t)blockIdx.y;
+    part += seg[0];
+    d.n = d.sstride = seg[1];
+    d.nsplit = (int32_t)seg[2];
+  }
   const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
   const bool vec = (d.n & 3) == 0 && (d.sstride & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
   for (int64_t base = (int64_t)blockIdx.x * 64; base < d.n; base += (int64_t)gridDim.x * 64) {
@@ -989,7 +995,9 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_PACKMULTI:
       hipLaunchKernelGGL(packmulti_kernel, dim3(128, op.packm.count), dim3(256), 0, st, op.packm, ab); break;
     case OP_SPLITSUM:
-      hipLaunchKernelGGL(splitsum_kernel, dim3((unsigned)std::min<int64_t>((op.unpack.n + 63) / 64, 8192)), dim3(256), 0, st, op.unpack, ab); break;
+      hipLaunchKernelGGL(splitsum_kernel, dim3((unsigned)std::min<int64_t>((op.unpack.n + 63) / 64, op.unpack.nseg > 0 ? 1024 : 8192), std::max(1, op.unpack.nseg)),
+                         dim3(256), 0, st, op.unpack, ab);
+      break;
     case OP_UNPACK:
       hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(op.unpack.n)), dim3(256), 0, st, op.unpack, ab); break;
     case OP_BN_FINALIZE: {

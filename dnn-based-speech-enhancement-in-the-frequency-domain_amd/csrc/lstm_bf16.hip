@@ -171,13 +171,17 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_fwd_bf16_kernel(const LstmRec d
   if (t < te) { step(t, b1v, b0v); ++t; }
 }
 
-template <int HMAX>
+// RPW as in the forward kernel.  4: the sequences sit in rows 0, 4, 8, 12 of the dgates tile (A operand), so the accumulator row a lane
+// reads back (row 4*kq of dh_{t-1} = dgates_t . W_hh) is the ONE cell whose gate gradients it forms: a quarter of the loads and of the
+// gate math per lane and four times the workgroups (DCCRN step: 8 -> 32 of 256 CUs).  Same operations in the same order per element.
+template <int HMAX, int RPW>
 __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d, const ArenaBases ab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t ldsh[];
   constexpr int H = HMAX;
   const int T = d.T;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int g = blockIdx.y, b0 = blockIdx.x * 16;
+  const int g = blockIdx.y, b0 = blockIdx.x * RPW;
+  constexpr int NR = RPW == 16 ? 4 : 1;            // cells per lane
   const float* whh = reinterpret_cast<const float*>(rp(ab, d.whh[g % d.nset]));
   const float* gates = reinterpret_cast<const float*>(rp(ab, d.gates));
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
@@ -202,47 +206,56 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
     }
     wreg[ks] = v;
   }
-  bool rvalid[4];
-  int64_t fo[4];                                // fetch position: (g*GBT + row*T + t) * H + unit
+  if constexpr (RPW != 16) {                     // tile rows that hold no sequence are multiplied too (results unused): keep them finite
+    for (int i = threadIdx.x; i < 16 * gs; i += blockDim.x) ldsh[i] = 0;
+    __syncthreads();
+  }
+  bool rvalid[NR];
+  int64_t fo[NR];                               // fetch position: (g*GBT + row*T + t) * H + unit
   const int64_t GBT = (int64_t)d.B * T;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * kq + r;
+  for (int r = 0; r < NR; ++r) {
+    const int b = RPW == 16 ? b0 + 4 * kq + r : b0 + kq;
     rvalid[r] = b < d.B;
     fo[r] = ((int64_t)g * GBT + (int64_t)(rvalid[r] ? b : 0) * T + (T - 1)) * H + unit;   // rows >= B alias row 0, results unused
   }
-  // dgates_t leave through the LDS tile with 16-byte stores: 16 rows x H/2 chunks = 2 chunks per thread (rows w', w'+8)
+  // dgates_t leave through the LDS tile with 16-byte stores: H/2 chunks per sequence; RPW 16: 2 chunks per thread (tile rows w', w'+8),
+  // RPW 4: threads 0 .. 2H-1 move one chunk each (tile rows 0, 4, 8, 12)
   constexpr int CPR = H / 2;
+  constexpr int ND = RPW == 16 ? 2 : 1;
   const int crow = threadIdx.x / CPR, cc8 = threadIdx.x % CPR;
-  uint16_t* dptr[2];
-  bool dvalid[2];
+  uint16_t* dptr[ND];
+  bool dvalid[ND];
+  int drow[ND];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int b = b0 + crow + 8 * i;
-    dvalid[i] = b < d.B;
+  for (int i = 0; i < ND; ++i) {
+    const int b = RPW == 16 ? b0 + crow + 8 * i : b0 + crow;
+    drow[i] = RPW == 16 ? crow + 8 * i : 4 * (crow & 3);
+    dvalid[i] = b < d.B && (RPW == 16 || crow < 4);
     dptr[i] = dgo + d.gx_goff[g] + ((int64_t)(dvalid[i] ? b : 0) * T + (T - 1)) * d.gx_ld + cc8 * 8;
   }
   const int64_t gx_ld = d.gx_ld;
 
-  float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+  float dcarry[NR] = {};
   f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
   // software prefetch ring, two steps of look-ahead (one step does not cover an HBM round trip); unrolled, no copies
-  struct Sav { float4 g[4]; float cp[4], dh[4]; };
+  struct Sav { float4 g[NR]; float cp[NR], dh[NR]; };
   auto fetch = [&](int t_, Sav& s) {            // reads the current position, then steps back one frame (stays at frame 0)
     const int64_t back = t_ > 0 ? H : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR; ++r) {
       s.g[r] = *reinterpret_cast<const float4*>(gates + fo[r] * 4);
       s.cp[r] = cs[fo[r] - back];
       s.dh[r] = dh[fo[r]];
       fo[r] -= back;
     }
   };
-  float pct[4];
+  float pct[NR];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pct[r] = cs[fo[r]];
+  for (int r = 0; r < NR; ++r) pct[r] = cs[fo[r]];
   auto step = [&](int t, const Sav& cur, Sav& pre) {
     fetch(t - 2, pre);
+    if constexpr (RPW == 16) {
 #pragma unroll
     for (int rp2 = 0; rp2 < 4; rp2 += 2) {
       const f32x2 ig = {cur.g[rp2].x, cur.g[rp2 + 1].x}, fg = {cur.g[rp2].y, cur.g[rp2 + 1].y};
@@ -267,10 +280,25 @@ __global__ __launch_bounds__(HMAX * 4) void lstm_bwd_bf16_kernel(const LstmRec d
             v ? make_uint2(pack2(di[k], df[k]), pack2(dg[k], dog[k])) : make_uint2(0u, 0u);
       }
     }
+    } else {                                      // the same expressions, one cell
+      const float ig = cur.g[0].x, fg = cur.g[0].y, gg = cur.g[0].z, og = cur.g[0].w;
+      const float cp = t > 0 ? cur.cp[0] : 0.f;
+      const float dht = cur.dh[0] + dhrec[0];
+      const float tc = __builtin_fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(pct[0] * 2.8853900817779268f) + 1.f), -2.f, 1.f);
+      const float dog = dht * tc * og * (1.f - og);
+      const float dc = dht * og * (1.f - tc * tc) + dcarry[0];
+      const float di = dc * gg * ig * (1.f - ig);
+      const float df = dc * cp * fg * (1.f - fg);
+      const float dg = dc * ig * (1.f - gg * gg);
+      const bool v = rvalid[0];
+      dcarry[0] = v ? dc * fg : 0.f;
+      pct[0] = cur.cp[0];
+      *reinterpret_cast<uint2*>(ldsh + 4 * kq * gs + gate_col(0, unit)) = v ? make_uint2(pack2(di, df), pack2(dg, dog)) : make_uint2(0u, 0u);
+    }
     lds_barrier();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (dvalid[i]) *reinterpret_cast<uint4*>(dptr[i]) = *reinterpret_cast<const uint4*>(ldsh + (crow + 8 * i) * gs + cc8 * 8);
+    for (int i = 0; i < ND; ++i) {
+      if (dvalid[i]) *reinterpret_cast<uint4*>(dptr[i]) = *reinterpret_cast<const uint4*>(ldsh + drow[i] * gs + cc8 * 8);
       dptr[i] -= gx_ld;
     }
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -305,11 +333,16 @@ template <int HMAX>
 static void launch_t(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
   dim3 grid((d.B + 15) / 16, d.G);
   dim3 block(64 * (d.H / 16));
-  static const int rpw_env = getenv("SEFD_LSTM_RPW") ? atoi(getenv("SEFD_LSTM_RPW")) : 0;
+  // SEFD_LSTM_RPW = 4 / 16 forces a variant for both directions, SEFD_LSTM_RPW_BWD for the backward alone (read per launch: the per-op test
+  // runs both variants in one process)
+  const char* ev = getenv("SEFD_LSTM_RPW");
+  const char* evb = getenv("SEFD_LSTM_RPW_BWD");
+  const int rpw_env = !fwd && evb ? atoi(evb) : ev ? atoi(ev) : 0;
   const bool spread = rpw_env ? rpw_env == 4 : (int64_t)((d.B + 3) / 4) * d.G <= 1024;      // one cell per lane while the chip has CUs to spare
   if (fwd && spread) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX, 4>), dim3((d.B + 3) / 4, d.G), block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);
   else if (fwd) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX, 16>), grid, block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);
-  else hipLaunchKernelGGL((lstm_bwd_bf16_kernel<HMAX>), grid, block, 16 * (4 * d.H + 8) * sizeof(uint16_t), st, d, ab);
+  else if (spread) hipLaunchKernelGGL((lstm_bwd_bf16_kernel<HMAX, 4>), dim3((d.B + 3) / 4, d.G), block, 16 * (4 * d.H + 8) * sizeof(uint16_t), st, d, ab);
+  else hipLaunchKernelGGL((lstm_bwd_bf16_kernel<HMAX, 16>), grid, block, 16 * (4 * d.H + 8) * sizeof(uint16_t), st, d, ab);
 }
 
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {

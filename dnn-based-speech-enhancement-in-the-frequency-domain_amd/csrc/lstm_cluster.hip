@@ -15,7 +15,8 @@
 // Per step a wave issues H/8 (forward) MFMAs of 16 cycles; the step time is the hand-off latency plus that, ~2-3 us, against
 // ~50 us for the GEMM + cell launch pair per step this replaces (DCCRN-large: 203 ms of a 229 ms step).
 // Dispatch order: cluster members are consecutive block ids, so a partially resident cluster only ever waits for blocks that
-// are next in the dispatch queue; every spin is bounded (a latched budget) so a lost block cannot hang the device.
+// are next in the dispatch queue; every spin is bounded (a latched budget) so a lost block cannot hang the device; a wave whose budget ran out reports it
+// in a host-mapped status word and the next sefd_plan_run returns -5 (lstm_cluster_take_status).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
@@ -66,6 +67,12 @@ __device__ __forceinline__ void gather(__amdgpu_buffer_rsrc_t r, uint32_t off0, 
   }
 }
 
+// A wave that spent its whole budget consumed fragments its peers had not written: the launch's results are garbage.  It says so in a
+// host-mapped status word (system-scope store) that the next sefd_plan_run reads on the host - the step fails loudly instead of training on NaNs.
+__device__ __forceinline__ void report_timeout(int* status, int budget) {
+  if (budget <= 0 && (threadIdx.x & 63) == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- forward
@@ -77,7 +84,7 @@ __device__ __forceinline__ void gather(__amdgpu_buffer_rsrc_t r, uint32_t off0, 
 constexpr int kMaxMT = 8;
 
 template <int H, bool PF>
-__global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT) {
+__global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT, int* status) {
   constexpr int KS = H / 32;
   constexpr int HAS = H + 8, HCPR = H / 8, HNCH = (16 * HCPR + 255) / 256;      // cooperative gather tile: row stride, chunks per row / thread
   __shared__ __attribute__((aligned(16))) uint16_t htile[PF ? 8 : 2 * 16 * HAS];
@@ -271,13 +278,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
   }
   if (n < ntile) { tile(b0v, b2v); ++n; }
   if (n < ntile) { tile(b1v, b0v); ++n; }
+  report_timeout(status, budget);
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
 // Tile (t, mt), frames last to first: dh_rec = dgates_{t+1}[tile] . W_hh (gathered first: the peers stored it MT tiles ago),
 // then the cell backward of frame t, whose dgates_t leave write-through for the peers' (and this wave's) tile (t-1, mt).
 template <int H>
-__global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT) {
+__global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT, int* status) {
   constexpr int KS = 4 * H / 32;                 // k32 steps over the 4H gate columns
   constexpr int AS = 4 * H + 8, CPR = 4 * H / 8, NCH = 16 * CPR / 256;   // LDS tile row stride, 16-byte chunks per row, chunks per thread
   constexpr bool DB = H <= 448;                  // two tiles (ping-pong, one barrier per tile) while 2 x 16 x 4H bf16 fits next to the rest
@@ -438,6 +446,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, 
   }
   if (n < ntile) { tile(s0, s2); ++n; }
   if (n < ntile) { tile(s1, s0); ++n; }
+  report_timeout(status, budget);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ launch
@@ -471,15 +480,36 @@ static int pick_mt(const LstmRec& d, int nc) {
   return best;
 }
 
+// Host-mapped status word of the cluster kernels (0: fine; 1: a hand-over wait ran out of budget in some launch since the last check).
+static int* cluster_status_word() {
+  static int* w = [] {
+    int* q = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&q), sizeof(int), hipHostMallocMapped) != hipSuccess) return static_cast<int*>(nullptr);
+    *q = 0;
+    return q;
+  }();
+  return w;
+}
+static bool g_cluster_used = false;
+int lstm_cluster_take_status() {               // read and clear (host side; kernels that set it have long finished or are about to be re-run)
+  if (!g_cluster_used) return 0;
+  int* w = cluster_status_word();
+  if (!w) return 0;
+  const int v = __atomic_exchange_n(w, 0, __ATOMIC_RELAXED);
+  return v;
+}
+
 template <int H>
 static void launch_c(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
+  int* status = cluster_status_word();
+  g_cluster_used = true;
   const int mt = pick_mt(d, H / 64);
   const dim3 grid(H / 64, (d.B + 16 * mt - 1) / (16 * mt), d.G);
   if (fwd) {
-    if constexpr (H <= 384) { if (mt > 1) { hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, true>), grid, dim3(256), 0, st, d, ab, mt); return; } }
-    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, false>), grid, dim3(256), 0, st, d, ab, mt);
+    if constexpr (H <= 384) { if (mt > 1) { hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, true>), grid, dim3(256), 0, st, d, ab, mt, status); return; } }
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, false>), grid, dim3(256), 0, st, d, ab, mt, status);
   } else {
-    hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab, mt);
+    hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab, mt, status);
   }
 }
 

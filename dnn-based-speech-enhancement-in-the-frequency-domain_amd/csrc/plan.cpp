@@ -170,8 +170,8 @@ struct Builder {
     for (size_t j = 0; j < win.size(); ++j) wf[j] = (float)win[j];
     Op& op = push(ops, OP_STFT_FFT, tag);
     op.fft.src = src; op.fft.spec = spec; op.fft.tw = fft_tw; op.fft.win = cst(wf.data(), 2048);
-    op.fft.B = B; op.fft.L = L; op.fft.T = T; op.fft.hop = hop; op.fft.off = off; op.fft.pad_ = 0;
-    op.fft.corr = none(); op.fft.scale = 1.f;
+    op.fft.B = B; op.fft.L = L; op.fft.T = T; op.fft.hop = hop; op.fft.off = off; op.fft.lp_dt = 0;
+    op.fft.corr = none(); op.fft.scale = 1.f; op.fft.lp = none();
     return true;
   }
   Ptr fft_tw = Ptr{-1, 0, 0};
@@ -214,8 +214,8 @@ struct Builder {
     if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM") || fft_tw.arena < 0) return false;
     Op& op = push(ops, OP_STFT_FFT, tag);
     op.fft.src = dpad; op.fft.spec = dest; op.fft.tw = fft_tw; op.fft.win = win512(win);
-    op.fft.B = B; op.fft.L = Lp; op.fft.T = T; op.fft.hop = hop; op.fft.off = 0; op.fft.pad_ = 0;
-    op.fft.corr = istft_corr((int)win.size()); op.fft.scale = 1.f / 256.f;
+    op.fft.B = B; op.fft.L = Lp; op.fft.T = T; op.fft.hop = hop; op.fft.off = 0; op.fft.lp_dt = 0;
+    op.fft.corr = istft_corr((int)win.size()); op.fft.scale = 1.f / 256.f; op.fft.lp = none();
     return true;
   }
 
@@ -256,14 +256,7 @@ struct Builder {
     Op& op = push(ops, OP_WGRAD, tag);
     op.g = g;
     fixes.push_back(Fix{(int)ops.size() - 1, rel, 0});
-    if (ns > 1) {
-      Op& os = push(ops, OP_SPLITSUM, tag);
-      os.unpack.n = sz;
-      os.unpack.sstride = sz;
-      os.unpack.nsplit = ns;
-      os.unpack.start = os.unpack.ent = os.unpack.dst = none();
-      fixes.push_back(Fix{(int)ops.size() - 1, rel, 1});
-    }
+    if (ns > 1) split_sum(ops, rel, sz, ns, tag);
     // inverse table
     for (int n = 0; n < g.N; ++n) {
       for (int s = 0; s < g.nseg; ++s) {
@@ -286,11 +279,49 @@ struct Builder {
     }
   }
 
+  // Split sums: nothing reads a weight gradient's partial sums before the UNPACK that gathers them, so the folds of ALL weight gradients
+  // planned since the last UNPACK wait in `pending_sums` and become ONE table-driven SPLITSUM launch in front of it (43 launches of
+  // 6-20 us on the weight-gradient lane before: 0.37 ms per step).  SEFD_SPLITSUM_MULTI=0 plans one SPLITSUM behind every WGRAD again.
+  struct SumSeg { int64_t rel, n, ns; };
+  std::vector<SumSeg> pending_sums;
+  void split_sum(std::vector<Op>& ops, int64_t rel, int64_t n, int64_t ns, int tag) {
+    static const bool multi = !(getenv("SEFD_SPLITSUM_MULTI") && atoi(getenv("SEFD_SPLITSUM_MULTI")) == 0);
+    if (multi) { pending_sums.push_back(SumSeg{rel, n, ns}); return; }
+    Op& os = push(ops, OP_SPLITSUM, tag);
+    os.unpack.n = n;
+    os.unpack.sstride = n;
+    os.unpack.nsplit = (int32_t)ns;
+    os.unpack.start = os.unpack.ent = os.unpack.dst = none();
+    fixes.push_back(Fix{(int)ops.size() - 1, rel, 1});
+  }
+  // side = true: the launch rides the weight-gradient lane behind the WGRADs it folds (a pure HBM stream next to the other lane's GEMMs);
+  // false: main stream, which first waits for the weight-gradient lane (the fold in front of an UNPACK)
+  void flush_sums(std::vector<Op>& ops, int tag, bool side = false) {
+    if (pending_sums.empty()) return;
+    std::vector<int64_t> tab;
+    int64_t nmax = 0;
+    for (const SumSeg& sg : pending_sums) { tab.push_back(sg.rel); tab.push_back(sg.n); tab.push_back(sg.ns); nmax = std::max(nmax, sg.n); }
+    const int save = cur_lane;
+    cur_lane = side ? 1 : 0;
+    Op& os = push(ops, OP_SPLITSUM, tag);
+    cur_lane = save;
+    os.join = side ? 0 : 1;                                // the partial sums come from the weight-gradient lane
+    os.unpack.start = cst(tab.data(), (int64_t)tab.size() * 8);     // int64 [nseg][3]: offset from the partial-sum base, elements, splits
+    os.unpack.ent = os.unpack.dst = none();
+    os.unpack.n = nmax;
+    os.unpack.sstride = 0;
+    os.unpack.nsplit = 0;
+    os.unpack.nseg = (int32_t)pending_sums.size();
+    fixes.push_back(Fix{(int)ops.size() - 1, 0, 1});
+    pending_sums.clear();
+  }
+
   int64_t unpack_lo = 0;                                   // flat gradient elements below this are still to be unpacked
   int64_t unpack_hi = -1;                                  // (set by unpack_range: elements [unpack_hi, end) are already done)
   // UNPACK of the flat gradient elements [lo, hi): every weight gradient GEMM that contributes to them must have been planned.
   // The partial-sum base is not known yet (finish_unpack allocates it): recorded as a fix-up.
   void unpack_range(std::vector<Op>& ops, int64_t lo, int64_t hi, int tag) {
+    flush_sums(ops, tag);
     const int64_t n = hi - lo;
     std::vector<int32_t> start(n + 1, 0), ent;
     for (int64_t j = 0; j < n; ++j) {
@@ -612,7 +643,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // ------------------------------------------------------------------ STFT (ConvSTFT.forward, tools_for_model.py:54-61)
   Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
   Ptr spec_lp = spec;
-  if (!b.stft_fft(F, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win)) {
+  const bool spec_fft = b.stft_fft(F, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win);
+  if (!spec_fft) {
     RunGemm g = Builder::gemm0();
     g.x[0] = io_wav; g.xdt = DT_F32; g.ydt = DT_F32;
     g.bstride[0] = L; g.tstride[0] = 0; g.base[0] = 0; g.rowlen[0] = L; g.fstride[0] = hop; g.Tin[0] = 1;
@@ -628,8 +660,13 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   const int CP = 8;
   {
     spec_lp = b.ws("xin", (int64_t)B * T * NS * CP, adt);
-    Op& op = b.push(F, OP_SPECPAD, 1);
-    op.mags.spec = spec; op.mags.mags = spec_lp; op.mags.frames = (int64_t)B * T; op.mags.NF = NS; op.mags.MS = CP; op.mags.MO = 0; op.mags.dt = adt;
+    static const bool fuse_pad = !(getenv("SEFD_SPECPAD_FUSE") && atoi(getenv("SEFD_SPECPAD_FUSE")) == 0);
+    if (spec_fft && fuse_pad && NS == 258) {      // the FFT kernel writes the padded copy beside the spectrogram (no SPECPAD pass: 48 us at B = 32)
+      F.back().fft.lp = spec_lp; F.back().fft.lp_dt = adt;
+    } else {
+      Op& op = b.push(F, OP_SPECPAD, 1);
+      op.mags.spec = spec; op.mags.mags = spec_lp; op.mags.frames = (int64_t)B * T; op.mags.NF = NS; op.mags.MS = CP; op.mags.MO = 0; op.mags.dt = adt;
+    }
   }
 
   // ------------------------------------------------------------------ encoder
@@ -1280,10 +1317,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         const int64_t rel = b.gp_off;
         b.gp_off += (int64_t)kCsRows * 8;
         b.fixes.push_back(Builder::Fix{mask_colsum_op, rel, 2});
-        Op& os = b.push(R, OP_SPLITSUM, 400 + d);
-        os.unpack.n = 128 * 8; os.unpack.sstride = 128 * 8; os.unpack.nsplit = kCsRows / 128;
-        os.unpack.start = os.unpack.ent = os.unpack.dst = b.none();
-        b.fixes.push_back(Builder::Fix{(int)R.size() - 1, rel, 1});
+        b.split_sum(R, rel, 128 * 8, kCsRows / 128, 400 + d);
         for (int nn = 0; nn < Co; ++nn) {
           int32_t bt[2] = {0, 0};
           dec[d].bias(nn, bt);
@@ -1616,6 +1650,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // ---- data-parallel overlap: the gradients of decoder + LSTM (flat range [decoder.0 ..., end)) are complete here - every
     // weight gradient GEMM and BatchNorm parameter gradient that writes them has been planned above.  Their UNPACK goes here, so
     // a caller can start their all-reduce while the encoder backward still runs (sefd_plan_grad_bucket / sefd_plan_run_cb).
+    // The folds of the decoder + LSTM weight gradients (3/4 of the 1.2 GB of partial sums of a step) go here, on the weight-gradient lane:
+    // a bandwidth-bound pass beside the encoder's input-gradient GEMMs instead of in front of the final UNPACK on the main stream.
+    if (!(getenv("SEFD_SPLITSUM_MID") && atoi(getenv("SEFD_SPLITSUM_MID")) == 0)) b.flush_sums(R, 997, true);
     if (cfg.grad_buckets >= 2) {
       const int64_t lo = b.par("decoder.0.0.real_conv.weight").off;
       b.unpack_range(R, lo, nparam, 998);

@@ -123,7 +123,9 @@ struct Unpack {
   Ptr start, ent, part, dst;   // start: int32[n+1]; ent: int32[]; part: fp32 ; dst fp32
   int64_t n;                   // SPLITSUM: elements per split ; UNPACK: number of gradient elements written
   int64_t sstride;             // elements between splits
-  int32_t nsplit, pad_;
+  int32_t nsplit;
+  int32_t nseg;                // SPLITSUM with nseg > 0: `start` is an int64 [nseg][3] table (offset from `part` in elements, elements per
+                               // split, splits; split stride = elements) - the folds of many weight gradients in one launch; n = largest segment
 };
 
 // BatchNorm2d (training) + PReLU on channels-last rows [R][C].
@@ -277,7 +279,11 @@ struct Memset {
 // spec [B][T][258][2] (slot 0 = 0).  tw: fp32 (cos, sin)(2 pi k / 512), k < 512 ; win: fp32 [512]  (both A_CONST).
 struct StftFft {
   Ptr src, spec, tw, win;
-  int32_t B, L, T, hop, off, pad_;
+  int32_t B, L, T, hop, off;
+  int32_t lp_dt;               // dtype of `lp`
+  // Optional second output (plain STFT only): the channel-padded copy [frames][258][8] (re, im, 0 x 6) in the activation dtype that the
+  // first encoder layer reads (16-byte runs for its LDS-DMA loader) - a separate SPECPAD pass over the spectrogram otherwise.  A_NONE: absent.
+  Ptr lp;
   // Backward of the pinv synthesis (ConviSTFT, tools_for_model.py:64-112): d spec = Kinv . d frames is the SAME transform of
   // the padded waveform gradient, with a rank-2 term and the 1/256:  out[part][k] = scale * ( FFT(v)[part][k]
   //   - cE[part][k] * sum_{n even} v[n] - cO[part][k] * sum_{n odd} v[n] ),  v = windowed frame.  corr = A_NONE: plain STFT.

@@ -106,22 +106,51 @@ __global__ __launch_bounds__(256) void stft_fft_kernel(const StftFft d, const Ar
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float v = raw[f][j] * wn[j]; x[j] = {v, 0.f}; vs += v; }
     fft512_wave(x, X, lds[wv], twl, lane);
+    // Bins leave in bin order: the transform ends with lane l holding bins (l >> 3) + 8 (l & 7) + 64 mb - stored from there every store
+    // instruction touched 64 different 64-byte segments (and 64 different lines of the padded copy).  One more pass through the wave's LDS
+    // slice (conflict-free: (l >> 3) + 8 (l & 7) is a permutation of 0..63) and lane l stores bins l + 64 j: whole lines per instruction.
+    float2* buf = lds[wv];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) buf[k0 + 8 * ma + 64 * mb] = make_float2(X[mb].x, X[mb].y);
+    const cf x256 = X[4];                                    // bin 256: lane 0 (k0 = ma = 0, mb = 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float2 Y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y[j] = buf[lane + 64 * j];
     float2* out = spec + fr * 258;
     if (d.corr.arena >= 0) {                                 // backward of the pinv synthesis (see sefd_desc.h)
       const float* cr = reinterpret_cast<const float*>(rp(ab, d.corr));
       const float ge = wave_sum((lane & 1) ? 0.f : vs), go = wave_sum((lane & 1) ? vs : 0.f);   // n = lane + 64 j has the parity of lane
 #pragma unroll
-      for (int mb = 0; mb < 5; ++mb) {
-        const int k = k0 + 8 * ma + 64 * mb;
-        if (k <= 256)
-          out[1 + k] = make_float2(d.scale * (X[mb].x - cr[k] * ge - cr[2 * 257 + k] * go),
-                                   d.scale * (X[mb].y - cr[257 + k] * ge - cr[3 * 257 + k] * go));
+      for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        out[1 + k] = make_float2(d.scale * (Y[j].x - cr[k] * ge - cr[2 * 257 + k] * go),
+                                 d.scale * (Y[j].y - cr[257 + k] * ge - cr[3 * 257 + k] * go));
       }
-      if (lane == 0) out[0] = make_float2(0.f, 0.f);
+      if (lane == 0) {
+        out[1 + 256] = make_float2(d.scale * (x256.x - cr[256] * ge - cr[2 * 257 + 256] * go),
+                                   d.scale * (x256.y - cr[257 + 256] * ge - cr[3 * 257 + 256] * go));
+        out[0] = make_float2(0.f, 0.f);
+      }
     } else {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) out[1 + k0 + 8 * ma + 64 * mb] = make_float2(X[mb].x, X[mb].y);
-      if (lane == 0) { out[1 + 256] = make_float2(X[4].x, X[4].y); out[0] = make_float2(0.f, 0.f); }
+      for (int j = 0; j < 4; ++j) out[1 + lane + 64 * j] = Y[j];
+      if (lane == 0) { out[1 + 256] = make_float2(x256.x, x256.y); out[0] = make_float2(0.f, 0.f); }
+      if (d.lp.arena >= 0) {                                 // channel-padded copy for the first encoder layer: one 16 / 32-byte slot per bin
+        char* lp = rp(ab, d.lp);
+        auto put = [&](int slot, float re, float im) {
+          const int64_t s = fr * 258 + slot;
+          if (d.lp_dt == DT_BF16) *reinterpret_cast<uint4*>(lp + s * 16) = make_uint4(pack_bf16x2(re, im), 0u, 0u, 0u);
+          else {
+            *reinterpret_cast<float4*>(lp + s * 32) = make_float4(re, im, 0.f, 0.f);
+            *reinterpret_cast<float4*>(lp + s * 32 + 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(1 + lane + 64 * j, Y[j].x, Y[j].y);
+        if (lane == 0) { put(1 + 256, x256.x, x256.y); put(0, 0.f, 0.f); }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's LDS slice is reused by its next frame
   }
@@ -159,10 +188,16 @@ __global__ __launch_bounds__(256) void istft_fft_kernel(const IstftFft d, const 
   fft512_wave(x, X, lds[wv], twl, lane);
   const int k0 = lane >> 3, ma = lane & 7;
   float* out = frames + fr * d.W;
+  // samples leave in sample order (see stft_fft_kernel): real parts through the wave's LDS slice, lane l stores samples l + 64 i
+  float* buf = reinterpret_cast<float*>(lds[wv]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int mb = 0; mb < 8; ++mb) {
-    const int j = k0 + 8 * ma + 64 * mb;
-    if (j < d.W) out[j] = (X[mb].x - ((j & 1) ? co : ce)) * win[j] * (1.f / 256.f);
+  for (int mb = 0; mb < 8; ++mb) buf[k0 + 8 * ma + 64 * mb] = X[mb].x;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    if (j < d.W) out[j] = (buf[j] - ((j & 1) ? co : ce)) * win[j] * (1.f / 256.f);
   }
 }
 

@@ -190,4 +190,5 @@ class Plan:
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         rc = self.lib.sefd_plan_run(self.h, phase, first, last, ptrs, C.c_void_p(stream))
         if rc != 0:
-            raise RuntimeError(f"sefd_plan_run failed ({rc})")
+            raise RuntimeError(f"sefd_plan_run failed ({rc})" + (": a cluster-LSTM launch of the previous call gave up waiting for a peer workgroup "
+                               "(GPU shared or preempted?) - that step's results are invalid" if rc == -5 else ""))

@@ -84,7 +84,10 @@ int32_t sefd_plan_op_info(const sefd_plan* p, int phase, int i, int64_t* out8);
 /* ---- execution (device) --------------------------------------------------------------------------
  * arenas: SEFD_ARENA_COUNT device pointers.  Runs ops [first, last) of the phase on `stream`.
  * Forward  = DCCRN.forward  (models.py:176-284): IO.wav -> IO.out_wav, IO.out_real, IO.out_imag.
- * Backward = autograd of it: IO.grad_wav / grad_real / grad_imag -> A_GRAD (all parameters). */
+ * Backward = autograd of it: IO.grad_wav / grad_real / grad_imag -> A_GRAD (all parameters).
+ * Returns 0, or < 0: -1 invalid plan, -2 a launch failed, -3 stream / event creation failed, -5 a cluster-LSTM launch of an EARLIER
+ * call gave up waiting for a peer workgroup (bounded spin ran out: co-residency lost on a shared / preempted GPU) - that step's
+ * results are invalid; the flag is cleared by the call that reports it. */
 int32_t sefd_plan_run(const sefd_plan* p, int phase, int first, int last, void* const* arenas, void* stream);
 /* grad_buckets == 2: index (backward phase) of the UNPACK op that completes the first gradient bucket and the first flat element
    of that bucket; returns -1 when the plan has a single bucket. */

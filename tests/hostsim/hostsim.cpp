@@ -469,6 +469,11 @@ bool run_fsn(const Op& op, const AB& ab) {
           if (cr) { re = d.scale * (re - cr[k] * ge - cr[2 * 257 + k] * go); im = d.scale * (im - cr[257 + k] * ge - cr[3 * 257 + k] * go); }
           o[2 * (k + 1)] = (float)re; o[2 * (k + 1) + 1] = (float)im;
         }
+        if (d.lp.arena >= 0) {                    // channel-padded copy [frames][258][8] in the activation dtype
+          char* lp = rp(ab, d.lp);
+          for (int slot = 0; slot < 258; ++slot)
+            for (int ch = 0; ch < 8; ++ch) st(lp, d.lp_dt, (fr * 258 + slot) * 8 + ch, ch < 2 ? o[2 * slot + ch] : 0.f);
+        }
       }
       return true;
     }
@@ -542,11 +547,16 @@ void run_op(const Op& op, const AB& ab) {
     }
     case OP_SPLITSUM: {
       const Unpack& d = op.unpack;
-      float* part = (float*)rp(ab, d.part);
-      for (int64_t i = 0; i < d.n; ++i) {
-        double s = 0;
-        for (int k = 0; k < d.nsplit; ++k) s += part[k * d.sstride + i];
-        part[i] = (float)s;
+      float* base = (float*)rp(ab, d.part);
+      const int64_t* tab = d.nseg > 0 ? (const int64_t*)rp(ab, d.start) : nullptr;
+      for (int sgi = 0; sgi < (d.nseg > 0 ? d.nseg : 1); ++sgi) {
+        float* part = tab ? base + tab[3 * sgi] : base;
+        const int64_t n = tab ? tab[3 * sgi + 1] : d.n, stride = tab ? n : d.sstride, ns = tab ? tab[3 * sgi + 2] : d.nsplit;
+        for (int64_t i = 0; i < n; ++i) {
+          double s = 0;
+          for (int64_t k = 0; k < ns; ++k) s += part[k * stride + i];
+          part[i] = (float)s;
+        }
       }
       break;
     }
@@ -863,7 +873,10 @@ void run_op(const Op& op, const AB& ab) {
       const int NB = d.NF - 1, NS = d.NF + 1;
       const int lead = (int)(d.mask_base / d.mask_fstride), TT = d.T + lead;
       const int64_t B = d.frames / d.T;
-      double csum[2] = {0, 0};
+      // column sums of dmask: the kernel's workgroup w (256 threads, grid stride) owns the elements i with (i / 256) % rows == w and leaves
+      // its share in row w - mirrored here so that the partial-sum buffer compares element by element
+      const int csr = d.colsum_rows > 0 ? d.colsum_rows : 1;
+      std::vector<double> csum(2 * (size_t)csr, 0.0);
       for (int64_t b = 0; b < B; ++b)
         for (int u = 0; u < TT; ++u)
           for (int k = 0; k < NB; ++k) {
@@ -897,13 +910,14 @@ void run_op(const Op& op, const AB& ab) {
             }
             st(rp(ab, d.dmask), d.mdt, mo, (float)gr);
             if (d.mch >= 2) st(rp(ab, d.dmask), d.mdt, mo + 1, (float)gi);
-            csum[0] += ld(rp(ab, d.dmask), d.mdt, mo);
-            if (d.mch >= 2) csum[1] += ld(rp(ab, d.dmask), d.mdt, mo + 1);
+            const int64_t wg = ((((b * TT + u) * NB + k) / 256) % csr);
+            csum[2 * wg] += ld(rp(ab, d.dmask), d.mdt, mo);
+            if (d.mch >= 2) csum[2 * wg + 1] += ld(rp(ab, d.dmask), d.mdt, mo + 1);
           }
-      if (d.colsum_rows > 0) {                   // the kernel spreads the column sums over its workgroups; any split with the same total will do
+      if (d.colsum_rows > 0) {
         float* cs = (float*)rp(ab, d.colsum);
         std::fill(cs, cs + (int64_t)d.colsum_rows * 8, 0.f);
-        cs[0] = (float)csum[0]; cs[1] = (float)csum[1];
+        for (int w = 0; w < d.colsum_rows; ++w) { cs[w * 8] = (float)csum[2 * w]; cs[w * 8 + 1] = (float)csum[2 * w + 1]; }
       }
       break;
     }

@@ -78,6 +78,9 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         os.environ["SEFD_BN_FUSE"] = "2"   # ... and every BatchNorm layer's backward sums come from its producers' epilogues (thin + tiled kernels)
     if L == 2401 or (model == "DCCRN" and dtype == "fp32" and L == 2400):
         os.environ["SEFD_BN_FUSE"] = "2"   # the same through the wide-tile kernel / in fp32
+    os.environ.pop("SEFD_LSTM_RPW", None)
+    if model == "DCCRN" and L == 4000 and dtype == "bf16" and os.environ.get("SEFD_DIRECT_MINM") == "0":
+        os.environ["SEFD_LSTM_RPW"] = "16"  # the 16-sequences-per-workgroup recurrences (the default picks one cell per lane below 4096 sequences); read per launch
     os.environ.pop("SEFD_LSTM_MT", None)
     if model == "FullSubNet" and L == 10:
         os.environ["SEFD_LSTM_MT"] = "3"
@@ -183,6 +186,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
             if not (worst < 1.0) or stray:
                 bad.append(lines[-1])
     os.environ.pop("SEFD_LSTM_MT", None)
+    os.environ.pop("SEFD_LSTM_RPW", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
     os.environ.pop("SEFD_WINCONV_MINM", None)
     os.environ.pop("SEFD_WINCONV", None)
