@@ -1653,11 +1653,17 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // The folds of the decoder + LSTM weight gradients (3/4 of the 1.2 GB of partial sums of a step) go here, on the weight-gradient lane:
     // a bandwidth-bound pass beside the encoder's input-gradient GEMMs instead of in front of the final UNPACK on the main stream.
     if (!(getenv("SEFD_SPLITSUM_MID") && atoi(getenv("SEFD_SPLITSUM_MID")) == 0)) b.flush_sums(R, 997, true);
-    if (cfg.grad_buckets >= 2) {
+    // Without an exchange (one bucket) the same early UNPACK rides the weight-gradient lane (tag 997): the gather of 83 % of the parameters
+    // leaves the tail of the main stream (79 us for all of them in front of Adam before); SEFD_UNPACK_MID=0 keeps the single UNPACK.
+    const bool unpack_mid = cfg.grad_buckets < 2 && !(getenv("SEFD_UNPACK_MID") && atoi(getenv("SEFD_UNPACK_MID")) == 0);
+    if (cfg.grad_buckets >= 2 || unpack_mid) {
       const int64_t lo = b.par("decoder.0.0.real_conv.weight").off;
-      b.unpack_range(R, lo, nparam, 998);
+      b.flush_sums(R, 997, unpack_mid);                      // (nothing pending unless SEFD_SPLITSUM_MID=0)
+      if (unpack_mid) b.cur_lane = 1;
+      b.unpack_range(R, lo, nparam, unpack_mid ? 997 : 998);
+      b.cur_lane = 0;
       b.unpack_hi = lo;
-      P->bucket_elem = lo;                                   // (the op index is looked up after the op list is final)
+      if (!unpack_mid) P->bucket_elem = lo;                  // (the op index is looked up after the op list is final)
     }
     // ---- encoder backward
     for (int i = n - 1; i >= 0; --i) {
@@ -1665,6 +1671,9 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const std::string nm = "enc" + std::to_string(i);
       const std::string pp = "encoder." + std::to_string(i);
       bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm, &bnb_enc[i]);
+      // the folds of enc5 .. enc1 go in front of the LAST weight gradient on its lane (its input is the last thing the dgrad chain produces,
+      // the lane usually waits for it): the fold in front of the final UNPACK then covers one thin layer
+      if (i == 0 && lane_all && n > 1 && !(getenv("SEFD_SPLITSUM_MID") && atoi(getenv("SEFD_SPLITSUM_MID")) == 0)) b.flush_sums(R, 996, true);
       b.cur_lane = lane_all ? 1 : 0;             // encoder weight gradients next to the dgrad chain
       b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
       b.cur_lane = 0;
