@@ -181,6 +181,8 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   std::vector<int> held;
   bool has_lstm_bwd = false;
   for (const Op& op : ops) has_lstm_bwd |= op.kind == OP_LSTM_BWD;
+  int last_lstm = -1;                                    // lane-1 ops behind the last recurrence are never held back
+  for (int i = 0; i < (int)ops.size(); ++i) if (ops[i].kind == OP_LSTM_BWD) last_lstm = i;
   bool forked = !has_lstm_bwd;                           // no LSTM backward in this phase: lane-1 ops are never held back
   bool side_busy = false;                                // the side stream holds work the main stream has not waited for
   auto side_launch = [&](const Op& op) {                 // program order up to here is satisfied on the main stream
@@ -197,14 +199,16 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   };
   for (int i = first; i < last; ++i) {
     const Op& op = ops[i];
-    if (op.lane == 1 && !forked) { held.push_back(i); continue; }
+    // held: every lane-1 op in front of the first recurrence, and the ones marked kOpHold, wait for the next recurrence launch
+    if (op.lane == 1 && i < last_lstm && (!forked || op.join == kOpHold)) { held.push_back(i); continue; }
     if (op.lane == 1 || op.lane == 2) { side_launch(op); continue; }
-    if (op.kind == OP_LSTM_BWD && !forked) {
+    if (op.kind == OP_LSTM_BWD && (!forked || !held.empty())) {
       (void)hipEventRecord(h->ev_fork, st);              // everything the held ops read has been produced before this point
       launch(op, st);                                    // the recurrence takes its CUs first
       (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
       for (int j : held) launch(ops[j], h->side);
       side_busy = side_busy || !held.empty();
+      held.clear();
       forked = true;
       continue;
     }

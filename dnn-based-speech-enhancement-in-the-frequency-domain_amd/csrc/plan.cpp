@@ -97,13 +97,16 @@ struct Builder {
   Ptr pptr(const std::string& n, int arena = A_PARAM) { return mk(arena, par(n).off * 4); }
   Ptr sptr(const std::string& n) { return mk(A_STATE, P->state[sidx.at(n)].off * 4); }
 
+  int wg_rounds = 1;                                       // see wgrad(): row splits sized for this many dispatch rounds
   int cur_lane = 0;
+  int cur_hold = 0;                                        // lane-1 ops pushed while set wait for the NEXT recurrence launch (kOpHold)
   Op& push(std::vector<Op>& v, int kind, int tag) {
     Op op;
     std::memset(&op, 0, sizeof(op));
     op.kind = kind;
     op.tag = tag;
     op.lane = cur_lane;
+    if (cur_lane == 1 && cur_hold) op.join = kOpHold;
     v.push_back(op);
     return v.back();
   }
@@ -244,7 +247,9 @@ struct Builder {
     int tk = kWgTK;
     if (narrow && wide_on && g.Npad % 256 == 0 && g.ldw >= 384 && g.M >= wide_minm) { tn = 256; tk = 256; g.flags |= kRunWgWide; }
     else if (narrow && wide_on && g.Npad == 128 && g.ldw >= 1024 && g.M >= wide_minm) { tn = 128; tk = 512; g.flags |= kRunWgWide; }
-    const int slots = g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768;
+    // wg_rounds > 1 (FullSubNet): that many dispatch rounds of shorter workgroups - the launch shares the chip with a recurrence whose
+    // second round leaves 2/3 of the CUs idle, and a workgroup that needs the whole kernel's duration on its CU cannot use such a hole
+    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768) * std::max(1, wg_rounds);
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
@@ -2611,6 +2616,12 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
 
   // =================================================================================================== backward
   if (cfg.training) {
+    // lane of the weight-gradient GEMMs: 1 = second stream (api.hip: issued behind the first recurrence kernel of the phase, joined in front of
+    // the UNPACK); only when the recurrences are single launches (the per-frame GRU / fp32 formulation has no OP_LSTM_BWD to fork at)
+    const int wg_lane = (!gru && adt == DT_BF16 && !(getenv("SEFD_FSN_LANES") && atoi(getenv("SEFD_FSN_LANES")) == 0)) ? 1 : 0;
+    // wg_hold: the weight gradients of the layer wait for the NEXT recurrence launch instead of starting beside the input-gradient GEMM in
+    // between (two MFMA-bound GEMMs side by side ran 10 % slower than one after the other; beside the HBM-bound recurrence they fill its idle CUs)
+    int wg_hold = 0;
     auto lstm_backward = [&](LayerRt& L, Ptr dh, bool need_dx, Ptr dx, int dx_ld, int dx_off, int dx_N, int dx_dt, int tag) {
       const int H = L.H;
       const int64_t rows = L.rows;
@@ -2688,7 +2699,11 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         }
       }
       }
-      // weight gradients over all steps
+      // weight gradients over all steps: nothing needs them before UNPACK - on the weight-gradient lane (second stream) they run beside the
+      // input-gradient GEMM and the NEXT layer's recurrence (343 workgroups of 48 sequences on 256 CUs: its second round leaves 2/3 of the chip idle)
+      b.cur_lane = wg_lane;
+      b.cur_hold = wg_hold;
+      b.wg_rounds = wg_lane ? (getenv("SEFD_FSN_WG_ROUNDS") ? atoi(getenv("SEFD_FSN_WG_ROUNDS")) : 3) : 1;
       RunGemm fw = L.gx;
       fw.ydt = adt;
       if (gru) set_y(fw, dgates, rows, NG * H, 0);        // the GRU's gradient slab is 3H wide (the forward slab keeps a 4th block for W_hn h + b_hn)
@@ -2698,6 +2713,9 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       set_y(fh, dgh, rows, NG * H, 0);
       Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)(um ? gate_torch_row(nn, H) : nn) * H + j, 1); };
       b.wgrad(R, fh, dgh, chh, tag, gru ? &L.bhh : nullptr);           // GRU: b_hh belongs to this GEMM (bias "ones" run)
+      b.cur_lane = 0;
+      b.cur_hold = 0;
+      b.wg_rounds = 1;
       if (need_dx) {
         RunGemm g = seq_gemm(dgates, adt, rows, NG * H, 0, NG * H, dx_N, dx_dt);
         const Builder::Coef cf = L.cgx;
@@ -2738,7 +2756,9 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     if (Ls1.headfuse) { Ls1.dyo = d_sbo; Ls1.wo = b.pptr("sb_model.fc_output_layer.weight"); }
     fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model", Ls1.headfuse);
     Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, DT_F32);
+    wg_hold = !(getenv("SEFD_FSN_HOLD") && atoi(getenv("SEFD_FSN_HOLD")) == 0);
     lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, DT_F32, 203);
+    wg_hold = 0;
     Ptr dh2 = dropout_bwd(Ls0, dh2d, 202);
     Ptr d_sbin = b.ws("d_sbin", (int64_t)TP * rs * W, DT_F32);
     lstm_backward(Ls0, dh2, true, d_sbin, W, 0, W, DT_F32, 202);

@@ -373,6 +373,8 @@ enum OpKind : int32_t {
   OP_FSN_NORMSTAT, OP_FSN_NORMBWD,   // cfg.norm_type other than offline_laplace_norm (struct Fsn)
 };
 
+constexpr int kOpHold = 2;     // Op::join of a lane-1 op
+
 struct Op {
   int32_t kind;
   int32_t tag;                 // layer id for profiling / debugging
@@ -381,7 +383,7 @@ struct Op {
                                // second one first.  1: off the critical path (decoder weight gradients): a full-phase run
                                // holds these back and runs them on a second HIP stream next to the LSTM backward, whose
                                // recurrence occupies only 8 of the 256 CUs for ~1.5 ms (api.hip sefd_plan_run)
-  int32_t join;
+  int32_t join;                // lane 0: 1 = wait for the second stream first.  lane 1: kOpHold = issue behind the NEXT recurrence launch
   union {
     RunGemm g;
     Pack pack;

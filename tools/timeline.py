@@ -10,8 +10,11 @@ def short(n):
     return n
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) for r in rows]
 ks.sort()
-starts = [i for i, k in enumerate(ks) if k[2].startswith("stft_fft")]           # two STFTs open each step
-steps = [starts[i] for i in range(0, len(starts), 2)]
+import os
+mark = os.environ.get("TIMELINE_MARK", "stft_fft")                             # DCCRN: two STFTs open each step; FullSubNet: TIMELINE_MARK=fsn_in_kernel:1
+mark, per = (mark.split(":") + ["2"])[:2] if ":" in mark else (mark, "2")
+starts = [i for i, k in enumerate(ks) if k[2].startswith(mark)]
+steps = [starts[i] for i in range(0, len(starts), int(per))]
 a = steps[-1 - back]; b = steps[-back] if back > 0 else len(ks)
 ks = ks[a:b]
 t0 = ks[0][0]; t1 = max(k[1] for k in ks)
