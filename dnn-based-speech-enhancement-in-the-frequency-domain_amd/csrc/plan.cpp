@@ -290,7 +290,7 @@ struct Builder {
   struct SumSeg { int64_t rel, n, ns; };
   std::vector<SumSeg> pending_sums;
   void split_sum(std::vector<Op>& ops, int64_t rel, int64_t n, int64_t ns, int tag) {
-    static const bool multi = !(getenv("SEFD_SPLITSUM_MULTI") && atoi(getenv("SEFD_SPLITSUM_MULTI")) == 0);
+    const bool multi = !(getenv("SEFD_SPLITSUM_MULTI") && atoi(getenv("SEFD_SPLITSUM_MULTI")) == 0);
     if (multi) { pending_sums.push_back(SumSeg{rel, n, ns}); return; }
     Op& os = push(ops, OP_SPLITSUM, tag);
     os.unpack.n = n;
@@ -665,7 +665,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   const int CP = 8;
   {
     spec_lp = b.ws("xin", (int64_t)B * T * NS * CP, adt);
-    static const bool fuse_pad = !(getenv("SEFD_SPECPAD_FUSE") && atoi(getenv("SEFD_SPECPAD_FUSE")) == 0);
+    const bool fuse_pad = !(getenv("SEFD_SPECPAD_FUSE") && atoi(getenv("SEFD_SPECPAD_FUSE")) == 0);
     if (spec_fft && fuse_pad && NS == 258) {      // the FFT kernel writes the padded copy beside the spectrogram (no SPECPAD pass: 48 us at B = 32)
       F.back().fft.lp = spec_lp; F.back().fft.lp_dt = adt;
     } else {

@@ -160,6 +160,55 @@ def test_wide_wgrad_tile_only_changes_the_row_splits(monkeypatch):
     _grads_close(res[1], res[0], 1e-4)
 
 
+def _op_words(plan, phase):
+    """(kind, tag, lane, join) of every op, read from the op array the executor consumes (struct Op: four leading int32)."""
+    import ctypes as C
+    n, sz = plan.num_ops(phase), plan.lib.sefd_op_size()
+    raw = np.ctypeslib.as_array((C.c_int32 * (n * sz // 4)).from_address(plan.ops_ptr(phase))).reshape(n, sz // 4)
+    return raw[:, :4].copy()
+
+
+def test_folds_and_early_unpack_are_a_pure_reschedule(monkeypatch):
+    """Round 3: the row-split folds of all weight gradients are table-driven SPLITSUM launches (two on the weight-gradient lane, one in front
+    of the final UNPACK), and the decoder + LSTM parameter range is unpacked early on that lane.  Same gradients, bit for bit, as one SPLITSUM
+    behind every WGRAD and a single UNPACK (the folds add the same partials in the same order)."""
+    B, L = 1, 2400
+    P = oracle_params(DCCRNConfig(masking_mode="C", **SMALL))
+    x, _ = make_signals(B, L)
+    torch.manual_seed(8)
+    gw = torch.randn(B, L) * 1e-3
+    res, shape = [], []
+    for multi, mid in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("SEFD_SPLITSUM_MULTI", multi)
+        monkeypatch.setenv("SEFD_SPLITSUM_MID", mid)
+        monkeypatch.setenv("SEFD_UNPACK_MID", mid)
+        plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **SMALL)
+        w = _op_words(plan, PHASE_BWD)
+        shape.append(([tuple(r[2:]) for r in w if r[0] == 20], [tuple(r[2:]) for r in w if r[0] == 4]))     # SPLITSUM = 20, UNPACK = 4: (lane, join)
+        res.append(_run_plan(plan, P, x, gw)[1])
+    sums0, unp0 = shape[0]
+    sums1, unp1 = shape[1]
+    assert len(sums0) > 10 and len(unp0) == 1, (len(sums0), unp0)
+    assert sums1 == [(1, 0), (1, 0), (0, 1)], sums1             # two folds ride the weight-gradient lane, the last one joins it on the main stream
+    assert unp1 == [(1, 0), (0, 0)], unp1                       # decoder + LSTM range early on the lane, encoder range at the end
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_fsn_weight_gradients_ride_the_second_lane():
+    """FullSubNet bf16 plan: the weight-gradient GEMMs of the recurrent layers are lane-1 ops; the ones of the upper sub-band layer wait for the next
+    recurrence launch (Op::join == kOpHold = 2) instead of starting beside the input-gradient GEMM in between.  fp32 (per-frame formulation) stays single-lane."""
+    plan = Plan(2, 9, act_dtype="bf16", model="FullSubNet", fsn=dict(fb_hidden=256, sb_hidden=192, keep=0.2))
+    w = _op_words(plan, PHASE_BWD)
+    wg = [tuple(r[1:]) for r in w if r[0] == 2]                 # WGRAD: (tag, lane, join)
+    lane1 = [t for t in wg if t[1] == 1]
+    assert len(lane1) == 8, wg                                  # 4 layers x (W_ih, W_hh)
+    assert sorted(t[0] for t in lane1 if t[2] == 2) == [203, 203], wg       # upper sub-band layer: held
+    assert any(r[0] == 10 for r in w)                           # the recurrences are single OP_LSTM_BWD launches (what the lane forks at)
+    plan32 = Plan(2, 9, act_dtype="fp32", model="FullSubNet", fsn=dict(fb_hidden=64, sb_hidden=32, keep=0.2))
+    assert all(r[2] == 0 for r in _op_words(plan32, PHASE_BWD))
+
+
 def test_tiled_weight_layout_is_a_pure_relayout(monkeypatch):
     """Wide-tile GEMMs (cgemm256.hip) read their weights K-tile major (kRunWTile32): same numbers, different addresses.  The
     plan with every N % 256 == 0 bf16 layer switched to that layout must give bit-identical results on the host simulator."""
