@@ -1680,7 +1680,18 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // the lane usually waits for it): the fold in front of the final UNPACK then covers one thin layer
       if (i == 0 && lane_all && n > 1 && !(getenv("SEFD_SPLITSUM_MID") && atoi(getenv("SEFD_SPLITSUM_MID")) == 0)) b.flush_sums(R, 996, true);
       b.cur_lane = lane_all ? 1 : 0;             // encoder weight gradients next to the dgrad chain
-      b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, &enc[i].bias);
+      // Every encoder conv bias sits in front of a training-mode BatchNorm: its gradient is identically zero (the sum over all rows of the
+      // BatchNorm input gradient vanishes; the reference computes rounding noise there).  No bias "ones" run in these GEMMs - it cost a
+      // whole 64-column K segment (enc0: 192 -> 128 columns, half the K tiles; enc3: 6 -> 5 wide tiles) - UNPACK writes the exact zero.
+      const bool enc_bias_zero = !(getenv("SEFD_ENC_BIAS_ZERO") && atoi(getenv("SEFD_ENC_BIAS_ZERO")) == 0);
+      if (enc_bias_zero) {
+        b.zero_grad.resize(nparam, 0);
+        for (const char* part : {".0.real_conv.bias", ".0.imag_conv.bias"}) {
+          const ParamInfo& pb = b.par(pp + part);
+          for (int64_t e = 0; e < pb.numel; ++e) b.zero_grad[pb.off + e] = 1;
+        }
+      }
+      b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, enc_bias_zero ? nullptr : &enc[i].bias);
       b.cur_lane = 0;
       if (i == 0) continue;
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]
