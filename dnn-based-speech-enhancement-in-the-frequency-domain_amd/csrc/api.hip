@@ -157,9 +157,10 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     else launch_misc(op, ab, s);
     if (tev) (void)hipEventRecord((*tev)[2 * idx + 1], s);
   };
-  // Two-lane execution of a whole phase: lane-1 ops (decoder weight gradients + their split sums) are held back until the
-  // first LSTM backward, then issued on the side stream right after that kernel, so they fill the ~248 CUs the recurrence
-  // leaves idle; the main stream waits for them before the first op that follows the last lane-1 op's consumers (UNPACK).
+  // Two-lane execution of a whole phase: lane-1 ops (weight gradients, the folds of their row-split partial sums, the early UNPACK) in front
+  // of the first LSTM backward are held back and issued on the side stream right after that kernel, so they fill the CUs the recurrence
+  // leaves idle; later lane-1 ops follow at their program position, except the ones marked kOpHold, which wait for the NEXT recurrence
+  // launch (FullSubNet).  The main stream waits for the lane at the ops that carry `join` and at every main-stream UNPACK.
   // Partial runs (tests, per-op timing) and SEFD_NO_OVERLAP=1 execute everything in program order on `stream`.
   static const bool no_overlap = getenv("SEFD_NO_OVERLAP") != nullptr;
   bool two_lane = !no_overlap && first == 0 && last == (int)ops.size();
