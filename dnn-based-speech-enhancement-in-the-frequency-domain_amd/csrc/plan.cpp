@@ -388,6 +388,10 @@ void finalize_rungemms(Builder& b, Plan* P) {
   {
     const bool wide = !(getenv("SEFD_CG256") && atoi(getenv("SEFD_CG256")) == 0);
     const int wide_minm = getenv("SEFD_CG256_MINM") ? atoi(getenv("SEFD_CG256_MINM")) : 4096;
+    // ... and enough 256 x 256 tiles to occupy the chip: the projection's input gradient (M = B*T = 15 456, N = 256: 61 tiles on 256 CUs) ran
+    // 65 us on the wide kernel; as 242 workgroups of the 128-row kernel it fills the chip: 33 us.  Only up to K = 1024: DCCRN-large's few-tile
+    // GEMMs have K = 2048 and lost 0.75 ms per step on the 128-row kernel.  (Tests that lower MINM run small cases on purpose.)
+    const int wide_mintiles = getenv("SEFD_CG256_MINTILES") ? atoi(getenv("SEFD_CG256_MINTILES")) : (getenv("SEFD_CG256_MINM") ? 0 : 100);
     std::map<int64_t, bool> elig;                            // weight buffer offset -> every reader (either phase) qualifies
     std::vector<Op*> all;
     for (auto* ops : {&P->fwd, &P->bwd})
@@ -395,7 +399,8 @@ void finalize_rungemms(Builder& b, Plan* P) {
     for (Op* op : all) {
       if (op->kind != OP_RUNGEMM || op->g.w.arena != A_WS) continue;
       const RunGemm& g = op->g;
-      const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm && g.n2 == 0;
+      const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm && g.n2 == 0 &&
+                     (((g.M + 255) / 256) * (int64_t)(g.Npad / 256) >= wide_mintiles || g.ldw > 1024);
       auto it = elig.find(g.w.off);
       if (it == elig.end()) elig[g.w.off] = e; else it->second = it->second && e;
     }
