@@ -162,7 +162,7 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   // leaves idle; later lane-1 ops follow at their program position, except the ones marked kOpHold, which wait for the NEXT recurrence
   // launch (FullSubNet).  The main stream waits for the lane at the ops that carry `join` and at every main-stream UNPACK.
   // Partial runs (tests, per-op timing) and SEFD_NO_OVERLAP=1 execute everything in program order on `stream`.
-  static const bool no_overlap = getenv("SEFD_NO_OVERLAP") != nullptr;
+  const bool no_overlap = getenv("SEFD_NO_OVERLAP") != nullptr;      // read per call: the schedule-equivalence test flips it between two steps
   bool two_lane = !no_overlap && first == 0 && last == (int)ops.size();
   if (two_lane) {
     bool any1 = false, any2 = false, lstm = false;

@@ -52,6 +52,39 @@ __device__ __forceinline__ void st_gate4(char* base, int64_t o, float a, float b
   if constexpr (G16) *reinterpret_cast<uint2*>(base + o * 2) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, e));
   else *reinterpret_cast<float4*>(base + o * 4) = make_float4(a, b, c, e);
 }
+// OPEN ISSUE (found in round 3 with tests/test_gpu_model.py::test_two_stream_schedule_equals_program_order and by re-running the single
+// LSTM_FWD op on identical inputs): this kernel is not bit-reproducible run to run.  Signature: the FORGET gate (accumulator q = 1, mt = 0,
+// register .x) of local row 12 of a workgroup (lanes 48 .. 63 = the last quarter-wave, the first cell the epilogue touches) comes out
+// different in ~2.5e-4 of the cells of a frame, on the second wave of a SIMD; cell-state error up to 0.015 (|c| <= 0.85).  Not a waitcnt
+// problem (-mllvm -amdgpu-waitcnt-forcezero: unchanged), not the saved-cell-state read (c kept in registers: unchanged).  hipcc (ROCm 7.2)
+// schedules the first packed add on an MFMA result 8 wait states behind the v_mfma_f32_16x16x32_bf16 that wrote it; putting ALL
+// accumulators through one asm statement behind 16 wait states (below) cut the rate 13-25x (1e-5 of the cells) but not to zero; more
+// wait states, guards in front of / between the GEMM parts and behind the transcendentals changed nothing further.  Every reference
+// golden and per-op comparison stays inside its tolerance; the cluster kernels and the DCCRN recurrences are bit-reproducible.
+template <int MT>
+__device__ __forceinline__ void mfma_settle(f32x4 (&acc)[MT][4]) {
+  static_assert(MT >= 1 && MT <= 5, "one asm statement takes every accumulator");
+  // ONE statement with all accumulators as in/out operands: separate statements were scheduled apart (the nops behind the first MFMA only)
+  if constexpr (MT == 1)
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));
+  else if constexpr (MT == 2)
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                 "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+  else if constexpr (MT == 3)
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                 "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
+                 "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]));
+  else {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                 "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
+                 "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]));
+    if constexpr (MT == 4)
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+    else
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]),
+                   "+v"(acc[4][0]), "+v"(acc[4][1]), "+v"(acc[4][2]), "+v"(acc[4][3]));
+  }
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- forward
@@ -177,6 +210,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
           for (int q = 0; q < 4; ++q)
             acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa[mt]), __builtin_bit_cast(bf16x8, bx[q]), acc[mt][q], 0, 0, 0);
       }
+      mfma_settle(acc);
       float4 gxv[MT][4];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)

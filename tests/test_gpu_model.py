@@ -677,3 +677,54 @@ def test_bf16_dccrn_perceptual_at_bench_size(perceptual):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert np.isfinite(float(main)) and np.isfinite(float(perc)) and abs((float(main) + float(perc)) / 2 - losses[-1]) < 1e-4 * abs(losses[-1]) + 1e-5
     assert bool(torch.isfinite(m._flat_param).all())
+
+
+# ------------------------------------------------------------------------------------------------ the two-stream schedule is only a schedule
+@pytest.mark.parametrize("which", ["dccrn", "fullsubnet"])
+def test_two_stream_schedule_equals_program_order(which, monkeypatch):
+    """Every kernel is deterministic, so the gradients of one fused step must be BIT-identical whether the phase runs in its two-lane schedule
+    (weight gradients, folds, early UNPACK, chunked LSTM forward on the second stream; FullSubNet: held weight gradients) or in program order on
+    one stream (SEFD_NO_OVERLAP=1).  A missing dependency between the lanes shows up here as a mismatch.  Sizes large enough that kernels of the
+    two streams really overlap (DCCRN B = 8 x 3 s, FullSubNet B = 16 x 3 s); lr = 0 keeps the parameters of the two runs equal."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.optim import Adam
+    if which == "dccrn":
+        m = make_model((32, 64, 128, 256, 256, 256), 256, "C", "SI-SNR", dtype="bf16")
+        m.train()
+        x, y = _bench_batch(8)
+    else:
+        cfg.loss, cfg.act_dtype = "MSE", "bf16"
+        try:
+            torch.manual_seed(0)
+            m = models.FullSubNet().to("cuda").train()
+        finally:
+            cfg.act_dtype = "fp32"
+        x, y = _bench_batch(16)
+    opt = Adam(m.parameters(), lr=0.0)
+    grads, losses = [], []
+    for rep, single in enumerate((False, True, False)):
+        if single:
+            monkeypatch.setenv("SEFD_NO_OVERLAP", "1")
+        else:
+            monkeypatch.delenv("SEFD_NO_OVERLAP", raising=False)
+        if which == "fullsubnet" and rep > 0:              # same dropout masks: the step counter behind the mask hash goes back by one
+            plan, ar = next(v for k, v in m._runtimes.items() if k[0] == "fsn")
+            plan.view(ar, "io.seed").view(torch.int32)[:1].sub_(1)
+        losses.append(float(m.train_step(x, y, opt)))
+        torch.cuda.synchronize()
+        grads.append(m._flat_grad.clone())
+    monkeypatch.delenv("SEFD_NO_OVERLAP", raising=False)
+    assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
+    if which == "dccrn":
+        assert losses[0] == losses[1] == losses[2], losses
+        assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
+        assert torch.equal(grads[0], grads[2])
+    else:
+        # The row-block forward recurrence (lstm_rows.hip, see the OPEN ISSUE note there) is not bit-reproducible run to run - in EITHER schedule:
+        # ~1e-5 of the forget gates of a frame differ - so the schedules are compared at 1e-5 of the gradient norm and 1e-6 of the loss;
+        # a race between the lanes would be a gross error
+        assert max(losses) - min(losses) < 1e-6 * abs(losses[0]), losses
+        n0 = float(grads[0].double().norm())
+        for g in grads[1:]:
+            assert float((g.double() - grads[0].double()).norm()) < 1e-5 * n0
