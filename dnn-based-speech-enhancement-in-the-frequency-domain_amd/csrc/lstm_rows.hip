@@ -52,15 +52,16 @@ __device__ __forceinline__ void st_gate4(char* base, int64_t o, float a, float b
   if constexpr (G16) *reinterpret_cast<uint2*>(base + o * 2) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, e));
   else *reinterpret_cast<float4*>(base + o * 4) = make_float4(a, b, c, e);
 }
-// OPEN ISSUE (found in round 3 with tests/test_gpu_model.py::test_two_stream_schedule_equals_program_order and by re-running the single
-// LSTM_FWD op on identical inputs): this kernel is not bit-reproducible run to run.  Signature: the FORGET gate (accumulator q = 1, mt = 0,
-// register .x) of local row 12 of a workgroup (lanes 48 .. 63 = the last quarter-wave, the first cell the epilogue touches) comes out
-// different in ~2.5e-4 of the cells of a frame, on the second wave of a SIMD; cell-state error up to 0.015 (|c| <= 0.85).  Not a waitcnt
-// problem (-mllvm -amdgpu-waitcnt-forcezero: unchanged), not the saved-cell-state read (c kept in registers: unchanged).  hipcc (ROCm 7.2)
-// schedules the first packed add on an MFMA result 8 wait states behind the v_mfma_f32_16x16x32_bf16 that wrote it; putting ALL
-// accumulators through one asm statement behind 16 wait states (below) cut the rate 13-25x (1e-5 of the cells) but not to zero; more
-// wait states, guards in front of / between the GEMM parts and behind the transcendentals changed nothing further.  Every reference
-// golden and per-op comparison stays inside its tolerance; the cluster kernels and the DCCRN recurrences are bit-reproducible.
+// Reproducibility note (round 3; found with tests/test_gpu_model.py::test_two_stream_schedule_equals_program_order and by re-running the
+// single LSTM_FWD op on identical inputs): the forward kernel used to be not bit-reproducible run to run.  Signature: the FORGET gate
+// (accumulator q = 1, mt = 0, register .x) of local row 12 of a workgroup (lanes 48 .. 63 = the last quarter-wave) came out different in
+// ~2.5e-4 of the cells of a frame, on the second wave of a SIMD; cell-state error up to 0.015 (|c| <= 0.85).  Not a waitcnt problem
+// (-mllvm -amdgpu-waitcnt-forcezero: unchanged), not the saved-cell-state read (c kept in registers: unchanged).  Two changes:
+//  * all accumulators pass through ONE asm statement behind 16 wait states before the epilogue reads them (hipcc of ROCm 7.2 scheduled the
+//    first packed add on an MFMA result 8 wait states behind the v_mfma_f32_16x16x32_bf16 that wrote it): rate 2.5e-4 -> 1e-5;
+//  * with the fused input projection the bias rides in the accumulators' initial value instead of being added to the MFMA results with
+//    v_pk_add_f32 (op_sel broadcast of a bias register) in the epilogue: rate -> 0 (5 re-runs of both layers, 16 whole steps in both
+//    schedules: identical bits).  Which of the packed add's operands was read early was not pinned down; the sequence is avoided.
 template <int MT>
 __device__ __forceinline__ void mfma_settle(f32x4 (&acc)[MT][4]) {
   static_assert(MT >= 1 && MT <= 5, "one asm statement takes every accumulator");
@@ -171,7 +172,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) {
+          const float b = !XK ? 0.f : q == 0 ? bias4.x : q == 1 ? bias4.y : q == 2 ? bias4.z : bias4.w;    // fused projection: the bias rides in the accumulator
+          acc[mt][q] = f32x4{b, b, b, b};
+        }
       // weight fragments in chunks of KC k-steps (fragment-major packing, sefd_desc.h rows_wf_index), A fragments from an LDS tile
       auto gemm_part = [&](const uint16_t* wbase, const uint16_t* atile) {
         uint4 bqA[KC][4];
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (XK) gxv[mt][r] = bias4; else gxv[mt][r] = GateRaw<G16>::cvt(gxr[mt][r]);
+          if constexpr (XK) gxv[mt][r] = make_float4(0.f, 0.f, 0.f, 0.f); else gxv[mt][r] = GateRaw<G16>::cvt(gxr[mt][r]);
         }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
