@@ -6,7 +6,7 @@
 
 One "step" = forward + SI-SNR loss + backward + fused Adam (+ RCCL gradient all-reduce when N > 1) on a synthetic batch of
 B = 32 clips of 3 s @ 16 kHz per GPU that is already resident in HBM (BASELINE configs[1]).  Weak scaling: per-GPU batch fixed.
-`--model dccrn_large` (configs[4]: 2x channels, rnn_units 512) and `--model fullsubnet` (configs[2], B = 64) print the same
+`--model dccrn_large` (configs[4]: 2x channels, rnn_units 512, B = 64 = 512 / 8 GPUs) and `--model fullsubnet` (configs[2], B = 64) print the same
 line for the other single-GPU configurations; `--batch 64` is the batch size of the north_star sentence.
 
 Order of the run (N = 1): the bounded CPU baseline first, then warm-up, the timed region, and the roofline leg, so that the GPU
@@ -27,8 +27,8 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI3
 PEAK_HBM_GBS = 8000.0
 K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
 F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")       # default workload; main() switches to r03_pmc_traffic_<model>.json
-PMC_DEFAULT_BATCH = {"dccrn": 32, "dccrn_large": 32, "fullsubnet": 64}       # the batch each committed summary was collected at
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")       # default workload; main() switches to r04_pmc_traffic_<model>.json
+PMC_DEFAULT_BATCH = {"dccrn": 32, "dccrn_large": 64, "fullsubnet": 64}       # the batch each committed summary was collected at
 ALGO_GB_PER_UTT = 0.28                   # minimal fused activation traffic of one bf16 training step
 
 
@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--perceptual", default=None, choices=["LMS", "PMSQE"], help="DCCRN: loss = (SI-SNR + perceptual) / 2 (BASELINE configs[3] per-GPU shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the two side figures of the default run (B = 64 bf16, B = 32 fp32)")
     return ap.parse_args()
 
 
@@ -104,7 +105,7 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100):
     """Two timing legs over every MFMA GEMM, LSTM recurrence and STFT launch of one step:
       in situ  (the headline `frac`): sefd_plan_run_timed - each phase in its REAL two-stream schedule with a HIP event pair around every
                op on the stream it runs on, i.e. the kernel's duration while the other lane's kernels share the chip (what a rocprofv3
-               kernel trace of the bench command shows; profiles/r03_kernel_stats_default.csv);
+               kernel trace of the bench command shows; profiles/r04_kernel_stats_default.csv);
       isolated (`frac_isolated`): the phase in program order on ONE stream, event pair per op - per-kernel rates without contention.
     achieved = algorithmic FLOPs (2*M*N*K, true unpadded N and K; sefd_plan_op_info) / measured duration."""
     from sefd_amd.plan import PHASE_BWD, PHASE_FWD
@@ -214,7 +215,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # SEFD_DDP_FORCE=1 (with the torchrun environment of ONE rank): the whole exchange path - init_process_group("nccl", device_id=...),
+    # bucketed plan, all-reduces on the communication stream started from the plan callback - on a one-rank RCCL communicator
+    # (tests/test_gpu_ddp_smoke.py); never a reported number
+    dist_on = world > 1 or (os.environ.get("SEFD_DDP_FORCE", "0") == "1" and "MASTER_ADDR" in os.environ)
+    if dist_on:
         # RCCL ("nccl") is the product path.  SEFD_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices):
         # used only to exercise the bucketed exchange / callback path on a single-GPU box, never for a reported number.
         backend = os.environ.get("SEFD_DIST_BACKEND", "nccl")
@@ -241,21 +246,21 @@ def main():
         metric = "train utts/sec (3s@16kHz) FullSubNet"
     else:
         cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.act_dtype = list(kn), "C", "SI-SNR", args.dtype
-        B = args.batch or 32
+        B = args.batch or (64 if large else 32)      # configs[4]: batch 512 over 8 GPUs = 64 per GPU
         model = models.DCCRN(rnn_units=ru, masking_mode="C").to(dev).train()
-        workload = (f"DCCRN{'-large (2x channels, rnn_units 512; BASELINE configs[4] per-GPU shard)' if large else ''} mask C, SI-SNR, fwd+bwd+Adam, "
+        workload = (f"DCCRN{'-large (2x channels, rnn_units 512; BASELINE configs[4]: 512 / 8 GPUs = 64 per GPU)' if large else ''} mask C, SI-SNR, fwd+bwd+Adam, "
                     f"B={B}/GPU x {args.seconds:g}s@16kHz clips" + ("" if large else " (BASELINE configs[1])"))
         metric = "train utts/sec (3s@16kHz) DCCRN" + ("-large" if large else "")
         if args.perceptual:
             workload = workload.replace("SI-SNR,", f"(SI-SNR + {args.perceptual}) / 2,").replace(" (BASELINE configs[1])", " (BASELINE configs[3] per-GPU shard)")
             metric += " + " + args.perceptual
     opt = Adam(model.parameters(), lr=1e-3)
-    ex = GradientExchange() if world > 1 else None
+    ex = GradientExchange() if dist_on else None
     x, y = make_batch(B, L, rank, dev)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -272,7 +277,7 @@ def main():
     dt = time.perf_counter() - t0
     mine = torch.tensor([dt], device=dev)
     tmax = mine.clone()
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         per_rank = [torch.zeros(1, device=dev) for _ in range(world)]
         dist.all_gather(per_rank, mine)
@@ -289,7 +294,7 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "bn": "per-rank statistics",
                           "collective": (f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (single-GPU smoke test, not a measurement)'} world {dist.get_world_size()}, flat fp32 gradient all-reduce in 2 buckets (decoder+LSTM under the encoder backward)"
-                                         if world > 1 else "none"),
+                                         if dist_on else "none"),
                           "per_rank_ms": per_rank_ms},
                "final_loss": round(lossv, 5)}
         if not args.no_roofline:
@@ -301,7 +306,7 @@ def main():
             # committed PMC summaries: one per model at its default batch; anything else reports traffic null
             global PMC_SUMMARY
             if args.model != "dccrn":
-                PMC_SUMMARY = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{args.model}.json")
+                PMC_SUMMARY = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{args.model}.json")
             out["roofline"] = roofline(plan, arenas, pmc_ok=(B == PMC_DEFAULT_BATCH[args.model] and not args.perceptual and args.dtype == "bf16"))
             info = [plan.op_info(ph, i) for ph in (0, 1) for i in range(plan.num_ops(ph))]
             mf = sum(o["flops"] for o in info if o["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD))
@@ -315,7 +320,33 @@ def main():
                                                    traffic_over_algorithmic=round(tot / (ALGO_GB_PER_UTT * 1e9 * B), 2))
         if cpu is not None:
             out["cpu_baseline"] = cpu
-    if world > 1:
+        if world == 1 and not dist_on and args.model == "dccrn" and not args.perceptual and args.batch is None and args.dtype == "bf16" and not args.no_extra:
+            # side figures of the same workload, same code path, timed the same way (shorter): the north_star batch (64) and the dtype that
+            # carries the 1e-3 parity criterion (fp32 activations: fp32 MFMA, 1/16 of the bf16 matrix rate)
+            del opt, model
+            torch.cuda.empty_cache()
+            extra = {}
+            for tag, dt_, Bx, st_, wu_ in (("b64", "bf16", 64, 20, 5), ("fp32", "fp32", B, 6, 2)):
+                cfg.act_dtype = dt_
+                torch.manual_seed(0)
+                mx = models.DCCRN(rnn_units=ru, masking_mode="C").to(dev).train()
+                ox = Adam(mx.parameters(), lr=1e-3)
+                xx, yy = make_batch(Bx, L, rank, dev)
+                for _ in range(wu_):
+                    lx = mx.train_step(xx, yy, ox)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(st_):
+                    lx = mx.train_step(xx, yy, ox)
+                torch.cuda.synchronize()
+                dx = time.perf_counter() - t0
+                extra[tag] = dict(value=round(Bx * st_ / dx, 2), unit="utt/s", ms_per_step=round(dx / st_ * 1e3, 3), batch=Bx, dtype=dt_ if dt_ == "bf16" else "f32",
+                                  steps=st_, warmup=wu_, final_loss=round(float(lx), 5))
+                del mx, ox, xx, yy
+                torch.cuda.empty_cache()
+            cfg.act_dtype = args.dtype
+            out["extra"] = extra
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -15,7 +15,19 @@ struct sefd_plan {
   // second stream + events for the off-critical-path lane (created on first use, owned by the plan)
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // host-mapped status word of THIS plan (created on first use: plans are also built on hosts without a GPU).  0 = fine; sticky once set
+  // by a kernel that gave up (cluster LSTM hand-over timeout) until sefd_plan_status(clear = 1)
+  mutable int* status = nullptr;
 };
+static int* plan_status_word(const sefd_plan* h) {
+  if (!h->status) {
+    int* q = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&q), sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
+    *q = 0;
+    h->status = q;
+  }
+  return h->status;
+}
 
 static_assert(sizeof(sefd_model_config) == sizeof(ModelConfig), "config mirror out of sync");
 
@@ -34,6 +46,7 @@ void sefd_plan_destroy(sefd_plan* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->status) (void)hipHostFree(h->status);
   delete h->p;
   delete h;
 }
@@ -103,6 +116,11 @@ int32_t sefd_plan_op_info(const sefd_plan* h, int phase, int i, int64_t* o) {
   return 0;
 }
 
+const int32_t* sefd_plan_status_word(const sefd_plan* h) { return h ? reinterpret_cast<const int32_t*>(plan_status_word(h)) : nullptr; }
+int32_t sefd_plan_status(const sefd_plan* h, int32_t clear) {
+  if (!h || !h->status) return 0;
+  return clear ? __atomic_exchange_n(h->status, 0, __ATOMIC_RELAXED) : __atomic_load_n(h->status, __ATOMIC_RELAXED);
+}
 int32_t sefd_plan_grad_bucket(const sefd_plan* h, int32_t* op, int64_t* elem) {
   if (!h || h->p->bucket_op < 0) return -1;
   *op = h->p->bucket_op; *elem = h->p->bucket_elem;
@@ -142,12 +160,14 @@ int32_t sefd_plan_run_timed(const sefd_plan* h, int phase, void* const* arenas, 
 static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
                         std::vector<hipEvent_t>* tev) {
   if (!h || !h->p->error.empty()) return -1;
-  if (sefd::lstm_cluster_take_status() != 0) return -5;  // an earlier cluster-LSTM launch gave up waiting for a peer: its results (and everything after) are garbage
+  int* status = plan_status_word(h);
+  if (status && __atomic_load_n(status, __ATOMIC_RELAXED) != 0) return -5;   // an earlier launch of THIS plan gave up waiting (cluster LSTM): sticky until cleared
   const std::vector<Op>& ops = phase == 0 ? h->p->fwd : h->p->bwd;
   if (first < 0) first = 0;
   if (last < 0 || last > (int)ops.size()) last = (int)ops.size();
   ArenaBases ab;
   for (int a = 0; a < A_COUNT; ++a) ab.p[a] = reinterpret_cast<char*>(arenas[a]);
+  ab.status = status;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   auto launch = [&](const Op& op, hipStream_t s) {
     const size_t idx = (size_t)(&op - ops.data());
@@ -327,8 +347,107 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* est, const 
   }
 }
 
+// ---- short rows (FullSubNet.loss, models.py:674-682: the reductions of tools_for_loss.py run over the LAST axis of [B, F, T, 2], i.e. over
+// millions of two-element rows, and trainer.py:107 hands the network output over in the `target` slot).  One thread per row; every term is a
+// function f(see, set, stt) of the three inner products, so  d f / d est = 2 f_see est + f_set tgt,  d f / d tgt = f_set est + 2 f_stt tgt -
+// the gradient with respect to EITHER argument.  The differences (t - e, e - a t) are formed element-wise as the reference forms them, not
+// expanded (two-element rows of near-equal vectors cancel badly when expanded).
+constexpr int kRowsMaxL = 16;
+constexpr int kRowsMaxBlk = 4096;
+struct RowTerms { float v, fsee, fset, fstt; };
+
+__device__ __forceinline__ RowTerms row_terms(int kind, const float* e, const float* t, int L, float invR, float invRL) {
+  const float eps = 1e-8f, k10 = 4.342944819032518f;
+  float see = 0.f, set = 0.f, stt = 0.f, dd = 0.f;
+  for (int i = 0; i < L; ++i) { see += e[i] * e[i]; set += e[i] * t[i]; stt += t[i] * t[i]; const float d = t[i] - e[i]; dd += d * d; }
+  RowTerms r;
+  if (kind == SEFD_LOSS_MSE) {
+    r.v = dd * invRL; r.fsee = invRL; r.fset = -2.f * invRL; r.fstt = invRL;
+  } else if (kind == SEFD_LOSS_SDR) {            // -10 log10(stt^2 / (D^2 + eps)) / R, D = |t - e|^2, s1 = t (tools_for_loss.py:29-33)
+    r.v = -k10 * logf(stt * stt / (dd * dd + eps)) * invR;
+    const float q = k10 * invR * 2.f * dd / (dd * dd + eps);
+    r.fsee = q; r.fset = -2.f * q; r.fstt = -k10 * invR * 2.f / stt + q;
+  } else {
+    const bool snr = kind == SEFD_LOSS_SISNR;
+    const float den = snr ? stt + eps : stt;
+    const float a = snr ? set / den : set / den + eps;   // si_snr: <e,t>/(<t,t>+eps) ; si_sdr: <t,e>/<t,t> + eps
+    const float Tn = a * a * stt;
+    float Nn = 0.f;
+    for (int i = 0; i < L; ++i) { const float d = e[i] - a * t[i]; Nn += d * d; }
+    const float dNa = -2.f * set + 2.f * a * stt;          // d Nn / d a
+    const float da_dstt = snr ? -a / den : -set / (stt * stt);
+    if (snr) {                                             // -10 log10(Tn / (Nn + eps) + eps) / R    (:36-44)
+      const float Rr = Tn / (Nn + eps) + eps;
+      r.v = -k10 * logf(Rr) * invR;
+      const float g = -k10 * invR / Rr, A1 = 1.f / (Nn + eps), A2 = Tn / ((Nn + eps) * (Nn + eps));
+      r.fsee = g * (-A2);
+      r.fset = g * (A1 * 2.f * a * stt / den - A2 * (-2.f * a + dNa / den));
+      r.fstt = g * (A1 * (a * a + 2.f * a * stt * da_dstt) - A2 * (a * a + dNa * da_dstt));
+    } else {                                               // ratio = P / N + eps; the log follows the mean over rows   (:47-94)
+      r.v = Tn / Nn + eps;
+      const float q = Tn / (Nn * Nn);
+      r.fsee = -q;
+      r.fset = 2.f * a / Nn - q * (-2.f * a + dNa / den);
+      r.fstt = (a * a + 2.f * a * stt * da_dstt) / Nn - q * (a * a + dNa * da_dstt);
+    }
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void loss_rows_reduce_kernel(int kind, const float* est, const float* tgt, int64_t R, int L, float* part) {
+  const float invR = 1.f / (float)R, invRL = invR / (float)L;
+  float acc = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256)
+    acc += row_terms(kind, est + r * L, tgt + r * L, L, invR, invRL).v;
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ws: part [nblk] | G (SI-SDR: the factor -k10 / (mean + eps) / R of every row's ratio gradient; 1 otherwise)
+__global__ void loss_rows_finalize_kernel(int kind, int64_t R, int nblk, float* ws, float* loss_out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) acc += ws[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const float eps = 1e-8f, k10 = 4.342944819032518f;
+    if (kind == SEFD_LOSS_SISDR) {
+      const float m = red[0] / (float)R;
+      loss_out[0] = -k10 * logf(m + eps);
+      ws[nblk] = -k10 / (m + eps) / (float)R;
+    } else {
+      loss_out[0] = red[0];
+      ws[nblk] = 1.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_rows_grad_kernel(int kind, const float* est, const float* tgt, int64_t R, int L, const float* ws, int nblk,
+                                                            const float* gscale, float* gest, float* gtgt) {
+  const float invR = 1.f / (float)R, invRL = invR / (float)L;
+  const float gs = (gscale ? gscale[0] : 1.f) * ws[nblk];
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+    const float* e = est + r * L;
+    const float* t = tgt + r * L;
+    const RowTerms q = row_terms(kind, e, t, L, invR, invRL);
+    for (int i = 0; i < L; ++i) {
+      if (gest) gest[r * L + i] = gs * (2.f * q.fsee * e[i] + q.fset * t[i]);
+      if (gtgt) gtgt[r * L + i] = gs * (q.fset * e[i] + 2.f * q.fstt * t[i]);
+    }
+  }
+}
+static int rows_blocks(int64_t R) { const int64_t n = (R + 255) / 256; return (int)(n < kRowsMaxBlk ? n : kRowsMaxBlk); }
+
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
-                                                  float b1, float b2, float eps, float gscale) {
+                                                  float b1, float b2, float eps, float gscale, const int32_t* skip) {
+  // skip: the status word of the plan that produced g (host-mapped, system scope).  Set = a kernel of this step gave up and g is garbage:
+  // parameters and moments stay as they are (the host raises at its next look at the word)
+  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -358,14 +477,35 @@ int32_t sefd_loss_backward(int kind, const float* est, const float* tgt, int32_t
   hipLaunchKernelGGL(loss_grad_kernel, dim3(grid), dim3(256), 0, st, est, tgt, B, L, ws, grad_scale, grad_est);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+int64_t sefd_loss_rows_ws_floats(int64_t R) { return rows_blocks(R) + 16; }
+int32_t sefd_loss_rows_forward(int kind, const float* est, const float* tgt, int64_t R, int32_t L, float* ws, float* loss_out, void* stream) {
+  if (kind < 0 || kind > 3 || R < 1 || L < 1 || L > kRowsMaxL) return -1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nblk = rows_blocks(R);
+  hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(nblk), dim3(256), 0, st, kind, est, tgt, R, L, ws);
+  hipLaunchKernelGGL(loss_rows_finalize_kernel, dim3(1), dim3(256), 0, st, kind, R, nblk, ws, loss_out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int32_t sefd_loss_rows_backward(int kind, const float* est, const float* tgt, int64_t R, int32_t L, const float* ws, const float* grad_scale,
+                                float* grad_est, float* grad_tgt, void* stream) {
+  if (kind < 0 || kind > 3 || R < 1 || L < 1 || L > kRowsMaxL) return -1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nblk = rows_blocks(R);
+  hipLaunchKernelGGL(loss_rows_grad_kernel, dim3(nblk), dim3(256), 0, st, kind, est, tgt, R, L, ws, nblk, grad_scale, grad_est, grad_tgt);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  return sefd_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, nullptr, stream);
+}
+int32_t sefd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                               float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_if_set, void* stream) {
   if (n < 1 || step < 1) return -1;
   const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1), (float)std::sqrt(bc2),
-                     beta1, beta2, eps, grad_scale);
+                     beta1, beta2, eps, grad_scale, skip_if_set);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 }

@@ -11,7 +11,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 struct bf16_t { uint16_t v; };          // storage-only 16-bit type (sizeof == 2) used as the template tag of bf16 paths
 
-struct ArenaBases { char* p[A_COUNT]; };
+// status: host-mapped word of the PLAN that issues the launch (api.hip; 0 = fine), device-writable: a kernel that had to give up (the
+// cluster LSTM's bounded hand-over waits) sets it, sefd_adam_step_guarded skips the update while it is set, the host raises.
+struct ArenaBases { char* p[A_COUNT]; int* status; };
 
 __host__ __device__ __forceinline__ char* rp(const ArenaBases& ab, const Ptr& q) { return ab.p[q.arena] + q.off; }
 
@@ -141,7 +143,6 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);
 void launch_lstm_cluster(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);   // H > 128 (lstm_cluster.hip)
-int lstm_cluster_take_status();  // 1 once after a cluster launch whose hand-over wait ran out of budget (host-mapped word, read and cleared)
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);      // impl == 1 (lstm_rows.hip)
 
 }  // namespace sefd

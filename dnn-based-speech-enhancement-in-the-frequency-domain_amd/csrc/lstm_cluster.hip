@@ -16,7 +16,7 @@
 // ~50 us for the GEMM + cell launch pair per step this replaces (DCCRN-large: 203 ms of a 229 ms step).
 // Dispatch order: cluster members are consecutive block ids, so a partially resident cluster only ever waits for blocks that
 // are next in the dispatch queue; every spin is bounded (a latched budget) so a lost block cannot hang the device; a wave whose budget ran out reports it
-// in a host-mapped status word and the next sefd_plan_run returns -5 (lstm_cluster_take_status).
+// in the issuing plan's host-mapped status word: the guarded Adam skips the update and the plan's next run returns -5 (api.hip).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
@@ -68,7 +68,8 @@ __device__ __forceinline__ void gather(__amdgpu_buffer_rsrc_t r, uint32_t off0, 
 }
 
 // A wave that spent its whole budget consumed fragments its peers had not written: the launch's results are garbage.  It says so in a
-// host-mapped status word (system-scope store) that the next sefd_plan_run reads on the host - the step fails loudly instead of training on NaNs.
+// host-mapped status word of its plan (system-scope store): the guarded Adam kernel of the same step leaves the parameters untouched and the
+// host raises at the plan's next run / before a checkpoint is written - the step fails loudly instead of training on NaNs.
 __device__ __forceinline__ void report_timeout(int* status, int budget) {
   if (budget <= 0 && (threadIdx.x & 63) == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -480,7 +481,7 @@ static int pick_mt(const LstmRec& d, int nc) {
   return best;
 }
 
-// Host-mapped status word of the cluster kernels (0: fine; 1: a hand-over wait ran out of budget in some launch since the last check).
+// Fallback status word for launches issued without a plan's own word (ArenaBases::status == nullptr): host-mapped, never read by the library.
 static int* cluster_status_word() {
   static int* w = [] {
     int* q = nullptr;
@@ -490,19 +491,10 @@ static int* cluster_status_word() {
   }();
   return w;
 }
-static bool g_cluster_used = false;
-int lstm_cluster_take_status() {               // read and clear (host side; kernels that set it have long finished or are about to be re-run)
-  if (!g_cluster_used) return 0;
-  int* w = cluster_status_word();
-  if (!w) return 0;
-  const int v = __atomic_exchange_n(w, 0, __ATOMIC_RELAXED);
-  return v;
-}
 
 template <int H>
 static void launch_c(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
-  int* status = cluster_status_word();
-  g_cluster_used = true;
+  int* status = ab.status ? ab.status : cluster_status_word();      // the issuing plan's word (api.hip plan_run)
   const int mt = pick_mt(d, H / 64);
   const dim3 grid(H / 64, (d.B + 16 * mt - 1) / (16 * mt), d.G);
   if (fwd) {

@@ -176,6 +176,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
           const float b = !XK ? 0.f : q == 0 ? bias4.x : q == 1 ? bias4.y : q == 2 ? bias4.z : bias4.w;    // fused projection: the bias rides in the accumulator
           acc[mt][q] = f32x4{b, b, b, b};
         }
+      if constexpr (!XK) {
+        // hoisted input GEMM: its pre-activations are the accumulators' INITIAL value too - nothing is added onto fresh MFMA results in the
+        // epilogue in any variant (the sequence that was not reproducible run to run, note above mfma_settle; the cause at ISA level is unconfirmed)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float4 g = GateRaw<G16>::cvt(gxr[mt][r]);
+            acc[mt][0][r] = g.x; acc[mt][1][r] = g.y; acc[mt][2][r] = g.z; acc[mt][3][r] = g.w;
+          }
+      }
       // weight fragments in chunks of KC k-steps (fragment-major packing, sefd_desc.h rows_wf_index), A fragments from an LDS tile
       auto gemm_part = [&](const uint16_t* wbase, const uint16_t* atile) {
         uint4 bqA[KC][4];
@@ -215,21 +226,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
             acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa[mt]), __builtin_bit_cast(bf16x8, bx[q]), acc[mt][q], 0, 0, 0);
       }
       mfma_settle(acc);
-      float4 gxv[MT][4];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (XK) gxv[mt][r] = make_float4(0.f, 0.f, 0.f, 0.f); else gxv[mt][r] = GateRaw<G16>::cvt(gxr[mt][r]);
-        }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int rp2 = 0; rp2 < 4; rp2 += 2) {
-          const f32x2 ig = sigmoid2(f32x2{acc[mt][0][rp2] + gxv[mt][rp2].x, acc[mt][0][rp2 + 1] + gxv[mt][rp2 + 1].x});
-          const f32x2 fg = sigmoid2(f32x2{acc[mt][1][rp2] + gxv[mt][rp2].y, acc[mt][1][rp2 + 1] + gxv[mt][rp2 + 1].y});
-          const f32x2 gg = tanh2(f32x2{acc[mt][2][rp2] + gxv[mt][rp2].z, acc[mt][2][rp2 + 1] + gxv[mt][rp2 + 1].z});
-          const f32x2 og = sigmoid2(f32x2{acc[mt][3][rp2] + gxv[mt][rp2].w, acc[mt][3][rp2 + 1] + gxv[mt][rp2 + 1].w});
+          const f32x2 ig = sigmoid2(f32x2{acc[mt][0][rp2], acc[mt][0][rp2 + 1]});
+          const f32x2 fg = sigmoid2(f32x2{acc[mt][1][rp2], acc[mt][1][rp2 + 1]});
+          const f32x2 gg = tanh2(f32x2{acc[mt][2][rp2], acc[mt][2][rp2 + 1]});
+          const f32x2 og = sigmoid2(f32x2{acc[mt][3][rp2], acc[mt][3][rp2 + 1]});
           const f32x2 cn = fma2(fg, f32x2{cpv[mt][rp2], cpv[mt][rp2 + 1]}, ig * gg);
           const f32x2 hv = og * tanh2(cn);
 #pragma unroll

@@ -14,15 +14,23 @@ BatchNorm statistics stay per rank by default (standard DDP semantics; SURVEY.md
 use; `GradientExchange(sync_bn=True)` switches `train_step` to SyncBN plans (statistics over all ranks: N ranks x B/N
 utterances == the reference's single process with batch B; tests/test_ddp_gloo.py pins that with world size 2).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class GradientExchange:
-    def __init__(self, process_group=None, sync_bn=False):
+    def __init__(self, process_group=None, sync_bn=False, force=None):
         self.pg = process_group
         self.sync_bn = bool(sync_bn)     # True: BatchNorm statistics over all ranks (22 small all-reduces per step, parity mode)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # active: the exchange path (bucketed plans, communication stream, collectives) runs.  Always with more than one rank; with ONE rank
+        # only on request (force=True / SEFD_DDP_FORCE=1): RCCL accepts a one-rank communicator, which lets a single-GPU box execute
+        # init_process_group("nccl", device_id=...), begin / finish on the communication stream and the plan callback on RCCL itself
+        # (tests/test_gpu_ddp_smoke.py) - the collectives are then identities.
+        force = bool(int(os.environ.get("SEFD_DDP_FORCE", "0"))) if force is None else bool(force)
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.stream = None
 
     @property
@@ -32,7 +40,7 @@ class GradientExchange:
     def begin(self, part: torch.Tensor):
         """Start the sum all-reduce of `part` (a slice of the flat gradient) behind everything enqueued so far on the current
         stream, on the communication stream; `finish()` makes the current stream wait for it."""
-        if self.world == 1:
+        if not self.active:
             return
         if part.is_cuda:
             if self.stream is None:
@@ -44,12 +52,12 @@ class GradientExchange:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
 
     def finish(self, part: torch.Tensor):
-        if self.world > 1 and part.is_cuda and self.stream is not None:
+        if self.active and part.is_cuda and self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 
     def all_reduce(self, flat_grad: torch.Tensor, bounds=None):
         """Sum-all-reduce `flat_grad` in place.  `bounds` = optional list of (lo, hi) element ranges (buckets)."""
-        if self.world == 1:
+        if not self.active:
             return
         if flat_grad.is_cuda:
             if self.stream is None:
@@ -67,15 +75,14 @@ class GradientExchange:
     def all_reduce_stats(self, t: torch.Tensor):
         """SyncBN sync point: in-place sum of a per-channel statistics buffer (2*C values) over the ranks, ordered on the
         current stream (torch's NCCL wrapper inserts the stream dependencies)."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-
 
     # ---- what the epoch driver needs besides the gradient exchange (train_interface.run)
     def broadcast_model(self, model):
         """Rank 0's parameters and BatchNorm buffers to every rank, once before the first step: each process builds its model with its
         own RNG state, and the all-reduce only keeps replicas identical if they start identical."""
-        if self.world == 1:
+        if not self.active:
             return
         tensors = [t for t in (getattr(model, "_flat_param", None), getattr(model, "_flat_state", None), getattr(model, "_flat_nbt", None))
                    if t is not None]
@@ -87,23 +94,28 @@ class GradientExchange:
     def all_reduce_autograd(self, params):
         """The literal `loss.backward()` route under DDP (direct-mapping trainers, foreign optimizers): p.grad <- mean over ranks,
         as one flat all-reduce.  No overlap with the backward - the fused `train_step` is the fast path."""
-        if self.world == 1:
+        if not self.active:
             return
-        ps = [p for p in params if p.grad is not None]
+        # every rank flattens ALL parameters (zeros where this rank produced no gradient): the ranks then issue all-reduces of the same
+        # size whatever subset of parameters each of them touched
+        ps = list(params)
         if not ps:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
         self.all_reduce(flat)
         flat *= self.grad_scale
         off = 0
         for p in ps:
-            n = p.grad.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].view_as(p).to(p.dtype).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
 
     def mean_scalars(self, values):
         """Mean over ranks of a few host / device scalars (validation losses: every rank scores its own shard)."""
-        if self.world == 1:
+        if not self.active:
             return [float(v) for v in values]
         dev = next((v.device for v in values if torch.is_tensor(v)), torch.device("cpu"))
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)

@@ -6,6 +6,7 @@ checkpoints interchange - SURVEY.md Appendix B).  All arithmetic - STFT, complex
 LSTM, mask, iSTFT, losses, backward, Adam - runs in `libsefd_hip.so`; there is no PyTorch/CPU fallback.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -217,6 +218,7 @@ class _SefdModule(nn.Module):
         rt = self._runtimes.get(key)
         if rt is None:
             rt = _Runtime(self, B, L, bool(self.training), device)
+            rt.plan.owner = weakref.ref(self)            # running it makes it this model's `_status_plan` (guarded Adam, checkpoint check)
             # the plan's parameter table must agree with the module tree (names, order, sizes)
             names = [n for n, _ in self._trainable()]
             assert names == list(rt.plan.params.keys()), "parameter order differs from the plan"
@@ -255,7 +257,7 @@ class _SefdModule(nn.Module):
         if not isinstance(optimizer, Adam):
             raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
-        if exchange is not None and exchange.world > 1 and (loss_kind or cfg.loss) == 'SI-SDR':
+        if exchange is not None and exchange.world > 1 and (loss_kind or cfg.loss) == 'SI-SDR':  # (one forced rank: exact)
             # tools_for_loss.py:91-94 takes the batch mean of the ratios INSIDE the log: rank-averaged gradients of per-rank losses are not
             # the gradient of the global-batch loss; every other loss is a mean of per-utterance terms and shards exactly
             raise NotImplementedError("cfg.loss == 'SI-SDR' does not decompose over data-parallel ranks (mean of ratios inside the log); "
@@ -266,10 +268,10 @@ class _SefdModule(nn.Module):
         # SyncBN (exchange.sync_bn): a plan whose BatchNorm counts are global and whose phases are run in the op ranges
         # between its sync points, with the small statistics buffers all-reduced in between (parity with the reference's
         # single-process big batch).  Default: per-rank statistics, whole phases (two-lane backward).
-        sync = exchange is not None and exchange.world > 1 and getattr(exchange, "sync_bn", False)
+        sync = exchange is not None and exchange.active and getattr(exchange, "sync_bn", False)
         self._bn_world = exchange.world if sync else 1
         # data parallel: plans with two gradient buckets (decoder + LSTM complete before the encoder backward, see ddp.py)
-        self._grad_buckets = 2 if (exchange is not None and exchange.world > 1 and not sync) else 1
+        self._grad_buckets = 2 if (exchange is not None and exchange.active and not sync) else 1
         rt = self._runtime(B, L, inputs.device)
         optimizer.bind(self)
         self._flat_nbt += 1
@@ -312,7 +314,7 @@ class _SefdModule(nn.Module):
             rt.plan.run_cb(PHASE_BWD, rt.arenas, stream, op, lambda: exchange.begin(self._flat_grad[lo:]))   # under the encoder backward
         else:
             rt.run(PHASE_BWD)
-        if exchange is not None and exchange.world > 1:      # DDP: sum gradients over ranks (RCCL), average inside Adam
+        if exchange is not None and exchange.active:         # DDP: sum gradients over ranks (RCCL), average inside Adam
             if bucket is not None:
                 exchange.begin(self._flat_grad[:bucket[1]])
                 exchange.finish(self._flat_grad)
@@ -592,6 +594,7 @@ class FullSubNet(_SefdModule):
         if rt is None:
             plan = Plan(B, T, fft_len=2 * (self.num_freqs - 1), act_dtype=self.act_dtype, training=True, model="FullSubNet",
                         fsn=dict(self._fsn, keep=keep))
+            plan.owner = weakref.ref(self)
             assert [n for n, _ in self._trainable()] == list(plan.params.keys()), "parameter order differs from the plan"
             ar = [None] * ARENA_COUNT
             ar[ARENA_WS] = torch.zeros(max(plan.arena_bytes[ARENA_WS], 256), dtype=torch.uint8, device=device)
@@ -615,10 +618,15 @@ class FullSubNet(_SefdModule):
         return _FSNFunction.apply(self, rt, noisy_mag, *[p for _, p in self._trainable()])
 
     def loss(self, estimated, target):
-        """models.py:674-682.  cfg.loss == 'MSE' is the configuration the reference trains FullSubNet with."""
-        if cfg.loss != 'MSE':
-            raise NotImplementedError("FullSubNet.loss: only cfg.loss == 'MSE' is on the HIP path")
-        return tfl.mse(estimated.reshape(estimated.shape[0], -1), target.reshape(target.shape[0], -1))
+        """models.py:674-682: the four losses over the LAST axis (the real / imaginary pair of the [B, F, T, 2] masks)."""
+        if cfg.loss == 'MSE':
+            return tfl.mse(estimated.reshape(estimated.shape[0], -1), target.reshape(target.shape[0], -1))
+        elif cfg.loss == 'SDR':
+            return -tfl.sdr(target, estimated)
+        elif cfg.loss == 'SI-SNR':
+            return -tfl.si_snr(estimated, target)
+        elif cfg.loss == 'SI-SDR':
+            return -tfl.si_sdr(target, estimated)
 
     def train_step(self, inputs, targets, optimizer, loss_kind=None, exchange=None):
         """fullsubnet_train body (trainer.py:95-111), fused: stft x2 -> |.|, cIRM -> forward -> MSE -> backward -> Adam."""
@@ -635,11 +643,19 @@ class FullSubNet(_SefdModule):
         plan.io(ar, "mag", (B, F, T)).copy_(noisy_mag)
         plan.view(ar, "io.seed").view(torch.int32)[:1].add_(1)
         plan.run(PHASE_FWD, ar, stream)
-        crm = plan.io(ar, "crm", (B, F * T * 2))
-        ws, loss = tfl.loss_forward_raw(0, crm, cirm.view(B, -1), stream)
-        tfl.loss_backward_raw(0, crm, cirm.view(B, -1), ws, None, plan.io(ar, "grad_crm", (B, F * T * 2)), stream)
+        kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
+        if kind == 0:
+            crm = plan.io(ar, "crm", (B, F * T * 2))
+            ws, loss = tfl.loss_forward_raw(0, crm, cirm.view(B, -1), stream)
+            tfl.loss_backward_raw(0, crm, cirm.view(B, -1), ws, None, plan.io(ar, "grad_crm", (B, F * T * 2)), stream)
+        else:
+            # model.loss(cIRM, cRM) (trainer.py:107): in all three the cIRM sits in the kernels' `est` role and the network output in
+            # the `tgt` role (sdr(s1 = cRM, s2 = cIRM), si_snr(s1 = cIRM, s2 = cRM), si_sdr(reference = cRM, estimation = cIRM))
+            crm = plan.io(ar, "crm", (B * F * T, 2))
+            ws, loss = tfl.loss_rows_forward_raw(kind, cirm.view(-1, 2), crm, stream)
+            tfl.loss_rows_backward_raw(kind, cirm.view(-1, 2), crm, ws, None, None, plan.io(ar, "grad_crm", (B * F * T, 2)), stream)
         plan.run(PHASE_BWD, ar, stream)
-        if exchange is not None and exchange.world > 1:
+        if exchange is not None and exchange.active:
             exchange.all_reduce(self._flat_grad)
             optimizer.grad_scale = exchange.grad_scale
         optimizer.step_flat()

@@ -57,12 +57,17 @@ class Adam(torch.optim.Optimizer):
         g = m._flat_grad if grad is None else grad
         self._step += 1
         grp = self.param_groups[0]
-        rc = _lib.lib().sefd_adam_step(C.c_void_p(m._flat_param.data_ptr()), C.c_void_p(g.data_ptr()),
-                                       C.c_void_p(self._m.data_ptr()), C.c_void_p(self._v.data_ptr()),
-                                       m._flat_param.numel(), self._step, grp["lr"], grp["betas"][0], grp["betas"][1],
-                                       grp["eps"], self.grad_scale, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        # guarded by the status word of the plan that produced the gradient: a kernel of that plan that gave up (cluster LSTM hand-over
+        # timeout) set it earlier on this stream, and the update is then skipped on the device - no garbage step, no host sync here
+        plan = getattr(m, "_status_plan", None)
+        guard = plan.status_word() if plan is not None else None
+        rc = _lib.lib().sefd_adam_step_guarded(C.c_void_p(m._flat_param.data_ptr()), C.c_void_p(g.data_ptr()),
+                                               C.c_void_p(self._m.data_ptr()), C.c_void_p(self._v.data_ptr()),
+                                               m._flat_param.numel(), self._step, grp["lr"], grp["betas"][0], grp["betas"][1],
+                                               grp["eps"], self.grad_scale, C.c_void_p(guard) if guard else None,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"sefd_adam_step failed ({rc})")
+            raise RuntimeError(f"sefd_adam_step_guarded failed ({rc})")
 
     @torch.no_grad()
     def step(self, closure=None):

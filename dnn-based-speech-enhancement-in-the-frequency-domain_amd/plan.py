@@ -168,13 +168,32 @@ class Plan:
             return None
         return op.value, el.value
 
+    # ---- per-plan status word (a kernel that had to give up - the cluster LSTM's bounded hand-over waits - sets it)
+    owner = None                 # weakref to the model this plan belongs to: running the plan makes it the model's `_status_plan`
+
+    def _mark(self):
+        o = self.owner() if self.owner is not None else None
+        if o is not None:
+            o._status_plan = self
+
+    def status_word(self):
+        """Device-readable address of the word (sefd_adam_step_guarded's skip_if_set)."""
+        return self.lib.sefd_plan_status_word(self.h)
+
+    def status(self, clear=False):
+        return int(self.lib.sefd_plan_status(self.h, 1 if clear else 0))
+
+    _RC5 = (": a cluster-LSTM launch of this plan gave up waiting for a peer workgroup (GPU shared or preempted?) - that step's results "
+            "are invalid; the guarded Adam left the parameters untouched (Plan.status(clear=True) re-arms the plan)")
+
     def run_cb(self, phase, arenas, stream, at, fn):
         """Whole phase (two-lane schedule); `fn()` runs on the host right after op `at` has been enqueued."""
+        self._mark()
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _ctx: fn())
         rc = self.lib.sefd_plan_run_cb(self.h, phase, ptrs, C.c_void_p(stream), at, cb, None)
         if rc != 0:
-            raise RuntimeError(f"sefd_plan_run_cb failed ({rc})")
+            raise RuntimeError(f"sefd_plan_run_cb failed ({rc})" + (self._RC5 if rc == -5 else ""))
 
     def run_timed(self, phase, arenas, stream=0):
         """Whole phase in the real two-lane schedule with HIP events around every op (measurement): list of per-op milliseconds."""
@@ -187,8 +206,8 @@ class Plan:
         return list(ms)
 
     def run(self, phase, arenas, stream=0, first=0, last=-1):
+        self._mark()
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         rc = self.lib.sefd_plan_run(self.h, phase, first, last, ptrs, C.c_void_p(stream))
         if rc != 0:
-            raise RuntimeError(f"sefd_plan_run failed ({rc})" + (": a cluster-LSTM launch of the previous call gave up waiting for a peer workgroup "
-                               "(GPU shared or preempted?) - that step's results are invalid" if rc == -5 else ""))
+            raise RuntimeError(f"sefd_plan_run failed ({rc})" + (self._RC5 if rc == -5 else ""))

@@ -39,13 +39,65 @@ def loss_backward_raw(kind, est, tgt, ws, grad_scale, grad_out, stream):
         raise RuntimeError(f"sefd_loss_backward failed ({rc})")
 
 
+ROWS_MAX_L = 16                  # rows this short take the one-thread-per-row kernels (sefd_loss_rows_*): FullSubNet.loss, models.py:674-682
+
+
+def loss_rows_forward_raw(kind, est, tgt, stream):
+    """est, tgt: fp32 [R, L], L <= ROWS_MAX_L."""
+    L_ = _lib.lib()
+    R, L = est.shape
+    ws = torch.empty(L_.sefd_loss_rows_ws_floats(R), dtype=torch.float32, device=est.device)
+    out = torch.empty((), dtype=torch.float32, device=est.device)
+    rc = L_.sefd_loss_rows_forward(kind, _vp(est), _vp(tgt), R, L, _vp(ws), _vp(out), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"sefd_loss_rows_forward failed ({rc})")
+    return ws, out
+
+
+def loss_rows_backward_raw(kind, est, tgt, ws, grad_scale, grad_est, grad_tgt, stream):
+    R, L = est.shape
+    rc = _lib.lib().sefd_loss_rows_backward(kind, _vp(est), _vp(tgt), R, L, _vp(ws), _vp(grad_scale), _vp(grad_est), _vp(grad_tgt), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"sefd_loss_rows_backward failed ({rc})")
+
+
+class _LossRows(torch.autograd.Function):
+    """Same value as _Loss for rows of at most ROWS_MAX_L elements, differentiable with respect to BOTH arguments (the reference's
+    fullsubnet_train passes the network output in the `target` slot, trainer.py:107)."""
+
+    @staticmethod
+    def forward(ctx, kind, est, tgt):
+        est2 = est.float().contiguous().view(-1, est.shape[-1])
+        tgt2 = tgt.float().contiguous().view(-1, tgt.shape[-1])
+        ws, out = loss_rows_forward_raw(kind, est2, tgt2, torch.cuda.current_stream().cuda_stream)
+        ctx.kind, ctx.shape = kind, est.shape
+        ctx.save_for_backward(est2, tgt2, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        est2, tgt2, ws = ctx.saved_tensors
+        ge = torch.empty_like(est2) if ctx.needs_input_grad[1] else None
+        gt = torch.empty_like(tgt2) if ctx.needs_input_grad[2] else None
+        loss_rows_backward_raw(ctx.kind, est2, tgt2, ws, g.float().contiguous().view(1), ge, gt, torch.cuda.current_stream().cuda_stream)
+        return None, (ge.view(ctx.shape) if ge is not None else None), (gt.view(ctx.shape) if gt is not None else None)
+
+
+def _loss(kind, est, tgt):
+    if not (est.is_cuda and tgt.is_cuda):
+        raise RuntimeError("sefd losses run on the MI355X only (cuda tensors); there is no CPU fallback")
+    if est.shape[-1] <= ROWS_MAX_L:
+        return _LossRows.apply(kind, est, tgt)
+    if tgt.requires_grad:
+        raise NotImplementedError("the long-row loss kernels differentiate the estimate only (rows longer than %d elements)" % ROWS_MAX_L)
+    return _Loss.apply(kind, est, tgt)
+
+
 class _Loss(torch.autograd.Function):
     """value = the quantity the fused kernel computes: the *negated* metric for SDR / SI-SNR / SI-SDR, the MSE itself."""
 
     @staticmethod
     def forward(ctx, kind, est, tgt):
-        if not (est.is_cuda and tgt.is_cuda):
-            raise RuntimeError("sefd losses run on the MI355X only (cuda tensors); there is no CPU fallback")
         est2 = est.float().contiguous().view(-1, est.shape[-1])
         tgt2 = tgt.float().contiguous().view(-1, tgt.shape[-1])
         stream = torch.cuda.current_stream().cuda_stream
@@ -68,22 +120,22 @@ def mse(estimated, target):
     (FullSubNet calls model.loss(cIRM, cRM) with the network output in the `target` slot, trainer.py:107)."""
     if target.requires_grad and not estimated.requires_grad:
         estimated, target = target, estimated
-    return _Loss.apply(0, estimated, target)
+    return _loss(0, estimated, target)
 
 
 def sdr(s1, s2, eps=1e-8):
     """tools_for_loss.py:29-33: s1 = target, s2 = estimate.  Returns +SDR (the model negates it, models.py:319)."""
-    return -_Loss.apply(1, s2, s1)
+    return -_loss(1, s2, s1)
 
 
 def si_snr(s1, s2, eps=1e-8):
     """tools_for_loss.py:36-44: s1 = estimate, s2 = target."""
-    return -_Loss.apply(2, s1, s2)
+    return -_loss(2, s1, s2)
 
 
 def si_sdr(reference, estimation, eps=1e-8):
     """tools_for_loss.py:47-94."""
-    return -_Loss.apply(3, estimation, reference)
+    return -_loss(3, estimation, reference)
 
 
 # ------------------------------------------------------------------------------------------ LMS (tools_for_loss.py:120-249)

@@ -46,7 +46,13 @@ def build_model(DEVICE):
 
 
 def save_checkpoint(path, model, optimizer, epoch):
-    """train_interface.py:166-171 / 204-210."""
+    """train_interface.py:166-171 / 204-210.  A step whose kernels gave up (Plan.status) never reached the parameters (guarded Adam), but it
+    is an error all the same: checked here, behind a device synchronisation, BEFORE anything is written."""
+    plan = getattr(model, "_status_plan", None)
+    if plan is not None:
+        torch.cuda.synchronize()
+        if plan.status() != 0:
+            raise RuntimeError("checkpoint not written" + plan._RC5)
     torch.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch}, path)
 
 

@@ -28,7 +28,7 @@ def model_train(model, optimizer, train_loader, DEVICE, exchange=None):
             loss = model.loss(outputs, targets)
             optimizer.zero_grad()
             loss.backward()
-            _exchange_grads(model, exchange)
+            _exchange_grads(model, exchange, optimizer)
             optimizer.step()
         train_loss += loss.detach()          # the reference accumulates the graph-attached tensor (trainer.py:39)
     return train_loss / max(batch_num, 1)
@@ -56,7 +56,7 @@ def model_perceptual_train(model, optimizer, train_loader, DEVICE, exchange=None
             loss = (main_loss + perceptual_loss) / 2
             optimizer.zero_grad()
             loss.backward()
-            _exchange_grads(model, exchange)
+            _exchange_grads(model, exchange, optimizer)
             optimizer.step()
         train_loss += loss.detach()
         train_main += main_loss.detach()
@@ -65,12 +65,15 @@ def model_perceptual_train(model, optimizer, train_loader, DEVICE, exchange=None
     return train_loss / n, train_main / n, train_perc / n
 
 
-def _exchange_grads(model, exchange):
-    """Data-parallel step of the `loss.backward()` route: p.grad <- mean over ranks (ddp.GradientExchange.all_reduce_autograd)."""
-    if exchange is not None and exchange.world > 1:
-        if cfg.loss == 'SI-SDR':
+def _exchange_grads(model, exchange, optimizer=None):
+    """Data-parallel step of the `loss.backward()` route: p.grad <- mean over ranks (ddp.GradientExchange.all_reduce_autograd).  The mean is
+    formed here, so a fused-step 1/world left in the sefd Adam (models.train_step sets optimizer.grad_scale) must not be applied again."""
+    if exchange is not None and exchange.active:
+        if cfg.loss == 'SI-SDR' and exchange.world > 1:
             raise NotImplementedError("cfg.loss == 'SI-SDR' does not decompose over data-parallel ranks (tools_for_loss.py:91-94)")
         exchange.all_reduce_autograd(list(model.parameters()))
+        if optimizer is not None and hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = 1.0
 
 
 def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
@@ -95,7 +98,7 @@ def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
             loss = model.loss(cIRM, cRM)
             optimizer.zero_grad()
             loss.backward()
-            _exchange_grads(model, exchange)
+            _exchange_grads(model, exchange, optimizer)
             optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
@@ -117,7 +120,7 @@ def dccrn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
         loss = (real_loss + imag_loss) / 2
         optimizer.zero_grad()
         loss.backward()
-        _exchange_grads(model, exchange)
+        _exchange_grads(model, exchange, optimizer)
         optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)
@@ -137,7 +140,7 @@ def crn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
         loss = model.loss(output_mag, target_mag)
         optimizer.zero_grad()
         loss.backward()
-        _exchange_grads(model, exchange)
+        _exchange_grads(model, exchange, optimizer)
         optimizer.step()
         train_loss += loss.detach()
     return train_loss / max(batch_num, 1)

@@ -107,6 +107,15 @@ int32_t sefd_loss_forward(int kind, const float* est, const float* tgt, int32_t 
 int32_t sefd_loss_backward(int kind, const float* est, const float* tgt, int32_t B, int32_t L, const float* ws,
                            const float* grad_scale, float* grad_est, void* stream);
 
+/* Short rows: FullSubNet.loss (models.py:674-682) applies the same four losses to cRM / cIRM tensors [B, F, T, 2], whose last axis - the
+ * reduction axis of tools_for_loss.py:17-94 - has two elements, and trainer.py:107 passes the network output in the `target` slot.
+ * est, tgt: fp32 [R][L] device, L <= 16, same argument roles as above (SDR: est = s2, tgt = s1; SI-SNR: est = s1, tgt = s2; SI-SDR:
+ * est = estimation, tgt = reference).  backward writes d(loss)/d(est) and / or d(loss)/d(tgt) (either pointer may be NULL), times grad_scale[0]. */
+int64_t sefd_loss_rows_ws_floats(int64_t R);
+int32_t sefd_loss_rows_forward(int kind, const float* est, const float* tgt, int64_t R, int32_t L, float* ws, float* loss_out, void* stream);
+int32_t sefd_loss_rows_backward(int kind, const float* est, const float* tgt, int64_t R, int32_t L, const float* ws, const float* grad_scale,
+                                float* grad_est, float* grad_tgt, void* stream);
+
 /* ---- LMS log-mel perceptual loss (tools_for_loss.py:120-249 + the magnitude step of models.py:306-312) ------------
  * clean_* / est_*: fp32 [B][NF][T] device (reference layout).  If the *_i pointers are NULL the *_r arrays are magnitudes
  * already (get_array_lms_loss(clean_mags, est_mags) signature); otherwise mag = sqrt(r^2 + i^2 + 1e-7) is fused in.
@@ -151,6 +160,15 @@ int32_t sefd_fsn_targets(const float* noisy_c64, const float* clean_c64, int64_t
  * step is 1-based. */
 int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same update, skipped entirely (parameters and moments untouched) while *skip_if_set != 0.  skip_if_set = sefd_plan_status_word(plan)
+ * of the plan that produced `grad`: a kernel of that plan that had to give up (bounded hand-over waits of the cluster LSTM kernels on a
+ * shared / preempted GPU) sets the word, so a garbage gradient never reaches the parameters; NULL = unconditional. */
+int32_t sefd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                               float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_if_set, void* stream);
+/* Per-plan status word (host-mapped, device-readable; 0 = fine).  sefd_plan_run returns -5 while it is set (sticky);
+ * sefd_plan_status reads it (after a stream synchronisation for a definite answer) and optionally clears it. */
+const int32_t* sefd_plan_status_word(const sefd_plan* p);
+int32_t sefd_plan_status(const sefd_plan* p, int32_t clear);
 
 #ifdef __cplusplus
 }

@@ -200,9 +200,11 @@ def crn_case(cfg, models, name, kernel_num, rnn_units, rnn_input, mask, loss, B,
     print(f"crn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
 
 
-def fsn_case(cfg, models, tfm, name, B, L, hidden=(512, 384), sequence_model="LSTM", norm_type="offline_laplace_norm"):
-    """FullSubNet train step with the LSTM inter-layer dropout patched to 0 (p = 0.8 makes train mode stochastic)."""
-    cfg.loss = "MSE"
+def fsn_case(cfg, models, tfm, name, B, L, hidden=(512, 384), sequence_model="LSTM", norm_type="offline_laplace_norm", loss="MSE"):
+    """FullSubNet train step with the LSTM inter-layer dropout patched to 0 (p = 0.8 makes train mode stochastic).
+    loss != 'MSE': FullSubNet.loss (models.py:674-682) reduces over the LAST axis of [B, F, T, 2] - two-element rows -, and the trainer
+    passes the network output in the `target` slot (trainer.py:107): the gradient flows through s1 of sdr, s2 of si_snr, `reference` of si_sdr."""
+    cfg.loss = loss
     torch.manual_seed(0)
     m = models.FullSubNet(fb_model_hidden_size=hidden[0], sb_model_hidden_size=hidden[1], sequence_model=sequence_model, norm_type=norm_type)
     fill_state_dict_(m)
@@ -222,7 +224,8 @@ def fsn_case(cfg, models, tfm, name, B, L, hidden=(512, 384), sequence_model="LS
     opt.step()
     sd = m.state_dict()
     small = lambda k: "bias" in k or k.startswith("sb_model.fc_output_layer")
-    rec = dict(meta=dict(B=B, L=L, fb_hidden=hidden[0], sb_hidden=hidden[1], sequence_model=sequence_model, norm_type=norm_type),
+    cfg.loss = "MSE"
+    rec = dict(meta=dict(B=B, L=L, fb_hidden=hidden[0], sb_hidden=hidden[1], sequence_model=sequence_model, norm_type=norm_type, loss=np.array(loss)),
                noisy_mag=noisy_mag.numpy()[:, ::4, ::3], cirm=cirm.numpy()[:, ::4, ::3], crm=crm.detach().numpy(), loss=float(lossv),
                grad_norm={k: float(v.double().norm()) for k, v in g.items()},
                grad={k: v.numpy() for k, v in g.items() if small(k)},
@@ -230,6 +233,12 @@ def fsn_case(cfg, models, tfm, name, B, L, hidden=(512, 384), sequence_model="LS
                after_adam={k: sd[k].numpy().copy() for k in g if small(k)})
     np.savez_compressed(os.path.join(HERE, f"fsn_{name}.npz"), **flat(rec, "g"))
     print(f"fsn_{name}: loss {float(lossv):.6f}")
+
+
+def fsn_losses(cfg, models, tfm):
+    fsn_case(cfg, models, tfm, "small_sdr", 2, 6000, hidden=(128, 64), loss="SDR")        # config.py:36: the reference's DEFAULT cfg.loss
+    fsn_case(cfg, models, tfm, "small_sisnr", 2, 6000, hidden=(128, 64), loss="SI-SNR")
+    fsn_case(cfg, models, tfm, "small_sisdr", 2, 6000, hidden=(128, 64), loss="SI-SDR")
 
 
 def fsn_variants(cfg, models, tfm):
@@ -351,6 +360,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fsn_variants":  # cfg.sequence_model == 'GRU' and the three other norm_type choices
         fsn_variants(cfg, models, tfm)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "fsn_losses":    # FullSubNet.loss with SDR / SI-SNR / SI-SDR
+        fsn_losses(cfg, models, tfm)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "eval":          # regenerate only the validation-path case
         dccrn_eval_case(cfg, models, "small_eval", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", 2, 4000, 3, 5000)
         return
@@ -371,6 +383,7 @@ def main():
     fsn_case(cfg, models, tfm, "default_mse", 2, 6000)
     fsn_case(cfg, models, tfm, "small_mse", 2, 6000, hidden=(128, 64))
     fsn_variants(cfg, models, tfm)
+    fsn_losses(cfg, models, tfm)
     dccrn_eval_case(cfg, models, "small_eval", small, 128, "C", "SI-SNR", 2, 4000, 3, 5000)
     dccrn_case(cfg, models, "wide_C_sdr", small, 512, "C", "SDR", False, 1, 2000, store_taps=False)
     dccrn_case(cfg, models, "real_E_sisnr", small, 256, "E", "SI-SNR", False, 2, 3000, store_taps=False, lstm="real")

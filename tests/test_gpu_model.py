@@ -357,14 +357,18 @@ def test_dccrn_lms_joint_step_against_reference_golden():
                                                ("small_gru_mse", (128, 64), "GRU", "offline_laplace_norm"),
                                                ("small_cumlaplace_mse", (128, 64), "LSTM", "cumulative_laplace_norm"),
                                                ("small_gaussian_mse", (128, 64), "LSTM", "offline_gaussian_norm"),
-                                               ("small_cumlayer_gru_mse", (128, 64), "GRU", "cumulative_layer_norm")])
+                                               ("small_cumlayer_gru_mse", (128, 64), "GRU", "cumulative_layer_norm"),
+                                               ("small_sdr", (128, 64), "LSTM", "offline_laplace_norm"),
+                                               ("small_sisnr", (128, 64), "LSTM", "offline_laplace_norm"),
+                                               ("small_sisdr", (128, 64), "LSTM", "offline_laplace_norm")])
 def test_fullsubnet_step_against_reference_golden(name, hid, seq, norm):
-    """trainer.py:85-118 with the inter-layer dropout disabled on both sides; cfg.sequence_model / cfg.norm_type variants."""
+    """trainer.py:85-118 with the inter-layer dropout disabled on both sides (SURVEY Q6); cfg.sequence_model / cfg.norm_type variants;
+    FullSubNet.loss (models.py:674-682) with cfg.loss = SDR (config.py:36: the reference's default) / SI-SNR / SI-SDR over the 2-element last axis."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models, tools_for_model as tools
     g = load_golden("fsn_" + name)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
-    cfg.loss, cfg.act_dtype = "MSE", "fp32"
+    cfg.loss, cfg.act_dtype = (str(g["g/meta/loss"]) if "g/meta/loss" in g else "MSE"), "fp32"
     m = models.FullSubNet(fb_model_hidden_size=hid[0], sb_model_hidden_size=hid[1], sequence_model=seq, norm_type=norm)
     fill_state_dict_(m)
     m = m.to("cuda").train()
@@ -381,8 +385,9 @@ def test_fullsubnet_step_against_reference_golden(name, hid, seq, norm):
     lossv = m.loss(cirm, crm)
     opt.zero_grad()
     lossv.backward()
+    loss_kind, cfg.loss = cfg.loss, "MSE"
     assert rel_err(crm, g["g/crm"]) < TOL
-    assert abs(float(lossv) - float(g["g/loss"])) < TOL * float(g["g/loss"])
+    assert abs(float(lossv) - float(g["g/loss"])) < TOL * abs(float(g["g/loss"]))
     grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
     for k, v in sub(g, "g/grad_norm").items():
         assert abs(float(grads[k].double().norm()) - float(v)) <= TOL * float(v) + 1e-9, k
@@ -390,6 +395,14 @@ def test_fullsubnet_step_against_reference_golden(name, hid, seq, norm):
         assert rel_l2(grads[k], v) < TOL, k
     for k, v in sub(g, "g/grad_samp").items():
         assert rel_l2(grads[k].reshape(-1)[::211], v) < TOL, k
+    if loss_kind != "MSE":                       # the fused step (plan io buffers, no autograd) computes the same loss
+        from sefd_amd.optim import Adam
+        m.zero_grad()
+        fused = float(m.train_step(x, y, Adam(m.parameters(), lr=1e-3), loss_kind=loss_kind))
+        assert abs(fused - float(g["g/loss"])) < TOL * abs(float(g["g/loss"]))
+        sd = m.state_dict()
+        for k, v in sub(g, "g/after_adam").items():
+            assert np.abs(sd[k].cpu().numpy() - v).max() < 5e-5, k
 
 
 def test_fullsubnet_fused_train_step_and_dropout():
@@ -650,11 +663,11 @@ def test_bf16_fullsubnet_at_bench_size():
 
 
 def test_bf16_dccrn_large_at_bench_size():
-    """BASELINE configs[4] per-GPU shard as benched (B = 32): DCCRN-large, cluster LSTM kernels (H = 256)."""
+    """BASELINE configs[4] per-GPU shard at its real size (batch 512 over 8 GPUs = B 64 per GPU): DCCRN-large, cluster LSTM kernels (H = 256)."""
     from sefd_amd.optim import Adam
     m = make_model((64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", dtype="bf16")
     m.train()
-    x, y = _bench_batch(32)
+    x, y = _bench_batch(64)
     opt = Adam(m.parameters(), lr=1e-3)
     losses = [float(m.train_step(x, y, opt)) for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
@@ -680,14 +693,17 @@ def test_bf16_dccrn_perceptual_at_bench_size(perceptual):
 
 
 # ------------------------------------------------------------------------------------------------ the two-stream schedule is only a schedule
-@pytest.mark.parametrize("which", ["dccrn", "fullsubnet"])
+@pytest.mark.parametrize("which", ["dccrn", "fullsubnet", "fullsubnet_hoisted"])
 def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     """Every kernel is deterministic, so the gradients of one fused step must be BIT-identical whether the phase runs in its two-lane schedule
     (weight gradients, folds, early UNPACK, chunked LSTM forward on the second stream; FullSubNet: held weight gradients) or in program order on
     one stream (SEFD_NO_OVERLAP=1).  A missing dependency between the lanes shows up here as a mismatch.  Sizes large enough that kernels of the
     two streams really overlap (DCCRN B = 8 x 3 s, FullSubNet B = 16 x 3 s); lr = 0 keeps the parameters of the two runs equal.
     (Round 3: this test is what exposed the run-to-run differences of FullSubNet's row-block forward recurrence - lstm_rows.hip, note above
-    mfma_settle - which had nothing to do with the lanes: two runs of the SAME schedule differed.)"""
+    mfma_settle - which had nothing to do with the lanes: two runs of the SAME schedule differed.)
+    "fullsubnet_hoisted" (SEFD_LSTM_XFUSE=0): the row-block forward kernel WITHOUT the fused input projection (XF = 0: pre-activations of the
+    hoisted GEMM ride in the accumulators' initial value) and the row-block backward kernels behind it - run-to-run bit-reproducibility of the
+    variant the default configuration does not launch."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models
     from sefd_amd.optim import Adam
@@ -697,12 +713,15 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
         x, y = _bench_batch(8)
     else:
         cfg.loss, cfg.act_dtype = "MSE", "bf16"
+        if which == "fullsubnet_hoisted":
+            monkeypatch.setenv("SEFD_LSTM_XFUSE", "0")     # read when the plan is built (first step below)
         try:
             torch.manual_seed(0)
             m = models.FullSubNet().to("cuda").train()
         finally:
             cfg.act_dtype = "fp32"
-        x, y = _bench_batch(16)
+        x, y = _bench_batch(16 if which == "fullsubnet" else 8)
+        which = "fullsubnet"
     opt = Adam(m.parameters(), lr=0.0)
     grads, losses = [], []
     for rep, single in enumerate((False, True, False)):
@@ -721,3 +740,38 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     assert losses[0] == losses[1] == losses[2], losses
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
     assert torch.equal(grads[0], grads[2])
+
+
+def test_plan_status_word_guards_adam_and_checkpoint(tmp_path):
+    """A kernel that gives up (the cluster LSTM's bounded hand-over waits) sets its PLAN's host-mapped status word.  From then on: the
+    guarded Adam leaves parameters and moments untouched (no garbage step), save_checkpoint refuses to write, the plan's next run raises -
+    and another plan of the same model (other batch size) is not affected; clearing the word re-arms the plan."""
+    import ctypes as C
+    from sefd_amd import train_interface
+    from sefd_amd.optim import Adam
+    m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")
+    m.train()
+    x, y = make_signals(2, 4000)
+    x, y = x.cuda(), y.cuda()
+    opt = Adam(m.parameters(), lr=1e-3)
+    m.train_step(x, y, opt)
+    plan = m._status_plan
+    assert plan.status() == 0
+    C.c_int32.from_address(plan.status_word()).value = 1            # what report_timeout() does from the device
+    before, mom = m._flat_param.clone(), opt._m.clone()
+    m._flat_grad.fill_(1.0)
+    opt.step_flat()
+    torch.cuda.synchronize()
+    assert torch.equal(m._flat_param, before) and torch.equal(opt._m, mom)
+    with pytest.raises(RuntimeError, match="checkpoint not written"):
+        train_interface.save_checkpoint(str(tmp_path / "c.pt"), m, opt, 1)
+    assert not (tmp_path / "c.pt").exists()
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        m.train_step(x, y, opt)
+    x3, y3 = make_signals(3, 4000)
+    m.train_step(x3.cuda(), y3.cuda(), opt)                           # another plan of the same model: its own word
+    assert m._status_plan is not plan and m._status_plan.status() == 0
+    assert plan.status(clear=True) == 1 and plan.status() == 0
+    m.train_step(x, y, opt)
+    torch.cuda.synchronize()
+    assert not torch.equal(m._flat_param, before)

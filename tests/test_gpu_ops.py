@@ -218,6 +218,31 @@ def test_fused_losses_forward_backward(kind, name):
     assert rel_err(g.cpu(), 0.5 * est.grad) < 1e-3          # tolerance: 1e-3 relative fp32 (north_star)
 
 
+@pytest.mark.parametrize("name", ["MSE", "SDR", "SI-SNR", "SI-SDR"])
+@pytest.mark.parametrize("L", [2, 5])
+def test_short_row_losses_both_slots(name, L):
+    """FullSubNet.loss (models.py:674-682): reductions over a 2-element last axis, network output in EITHER slot (trainer.py:107 puts it
+    in `target`); the tools_for_loss mirrors must give the oracle's value and the gradient with respect to both arguments."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import tools_for_loss as tfl
+    torch.manual_seed(3)
+    a = (torch.randn(3, 41, 7, L) * 0.7)
+    b = (a + 0.3 * torch.randn(3, 41, 7, L))
+    fn = {"MSE": lambda e, t: tfl.mse(e, t), "SDR": lambda e, t: -tfl.sdr(t, e), "SI-SNR": lambda e, t: -tfl.si_snr(e, t), "SI-SDR": lambda e, t: -tfl.si_sdr(t, e)}[name]
+    for slot in (0, 1):
+        e, t = a.clone(), b.clone()
+        (e if slot == 0 else t).requires_grad_(True)
+        ref = ol.main_loss(name, e, t)
+        ref.backward()
+        ed, td = e.detach().cuda(), t.detach().cuda()
+        (ed if slot == 0 else td).requires_grad_(True)
+        out = fn(ed, td)
+        (out * 0.5).backward()
+        assert abs(float(out) - float(ref)) < 1e-4 * max(1.0, abs(float(ref))), (name, slot, float(out), float(ref))
+        gd, gr = (ed if slot == 0 else td).grad.cpu(), (e if slot == 0 else t).grad
+        assert rel_err(gd, 0.5 * gr) < 1e-3, (name, slot)
+
+
 def test_adam_step_matches_torch_formula():
     import ctypes as C
     from sefd_amd import _lib

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle.fullsubnet import FSNConfig, fsn_forward, fsn_state_shapes, fsn_targets
+from oracle.losses import main_loss
 from oracle.step import adam_update
 from oracle.weights import formula_state_dict, test_signals as make_signals
 from util import load_golden, rel_err, sub
@@ -15,9 +16,14 @@ from util import load_golden, rel_err, sub
                                                ("small_gru_mse", (128, 64), "GRU", "offline_laplace_norm"),
                                                ("small_cumlaplace_mse", (128, 64), "LSTM", "cumulative_laplace_norm"),
                                                ("small_gaussian_mse", (128, 64), "LSTM", "offline_gaussian_norm"),
-                                               ("small_cumlayer_gru_mse", (128, 64), "GRU", "cumulative_layer_norm")])
+                                               ("small_cumlayer_gru_mse", (128, 64), "GRU", "cumulative_layer_norm"),
+                                               # FullSubNet.loss (models.py:674-682) with cfg.loss = SDR (config.py:36 default) / SI-SNR / SI-SDR
+                                               ("small_sdr", (128, 64), "LSTM", "offline_laplace_norm"),
+                                               ("small_sisnr", (128, 64), "LSTM", "offline_laplace_norm"),
+                                               ("small_sisdr", (128, 64), "LSTM", "offline_laplace_norm")])
 def test_fsn_step_against_reference(name, hid, seq, norm):
     g = load_golden("fsn_" + name)
+    kind = str(g["g/meta/loss"]) if "g/meta/loss" in g else "MSE"
     cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1], sequence_model=seq, norm_type=norm)
     P = formula_state_dict(fsn_state_shapes(cfg))
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
@@ -27,11 +33,11 @@ def test_fsn_step_against_reference(name, hid, seq, norm):
     assert rel_err(cirm[:, ::4, ::3], g["g/cirm"]) < 1e-5
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     crm = fsn_forward(Pg, noisy_mag, cfg)
-    lossv = torch.mean((cirm - crm) ** 2)
+    lossv = main_loss(kind, cirm, crm)          # model.loss(cIRM, cRM): the network output sits in the `target` slot (trainer.py:107)
     names = list(Pg)
     grads = dict(zip(names, torch.autograd.grad(lossv, [Pg[k] for k in names])))
     assert rel_err(crm, g["g/crm"]) < 2e-5
-    assert abs(float(lossv) - float(g["g/loss"])) < 2e-5 * max(1.0, float(g["g/loss"]))
+    assert abs(float(lossv) - float(g["g/loss"])) < 2e-5 * max(1.0, abs(float(g["g/loss"])))
     for k, v in sub(g, "g/grad_norm").items():
         assert abs(float(grads[k].double().norm()) - float(v)) <= 3e-4 * float(v) + 1e-9, k
     for k, v in sub(g, "g/grad").items():

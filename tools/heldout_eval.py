@@ -57,11 +57,11 @@ def noise(rng, n=L):
     return c + hum
 
 
-def make_set(seed, count):
+def make_set(seed, count, n=L):
     rng = np.random.default_rng(seed)
     clean, noisy = [], []
     for _ in range(count):
-        s, v = speechlike(rng), noise(rng)
+        s, v = speechlike(rng, n), noise(rng, n)
         snr = 15 * rng.random()
         v = v * np.sqrt((s ** 2).mean() / ((v ** 2).mean() * 10 ** (snr / 10)))
         clean.append(s)
@@ -75,7 +75,7 @@ def train(args):
     from sefd_amd import config as cfg, models
     from sefd_amd.optim import Adam
     os.makedirs(args.out, exist_ok=True)
-    pool_c, pool_n = make_set(1, args.pool)
+    pool_c, pool_n = make_set(1, args.pool, args.train_len)
     held_c, held_n = make_set(2, args.heldout)
     B = args.batch
     res = {}
@@ -84,18 +84,25 @@ def train(args):
     # last leg: bf16 with the perceptual step (SI-SNR + PMSQE) / 2 - PMSQE is built to track PESQ, so a PESQ gain on the held-out set
     # is a consistency check of the (unpinned) loss and its hand-derived gradient
     for tag in args.legs.split(","):
+        # "fp32:5" = leg fp32 with batch-order seed 5, saved as enhanced_fp32_o5.npy (the protocol of tools/heldout_reference.py)
+        tag, _, oseed = tag.partition(":")
         dt = tag.split("_")[0]
         perc = "PMSQE" if "pmsqe" in tag else None
         cfg.pmsqe_power = tag.endswith("pmsqe_power")
         cfg.masking_mode, cfg.loss, cfg.act_dtype = "E", "SI-SNR", dt
         torch.manual_seed(0)
         m = models.DCCRN(rnn_units=cfg.rnn_units, masking_mode="E").to("cuda").train()
-        if init is None:
+        if args.init == "formula":               # oracle/weights.py values: what the reference leg (tools/heldout_reference.py) starts from
+            from oracle.weights import fill_state_dict_
+            fill_state_dict_(m)
+        elif init is None:
             init = {k: v.clone() for k, v in m.state_dict().items()}
         else:
             m.load_state_dict(init)
         opt = Adam(m.parameters(), lr=args.lr)
-        order = np.random.default_rng(4 if tag.endswith("rerun") else 3)
+        order = np.random.default_rng(int(oseed) if oseed else (4 if tag.endswith("rerun") else 3))
+        if oseed:
+            tag = f"{tag}_o{oseed}"
         losses = []
         for step in range(args.steps):
             idx = order.integers(0, args.pool, B)
@@ -173,6 +180,8 @@ if __name__ == "__main__":
     t.add_argument("--pool", type=int, default=96)
     t.add_argument("--heldout", type=int, default=16)
     t.add_argument("--legs", default="fp32,bf16,fp32_rerun,bf16_rerun,bf16_pmsqe")
+    t.add_argument("--init", default="torch", choices=("torch", "formula"))
+    t.add_argument("--train-len", type=int, default=L)
     t.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "heldout"))
     s = sub.add_parser("score")
     s.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out", "heldout"))
