@@ -72,6 +72,7 @@ def lib():
         "sefd_adam_step_guarded": (i32, [vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
         "sefd_plan_status_word": (vp, [vp]),
         "sefd_plan_status": (i32, [vp, i32]),
+        "sefd_plan_status_set": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -88,4 +89,4 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
             "sefd_plan_grad_bucket", "sefd_plan_run_cb", "sefd_plan_run_timed",
             "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_loss_rows_ws_floats", "sefd_loss_rows_forward", "sefd_loss_rows_backward", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
-            "sefd_adam_step", "sefd_adam_step_guarded", "sefd_plan_status_word", "sefd_plan_status"]
+            "sefd_adam_step", "sefd_adam_step_guarded", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set"]

@@ -18,13 +18,17 @@ struct sefd_plan {
   // host-mapped status word of THIS plan (created on first use: plans are also built on hosts without a GPU).  0 = fine; sticky once set
   // by a kernel that gave up (cluster LSTM hand-over timeout) until sefd_plan_status(clear = 1)
   mutable int* status = nullptr;
+  mutable int* dstatus = nullptr;             // the same word in device memory (what the guarded Adam reads)
 };
 static int* plan_status_word(const sefd_plan* h) {
   if (!h->status) {
     int* q = nullptr;
+    int* dq = nullptr;
     if (hipHostMalloc(reinterpret_cast<void**>(&q), sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dq), 256) != hipSuccess || hipMemset(dq, 0, 256) != hipSuccess) { (void)hipHostFree(q); return nullptr; }
     *q = 0;
     h->status = q;
+    h->dstatus = dq;
   }
   return h->status;
 }
@@ -47,6 +51,7 @@ void sefd_plan_destroy(sefd_plan* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->status) (void)hipHostFree(h->status);
+  if (h->dstatus) (void)hipFree(h->dstatus);
   delete h->p;
   delete h;
 }
@@ -116,10 +121,20 @@ int32_t sefd_plan_op_info(const sefd_plan* h, int phase, int i, int64_t* o) {
   return 0;
 }
 
-const int32_t* sefd_plan_status_word(const sefd_plan* h) { return h ? reinterpret_cast<const int32_t*>(plan_status_word(h)) : nullptr; }
+const int32_t* sefd_plan_status_word(const sefd_plan* h) { return (h && plan_status_word(h)) ? reinterpret_cast<const int32_t*>(h->dstatus) : nullptr; }
 int32_t sefd_plan_status(const sefd_plan* h, int32_t clear) {
   if (!h || !h->status) return 0;
-  return clear ? __atomic_exchange_n(h->status, 0, __ATOMIC_RELAXED) : __atomic_load_n(h->status, __ATOMIC_RELAXED);
+  if (!clear) return __atomic_load_n(h->status, __ATOMIC_RELAXED);
+  (void)hipDeviceSynchronize();                // no kernel of the plan is still about to set it
+  (void)hipMemset(h->dstatus, 0, sizeof(int));
+  return __atomic_exchange_n(h->status, 0, __ATOMIC_RELAXED);
+}
+int32_t sefd_plan_status_set(const sefd_plan* h) {   // what a kernel that gives up does, from the host (tests)
+  if (!h || !plan_status_word(h)) return -1;
+  const int one = 1;
+  if (hipMemcpy(h->dstatus, &one, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -2;
+  __atomic_store_n(h->status, 1, __ATOMIC_RELAXED);
+  return 0;
 }
 int32_t sefd_plan_grad_bucket(const sefd_plan* h, int32_t* op, int64_t* elem) {
   if (!h || h->p->bucket_op < 0) return -1;
@@ -168,6 +183,7 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   ArenaBases ab;
   for (int a = 0; a < A_COUNT; ++a) ab.p[a] = reinterpret_cast<char*>(arenas[a]);
   ab.status = status;
+  ab.dstatus = h->dstatus;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   auto launch = [&](const Op& op, hipStream_t s) {
     const size_t idx = (size_t)(&op - ops.data());
@@ -445,9 +461,9 @@ static int rows_blocks(int64_t R) { const int64_t n = (R + 255) / 256; return (i
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
                                                   float b1, float b2, float eps, float gscale, const int32_t* skip) {
-  // skip: the status word of the plan that produced g (host-mapped, system scope).  Set = a kernel of this step gave up and g is garbage:
-  // parameters and moments stay as they are (the host raises at its next look at the word)
-  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  // skip: the device copy of the status word of the plan that produced g.  Set = a kernel of this step gave up and g is garbage:
+  // parameters and moments stay as they are (the host raises at its next look at the host-mapped copy)
+  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;

@@ -11,9 +11,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 struct bf16_t { uint16_t v; };          // storage-only 16-bit type (sizeof == 2) used as the template tag of bf16 paths
 
-// status: host-mapped word of the PLAN that issues the launch (api.hip; 0 = fine), device-writable: a kernel that had to give up (the
-// cluster LSTM's bounded hand-over waits) sets it, sefd_adam_step_guarded skips the update while it is set, the host raises.
-struct ArenaBases { char* p[A_COUNT]; int* status; };
+// status / dstatus: the status word of the PLAN that issues the launch (api.hip; 0 = fine) as a host-mapped word (the host polls it without
+// a copy) and as a device word (the guarded Adam reads it - a million lanes loading a host-mapped word over PCIe cost 1.7 ms per step).  A
+// kernel that had to give up (the cluster LSTM's bounded hand-over waits) sets BOTH (report through set_status).
+struct ArenaBases { char* p[A_COUNT]; int* status; int* dstatus; };
+__device__ __forceinline__ void set_status(int* host_word, int* dev_word) {
+  if (host_word) __hip_atomic_store(host_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (dev_word) __hip_atomic_store(dev_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __host__ __device__ __forceinline__ char* rp(const ArenaBases& ab, const Ptr& q) { return ab.p[q.arena] + q.off; }
 
@@ -134,7 +139,6 @@ __device__ __forceinline__ void bnb_accum(const BnbCol& c, float slope, float dz
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
-bool launch_winconv(const RunGemm& d, const ArenaBases& ab, hipStream_t st);         // thin layers, LDS-resident input window (winconv.hip)
 bool launch_rundirect(const RunGemm& d, const ArenaBases& ab, hipStream_t st);       // thin layers, N <= 64 (thin.hip)
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);

@@ -879,7 +879,22 @@ __device__ __forceinline__ bool fin_stage1(const float* part, int nblk, int C, i
   const int per = (nblk + nch - 1) / nch, b0 = k * per, b1 = min(nblk, b0 + per);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int b = b0 + rl; b < b1; b += 8)
+    // four partial rows per trip, all their loads in flight before the first add: as one row per trip the loop was a chain of HBM round
+    // trips (242 rows per workgroup at the first encoder layer: 26 us for 4 MB)
+    int b = b0 + rl;
+    if (nsub == 1) {
+      for (; b + 24 < b1; b += 32) {
+        float v0[4], v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* row = part + (int64_t)(b + 8 * u) * rowstride;
+          v0[u] = row[c]; v1[u] = row[ld + c]; v2[u] = BWD ? row[2 * ld + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += v0[u]; s1 += v1[u]; if (BWD) s2 += v2[u]; }
+      }
+    }
+    for (; b < b1; b += 8)
       for (int u = 0; u < nsub; ++u) {
         const float* row = part + (int64_t)b * rowstride + u * substride;
         s0 += row[c];

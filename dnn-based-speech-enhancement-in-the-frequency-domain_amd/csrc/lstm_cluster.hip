@@ -70,8 +70,8 @@ __device__ __forceinline__ void gather(__amdgpu_buffer_rsrc_t r, uint32_t off0, 
 // A wave that spent its whole budget consumed fragments its peers had not written: the launch's results are garbage.  It says so in a
 // host-mapped status word of its plan (system-scope store): the guarded Adam kernel of the same step leaves the parameters untouched and the
 // host raises at the plan's next run / before a checkpoint is written - the step fails loudly instead of training on NaNs.
-__device__ __forceinline__ void report_timeout(int* status, int budget) {
-  if (budget <= 0 && (threadIdx.x & 63) == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void report_timeout(int* status, int* dstatus, int budget) {
+  if (budget <= 0 && (threadIdx.x & 63) == 0) set_status(status, dstatus);
 }
 
 }  // namespace
@@ -85,7 +85,7 @@ __device__ __forceinline__ void report_timeout(int* status, int budget) {
 constexpr int kMaxMT = 8;
 
 template <int H, bool PF>
-__global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT, int* status) {
+__global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT, int* status, int* dstatus) {
   constexpr int KS = H / 32;
   constexpr int HAS = H + 8, HCPR = H / 8, HNCH = (16 * HCPR + 255) / 256;      // cooperative gather tile: row stride, chunks per row / thread
   __shared__ __attribute__((aligned(16))) uint16_t htile[PF ? 8 : 2 * 16 * HAS];
@@ -279,14 +279,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_cluster_kernel(const LstmRec d, 
   }
   if (n < ntile) { tile(b0v, b2v); ++n; }
   if (n < ntile) { tile(b1v, b0v); ++n; }
-  report_timeout(status, budget);
+  report_timeout(status, dstatus, budget);
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
 // Tile (t, mt), frames last to first: dh_rec = dgates_{t+1}[tile] . W_hh (gathered first: the peers stored it MT tiles ago),
 // then the cell backward of frame t, whose dgates_t leave write-through for the peers' (and this wave's) tile (t-1, mt).
 template <int H>
-__global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT, int* status) {
+__global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, const ArenaBases ab, const int MT, int* status, int* dstatus) {
   constexpr int KS = 4 * H / 32;                 // k32 steps over the 4H gate columns
   constexpr int AS = 4 * H + 8, CPR = 4 * H / 8, NCH = 16 * CPR / 256;   // LDS tile row stride, 16-byte chunks per row, chunks per thread
   constexpr bool DB = H <= 448;                  // two tiles (ping-pong, one barrier per tile) while 2 x 16 x 4H bf16 fits next to the rest
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_cluster_kernel(const LstmRec d, 
   }
   if (n < ntile) { tile(s0, s2); ++n; }
   if (n < ntile) { tile(s1, s0); ++n; }
-  report_timeout(status, budget);
+  report_timeout(status, dstatus, budget);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ launch
@@ -498,10 +498,10 @@ static void launch_c(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
   const int mt = pick_mt(d, H / 64);
   const dim3 grid(H / 64, (d.B + 16 * mt - 1) / (16 * mt), d.G);
   if (fwd) {
-    if constexpr (H <= 384) { if (mt > 1) { hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, true>), grid, dim3(256), 0, st, d, ab, mt, status); return; } }
-    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, false>), grid, dim3(256), 0, st, d, ab, mt, status);
+    if constexpr (H <= 384) { if (mt > 1) { hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, true>), grid, dim3(256), 0, st, d, ab, mt, status, ab.dstatus); return; } }
+    hipLaunchKernelGGL((lstm_fwd_cluster_kernel<H, false>), grid, dim3(256), 0, st, d, ab, mt, status, ab.dstatus);
   } else {
-    hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab, mt, status);
+    hipLaunchKernelGGL((lstm_bwd_cluster_kernel<H>), grid, dim3(256), 0, st, d, ab, mt, status, ab.dstatus);
   }
 }
 

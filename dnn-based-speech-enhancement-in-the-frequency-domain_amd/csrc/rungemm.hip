@@ -1118,7 +1118,6 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (launch_cgemm256(d, ab, st)) return;                  // wide-tile kernel for the N >= 128 bf16 layers (cgemm256.hip)
-  if (launch_winconv(d, ab, st)) return;                   // LDS-resident input window for the thin bf16 layers with K of a few hundred (winconv.hip)
   if (launch_rundirect(d, ab, st)) return;                 // direct-operand kernel for the thin bf16 layers (thin.hip)
   if (d.xdt == DT_BF16) launch_rungemm_t<bf16_t>(d, ab, st);
   else launch_rungemm_t<float>(d, ab, st);

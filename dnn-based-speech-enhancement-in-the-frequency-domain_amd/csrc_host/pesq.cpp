@@ -88,13 +88,17 @@ static void apply_filter(std::vector<double>& data, long nsamples, const double*
   fft(a, true);
   for (long i = 0; i < n; ++i) data[(size_t)kSearch * kDown + i] = a[(size_t)i].real();
 }
-static void fix_power_level(Signal& s, long max_nsamples) {
+// false: no power in the 350 - 3250 Hz band (an all-zero or DC-only clip: a model that outputs zeros early in training, a silent reference) -
+// the level cannot be fixed (0 * inf = NaN through every later stage); the caller returns the floor of the scale instead
+static bool fix_power_level(Signal& s, long max_nsamples) {
   std::vector<double> f = s.data;
   apply_filter(f, s.nsamples, kAlignFilterDb, 26);
   const double p = pow_of(f, kSearch * kDown, s.nsamples - kSearch * kDown + kPadMs * (kFs / 1000),
                           max_nsamples - 2L * kSearch * kDown + kPadMs * (kFs / 1000));
+  if (!(p > 0.0) || !std::isfinite(p)) return false;
   const double g = std::sqrt(kTargetAvgPower / p);
   for (long i = 0; i < s.nsamples; ++i) s.data[(size_t)i] *= g;
+  return true;
 }
 static void wb_input_filter(Signal& s) {            // P.862.2: one biquad (direct form II) over the active part
   const double b0 = kWbHpSos[0], b1 = kWbHpSos[1], b2 = kWbHpSos[2], a1 = kWbHpSos[3], a2 = kWbHpSos[4];
@@ -166,12 +170,12 @@ static double lpq_weight(long start, long stop, double ps, double pt, const std:
 }
 
 // raw P.862 score of (reference, degraded), both n samples at 16 kHz, zero delay
+constexpr double kRawFloor = -0.5;          // lowest raw score of P.862 (MOS-LQO 1.04 through the P.862.2 mapping): silent / DC-only input
 static double pesq_raw(const double* refx, const double* degx, long n, double in_scale) {
   Signal ref = make_signal(refx, n, in_scale), deg = make_signal(degx, n, in_scale);
   const long maxn = std::max(ref.nsamples, deg.nsamples);
   const long pad = kPadMs * (kFs / 1000);
-  fix_power_level(ref, maxn);
-  fix_power_level(deg, maxn);
+  if (!fix_power_level(ref, maxn) || !fix_power_level(deg, maxn)) return kRawFloor;
   wb_input_filter(ref);
   wb_input_filter(deg);
 

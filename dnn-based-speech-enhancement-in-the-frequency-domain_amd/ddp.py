@@ -113,14 +113,18 @@ class GradientExchange:
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
 
-    def mean_scalars(self, values):
-        """Mean over ranks of a few host / device scalars (validation losses: every rank scores its own shard)."""
+    def mean_scalars(self, values, weight=1.0):
+        """Weighted mean over ranks of a few host / device scalars: sum_r weight_r * value_r / sum_r weight_r (validation: every rank scores
+        its own shard; weight = its number of batches, so ragged shards average like the single-process loop over all batches)."""
         if not self.active:
             return [float(v) for v in values]
         dev = next((v.device for v in values if torch.is_tensor(v)), torch.device("cpu"))
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        if dev.type != "cuda" and dist.get_backend(self.pg) == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        t = torch.tensor([float(v) * float(weight) for v in values] + [float(weight)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-        return [float(v) / self.world for v in t]
+        tot = float(t[-1])
+        return [float(v) / tot if tot > 0 else float("nan") for v in t[:-1]]
 
 
 def shard_batch(n_items: int, rank: int, world: int):

@@ -177,11 +177,16 @@ class Plan:
             o._status_plan = self
 
     def status_word(self):
-        """Device-readable address of the word (sefd_adam_step_guarded's skip_if_set)."""
+        """Address of the device copy of the word (sefd_adam_step_guarded's skip_if_set)."""
         return self.lib.sefd_plan_status_word(self.h)
 
     def status(self, clear=False):
         return int(self.lib.sefd_plan_status(self.h, 1 if clear else 0))
+
+    def status_set(self):
+        """Test hook: set the word from the host, as a kernel that gives up does from the device."""
+        if self.lib.sefd_plan_status_set(self.h) != 0:
+            raise RuntimeError("sefd_plan_status_set failed")
 
     _RC5 = (": a cluster-LSTM launch of this plan gave up waiting for a peer workgroup (GPU shared or preempted?) - that step's results "
             "are invalid; the guarded Adam left the parameters untouched (Plan.status(clear=True) re-arms the plan)")

@@ -126,11 +126,13 @@ def run(train_loader, validation_loader, model=None, optimizer=None, writer=None
         res = trainer(model, optimizer, train_loader, DEVICE, **kw)
         if master:                                                    # replicas are identical: same start (broadcast above), same averaged gradients
             save_checkpoint(str(dir_to_save + '/' + ('chkpt_%d.pt' % epoch)), model, optimizer, epoch)
-        # every rank validates its shard; the losses (what picks chkpt_opt) are averaged over the ranks, PESQ / STOI are rank 0's shard
-        val = estimator(model, validation_loader, writer if master else None, dir_to_save, epoch, DEVICE, scorers=scorers if master else None)
+        # every rank validates AND scores its shard; losses (what picks chkpt_opt), PESQ and STOI are averaged over the ranks weighted by
+        # their batch counts - the numbers in log.txt are those of the whole validation set whatever the world size
+        from . import trainer as _tr
+        _tr.SCORE_FILE_SUFFIX = "" if master else ".rank%d" % rank
+        val = estimator(model, validation_loader, writer if master else None, dir_to_save, epoch, DEVICE, scorers=scorers)
         if exchange is not None and exchange.world > 1:
-            nl = len(val) - 2
-            val = tuple(exchange.mean_scalars(val[:nl])) + tuple(val[nl:])
+            val = tuple(exchange.mean_scalars(val, weight=_tr.LAST_VALIDATE_BATCHES))
         if perceptual:
             train_loss, train_main_loss, train_perceptual_loss = res
             vali_loss, validation_main_loss, validation_perceptual_loss, vali_pesq, vali_stoi = val

@@ -147,6 +147,10 @@ def crn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
 
 
 # ------------------------------------------------------------------------------------------------ validation
+SCORE_FILE_SUFFIX = ""            # ".rank<r>" on the ranks > 0 of a data-parallel run
+LAST_VALIDATE_BATCHES = 0         # batches the last _validate call of this process went through
+
+
 def _default_scorers():
     """(cal_pesq, cal_stoi) of sefd_amd.tools_for_estimate (reference tools_for_estimate.py:68-99 calls a closed x86 PESQ.so and
     pystoi): the C++ scorers of libsefd_scorers.so (wide-band P.862 PESQ, STOI).  None only when the library has not been built."""
@@ -168,7 +172,9 @@ def _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batc
     sums = [torch.zeros((), device=DEVICE) for _ in range(n_losses)]
     avg_pesq = avg_stoi = 0.0
     batch_num = 0
-    f_score = open(f"{dir_to_save}/Epoch_{epoch:d}_SCORES", "a") if scorers is not None else None
+    # data parallel: every rank scores its own shard into its own file (rank 0 keeps the reference's file name, SCORE_FILE_SUFFIX is set by
+    # train_interface.run); the epoch driver then averages the scores over the ranks, weighted by their batch counts (LAST_VALIDATE_BATCHES)
+    f_score = open(f"{dir_to_save}/Epoch_{epoch:d}_SCORES{SCORE_FILE_SUFFIX}", "a") if scorers is not None else None
     was_training = model.training
     model.eval()
     last = None
@@ -196,6 +202,8 @@ def _validate(model, validation_loader, writer, dir_to_save, epoch, DEVICE, batc
             f_score.close()
         model.train(was_training)
     n = max(batch_num, 1)
+    global LAST_VALIDATE_BATCHES
+    LAST_VALIDATE_BATCHES = batch_num
     means = tuple(acc / n for acc in sums)
     if scorers is None:
         return means + (float("nan"), float("nan"))

@@ -165,10 +165,13 @@ int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* e
  * shared / preempted GPU) sets the word, so a garbage gradient never reaches the parameters; NULL = unconditional. */
 int32_t sefd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                                float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_if_set, void* stream);
-/* Per-plan status word (host-mapped, device-readable; 0 = fine).  sefd_plan_run returns -5 while it is set (sticky);
- * sefd_plan_status reads it (after a stream synchronisation for a definite answer) and optionally clears it. */
+/* Per-plan status word (0 = fine), kept twice: host-mapped (what sefd_plan_run / sefd_plan_status read) and in device memory (what
+ * sefd_plan_status_word returns, for sefd_adam_step_guarded).  sefd_plan_run returns -5 while it is set (sticky); sefd_plan_status reads
+ * it (after a stream synchronisation for a definite answer) and optionally clears both copies; sefd_plan_status_set sets both from the
+ * host (test hook: what a kernel that gives up does). */
 const int32_t* sefd_plan_status_word(const sefd_plan* p);
 int32_t sefd_plan_status(const sefd_plan* p, int32_t clear);
+int32_t sefd_plan_status_set(const sefd_plan* p);
 
 #ifdef __cplusplus
 }

@@ -271,6 +271,7 @@ def _driver_worker(rank, world, port, q):
         torch.nn.functional.mse_loss(ref(x), y).backward()
         err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
         means = ex.mean_scalars([torch.tensor(float(rank + 1)), 10.0 * (rank + 1)])
+        means += ex.mean_scalars([float(rank + 1)], weight=3 - 2 * rank)          # ragged shards: rank 0 ran 3 batches, rank 1 ran 1
         cfg.loss = 'SI-SDR'
         try:
             trainer._exchange_grads(net, ex)
@@ -303,4 +304,4 @@ def test_world2_epoch_driver_helpers_gloo():
     res = [q.get(timeout=5) for _ in range(world)]
     for rank, same, err, means, refused in res:
         assert same and err < 1e-6 and refused, res
-        assert means == [1.5, 15.0], means
+        assert means == [1.5, 15.0, 1.25], means          # (3 * 1 + 1 * 2) / 4: the mean over all four batches

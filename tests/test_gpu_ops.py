@@ -67,14 +67,10 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         os.environ.pop("SEFD_CG256_MINM", None)
         os.environ.pop("SEFD_WG256_MINM", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
-    os.environ.pop("SEFD_WINCONV_MINM", None)
-    os.environ.pop("SEFD_WINCONV", None)
     os.environ.pop("SEFD_BN_FUSE", None)
     if L in (4001, 2403):                  # the direct-operand kernel takes GEMMs with M >= 65536 by default
         L -= 1 if L == 4001 else 3
         os.environ["SEFD_DIRECT_MINM"] = "0"
-        os.environ["SEFD_WINCONV_MINM"] = "0"  # ... the (opt-in) LDS-window kernel takes the thin GEMMs with K of a few hundred (winconv.hip)
-        os.environ["SEFD_WINCONV"] = "1"
         os.environ["SEFD_BN_FUSE"] = "2"   # ... and every BatchNorm layer's backward sums come from its producers' epilogues (thin + tiled kernels)
     if L == 2401 or (model == "DCCRN" and dtype == "fp32" and L == 2400):
         os.environ["SEFD_BN_FUSE"] = "2"   # the same through the wide-tile kernel / in fp32
@@ -188,8 +184,6 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     os.environ.pop("SEFD_LSTM_MT", None)
     os.environ.pop("SEFD_LSTM_RPW", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
-    os.environ.pop("SEFD_WINCONV_MINM", None)
-    os.environ.pop("SEFD_WINCONV", None)
     with open(_report_path(f"ops_report_{model}_B{B}_{mode.replace('/', '-')}_{dtype}_{L}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])

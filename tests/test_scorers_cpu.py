@@ -137,6 +137,19 @@ def test_pesq_cpp_matches_reference_binary_goldens():
         te.cal_pesq(c[:, :100], c[:, :100])
 
 
+def test_pesq_of_a_silent_clip_is_the_floor_not_nan():
+    """A model that outputs zeros early in training (or a DC-only / silent clip): the level normalisation has no band power to work with;
+    the score is the floor of the scale (raw -0.5 -> MOS-LQO 1.04), finite, and the epoch's average stays a number."""
+    pairs = pesq_pairs()
+    clean = pairs[0][1]
+    for bad in (np.zeros_like(clean), np.full_like(clean, 0.25)):
+        for deg, ref in ((bad, clean), (clean, bad), (bad, bad)):
+            got = te.cal_pesq(deg[None], ref[None], nthreads=1)[0]
+            floor = 0.999 + 4.0 / (1.0 + np.exp(1.3669 * 0.5 + 3.8224))
+            assert np.isfinite(got) and got >= floor - 1e-9, got             # (a DC step leaves edge transients in the band: finite, scored normally)
+    assert abs(te.cal_pesq(np.zeros_like(clean)[None], clean[None], nthreads=1)[0] - floor) < 1e-9
+
+
 def test_pesq_cpp_on_heldout_model_outputs():
     """Three utterances of the held-out evaluation (clean / noisy / fp32-trained DCCRN output, int16) with the reference binary's scores: the
     noisy inputs agree to 0.002; on enhanced speech the one-delay-per-file alignment of the port differs from the binary's per-utterance
