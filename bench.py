@@ -293,7 +293,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "bn": "per-rank statistics",
-                          "collective": (f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (single-GPU smoke test, not a measurement)'} world {dist.get_world_size()}, flat fp32 gradient all-reduce in 2 buckets (decoder+LSTM under the encoder backward)"
+                          "collective": (f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (single-GPU smoke test, not a measurement)'} world {dist.get_world_size()}, flat fp32 gradient all-reduce in 2 buckets ({'full-band model under the sub-band weight gradients' if args.model == 'fullsubnet' else 'decoder+LSTM under the encoder backward'})"
                                          if dist_on else "none"),
                           "per_rank_ms": per_rank_ms},
                "final_loss": round(lossv, 5)}

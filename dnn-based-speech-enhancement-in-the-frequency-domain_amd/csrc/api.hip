@@ -141,6 +141,12 @@ int32_t sefd_plan_grad_bucket(const sefd_plan* h, int32_t* op, int64_t* elem) {
   *op = h->p->bucket_op; *elem = h->p->bucket_elem;
   return 0;
 }
+int32_t sefd_plan_grad_bucket_range(const sefd_plan* h, int32_t* op, int64_t* lo, int64_t* hi) {
+  if (!h || h->p->bucket_op < 0) return -1;
+  *op = h->p->bucket_op; *lo = h->p->bucket_elem;
+  *hi = h->p->bucket_end >= 0 ? h->p->bucket_end : h->p->arena_bytes[A_GRAD] / 4;
+  return 0;
+}
 
 static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
                         std::vector<hipEvent_t>* tev = nullptr);
@@ -249,7 +255,8 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
       forked = true;
       continue;
     }
-    if (op.join || op.kind == OP_UNPACK) join();         // UNPACK gathers every gradient partial: needs the side lane's results
+    if (op.join == 1 || (op.kind == OP_UNPACK && op.join != kOpNoJoin)) join();   // UNPACK gathers gradient partials: needs the side lane's results
+                                                         // (kOpNoJoin: a bucket whose partials all come from the main stream - FullSubNet's full-band model)
     launch(op, st);
     if (i == at && cb) cb(ctx);                          // e.g. the first gradient bucket is complete: the caller starts its all-reduce
   }

@@ -301,7 +301,7 @@ struct Builder {
   }
   // side = true: the launch rides the weight-gradient lane behind the WGRADs it folds (a pure HBM stream next to the other lane's GEMMs);
   // false: main stream, which first waits for the weight-gradient lane (the fold in front of an UNPACK)
-  void flush_sums(std::vector<Op>& ops, int tag, bool side = false) {
+  void flush_sums(std::vector<Op>& ops, int tag, bool side = false, bool join = true) {
     if (pending_sums.empty()) return;
     std::vector<int64_t> tab;
     int64_t nmax = 0;
@@ -310,7 +310,7 @@ struct Builder {
     cur_lane = side ? 1 : 0;
     Op& os = push(ops, OP_SPLITSUM, tag);
     cur_lane = save;
-    os.join = side ? 0 : 1;                                // the partial sums come from the weight-gradient lane
+    os.join = (side || !join) ? 0 : 1;                     // the partial sums come from the weight-gradient lane (join = false: from the main stream)
     os.unpack.start = cst(tab.data(), (int64_t)tab.size() * 8);     // int64 [nseg][3]: offset from the partial-sum base, elements, splits
     os.unpack.ent = os.unpack.dst = none();
     os.unpack.n = nmax;
@@ -321,12 +321,12 @@ struct Builder {
     pending_sums.clear();
   }
 
-  int64_t unpack_lo = 0;                                   // flat gradient elements below this are still to be unpacked
+  int64_t unpack_lo = 0;                                   // flat gradient elements below this are already unpacked (FullSubNet's first bucket)
   int64_t unpack_hi = -1;                                  // (set by unpack_range: elements [unpack_hi, end) are already done)
   // UNPACK of the flat gradient elements [lo, hi): every weight gradient GEMM that contributes to them must have been planned.
   // The partial-sum base is not known yet (finish_unpack allocates it): recorded as a fix-up.
-  void unpack_range(std::vector<Op>& ops, int64_t lo, int64_t hi, int tag) {
-    flush_sums(ops, tag);
+  void unpack_range(std::vector<Op>& ops, int64_t lo, int64_t hi, int tag, bool nojoin = false) {
+    flush_sums(ops, tag, false, !nojoin);
     const int64_t n = hi - lo;
     std::vector<int32_t> start(n + 1, 0), ent;
     for (int64_t j = 0; j < n; ++j) {
@@ -344,11 +344,12 @@ struct Builder {
     op.unpack.n = n;
     op.unpack.sstride = 0;
     op.unpack.nsplit = 1;
+    if (nojoin) op.join = kOpNoJoin;
     fixes.push_back(Fix{(int)ops.size() - 1, 0, 1});
   }
   void finish_unpack(std::vector<Op>& ops) {
     const int64_t n = unpack_hi >= 0 ? unpack_hi : (int64_t)inv.size();
-    unpack_range(ops, 0, n, 999);
+    unpack_range(ops, unpack_lo, n, 999);
     Ptr base = ws("gradpart", std::max<int64_t>(gp_off, 1), DT_F32);
     for (auto& f : fixes) {
       Ptr p = mk(A_WS, base.off + f.rel * 4);
@@ -2634,7 +2635,12 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   if (cfg.training) {
     // lane of the weight-gradient GEMMs: 1 = second stream (api.hip: issued behind the first recurrence kernel of the phase, joined in front of
     // the UNPACK); only when the recurrences are single launches (the per-frame GRU / fp32 formulation has no OP_LSTM_BWD to fork at)
-    const int wg_lane = (!gru && adt == DT_BF16 && !(getenv("SEFD_FSN_LANES") && atoi(getenv("SEFD_FSN_LANES")) == 0)) ? 1 : 0;
+    int wg_lane = (!gru && adt == DT_BF16 && !(getenv("SEFD_FSN_LANES") && atoi(getenv("SEFD_FSN_LANES")) == 0)) ? 1 : 0;
+    // data parallel (cfg.grad_buckets >= 2): the sub-band model's weight gradients keep the second lane busy for ~12 ms after the main stream
+    // is through (profiles/r03_tuning_notes.md section 8) - the full-band model's gradients (the FRONT of the flat arena, 2/3 of it) are
+    // therefore produced ON the main stream, folded and unpacked there without waiting for the lane, and their all-reduce (started by the
+    // caller at that op: sefd_plan_grad_bucket_range) runs under the sub-band weight gradients; the sub-band range follows at the end
+    const bool fsn_buckets = cfg.grad_buckets >= 2 && wg_lane == 1;
     // wg_hold: the weight gradients of the layer wait for the NEXT recurrence launch instead of starting beside the input-gradient GEMM in
     // between (two MFMA-bound GEMMs side by side ran 10 % slower than one after the other; beside the HBM-bound recurrence they fill its idle CUs)
     int wg_hold = 0;
@@ -2792,15 +2798,27 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         b.push(R, OP_FSN_NORMBWD, 201).fsn = f; }
       { Fsn f = fsn0(); f.in = dpre; f.aux = fbo; f.aux2 = mu_sb; f.sums = Sm; f.out = d_fb; f.mode = nmode; b.push(R, OP_FSN_SBBWD_APPLY, 200).fsn = f; }
     }
+    if (fsn_buckets) {
+      b.flush_sums(R, 997, true);                          // the sub-band folds: on the lane, behind the weight gradients they fold
+      wg_lane = 0;                                         // full-band weight gradients: main stream
+    }
     Ptr dh1 = b.ws("dh1", (int64_t)TP * B * Hf, DT_F32);
     fc_backward(fcf, d_fb, h1, B, Hf, F, FP, dh1, 102, "fb_model");
     Ptr dh0d = b.ws("dh0d", (int64_t)TP * B * Hf, DT_F32);
     lstm_backward(Lf1, dh1, true, dh0d, Hf, 0, Hf, DT_F32, 101);
     Ptr dh0 = dropout_bwd(Lf0, dh0d, 100);
     lstm_backward(Lf0, dh0, false, b.none(), 0, 0, 0, DT_F32, 100);
+    if (fsn_buckets) {
+      const int64_t sb_lo = b.par("sb_model.sequence_model.weight_ih_l0").off;
+      b.unpack_range(R, 0, sb_lo, 998, true);             // folds + UNPACK of the full-band range: no wait for the lane
+      b.unpack_lo = sb_lo;
+      P->bucket_elem = 0; P->bucket_end = sb_lo;
+    }
     b.finish_unpack(R);
   }
   finalize_rungemms(b, P);
+  for (size_t k = 0; k < P->bwd.size(); ++k)
+    if (P->bwd[k].kind == OP_UNPACK && P->bwd[k].tag == 998) P->bucket_op = (int32_t)k;
   P->arena_bytes[A_WS] = b.ws_off;
   P->arena_bytes[A_PARAM] = nparam * 4;
   P->arena_bytes[A_GRAD] = nparam * 4;

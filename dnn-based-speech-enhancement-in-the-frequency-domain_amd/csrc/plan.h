@@ -51,6 +51,7 @@ struct Plan {
   std::vector<SyncPoint> syncs;                // SyncBN all-reduce points, in execution order per phase
   int32_t bucket_op = -1;                      // grad_buckets == 2: backward op index of the first bucket's UNPACK
   int64_t bucket_elem = 0;                     //                    first flat gradient element of that bucket
+  int64_t bucket_end = -1;                     //                    one past its last element (-1: the end of the arena)
   std::string error;
 };
 

@@ -374,6 +374,7 @@ enum OpKind : int32_t {
 };
 
 constexpr int kOpHold = 2;     // Op::join of a lane-1 op
+constexpr int kOpNoJoin = 4;   // Op::join of a main-stream UNPACK whose inputs were all produced on the main stream: it does not wait for the second lane
 
 struct Op {
   int32_t kind;

@@ -589,11 +589,12 @@ class FullSubNet(_SefdModule):
         if not self._flat_ok(device):
             self._flatten(device)
         keep = self.dropout_keep if self.training else 1.0
-        key = ("fsn", B, T, bool(self.training), keep, self.act_dtype)
+        nb = getattr(self, "_grad_buckets", 1)
+        key = ("fsn", B, T, bool(self.training), keep, self.act_dtype, nb)
         rt = self._runtimes.get(key)
         if rt is None:
             plan = Plan(B, T, fft_len=2 * (self.num_freqs - 1), act_dtype=self.act_dtype, training=True, model="FullSubNet",
-                        fsn=dict(self._fsn, keep=keep))
+                        fsn=dict(self._fsn, keep=keep), grad_buckets=nb)
             plan.owner = weakref.ref(self)
             assert [n for n, _ in self._trainable()] == list(plan.params.keys()), "parameter order differs from the plan"
             ar = [None] * ARENA_COUNT
@@ -637,6 +638,8 @@ class FullSubNet(_SefdModule):
         noisy_complex, clean_complex = tools.stft(inputs), tools.stft(targets)
         noisy_mag, _, cirm = tools._targets(noisy_complex, clean_complex, True, False, True)
         B, F, T = noisy_mag.shape
+        # data parallel: two gradient buckets - the full-band model's range is final while the sub-band weight gradients still run (ddp.py)
+        self._grad_buckets = 2 if (exchange is not None and exchange.active) else 1
         plan, ar = self._fsn_runtime(B, T, noisy_mag.device)
         optimizer.bind(self)
         stream = torch.cuda.current_stream().cuda_stream
@@ -654,9 +657,20 @@ class FullSubNet(_SefdModule):
             crm = plan.io(ar, "crm", (B * F * T, 2))
             ws, loss = tfl.loss_rows_forward_raw(kind, cirm.view(-1, 2), crm, stream)
             tfl.loss_rows_backward_raw(kind, cirm.view(-1, 2), crm, ws, None, None, plan.io(ar, "grad_crm", (B * F * T, 2)), stream)
-        plan.run(PHASE_BWD, ar, stream)
+        bucket = plan.grad_bucket_range() if self._grad_buckets == 2 else None
+        if bucket is not None:
+            op, lo, hi = bucket
+            plan.run_cb(PHASE_BWD, ar, stream, op, lambda: exchange.begin(self._flat_grad[lo:hi]))
+        else:
+            plan.run(PHASE_BWD, ar, stream)
         if exchange is not None and exchange.active:
-            exchange.all_reduce(self._flat_grad)
+            if bucket is not None:
+                for a, z in ((0, bucket[1]), (bucket[2], self._flat_grad.numel())):
+                    if z > a:
+                        exchange.begin(self._flat_grad[a:z])
+                exchange.finish(self._flat_grad)
+            else:
+                exchange.all_reduce(self._flat_grad)
             optimizer.grad_scale = exchange.grad_scale
         optimizer.step_flat()
         return loss

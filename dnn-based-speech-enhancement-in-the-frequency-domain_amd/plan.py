@@ -191,6 +191,13 @@ class Plan:
     _RC5 = (": a cluster-LSTM launch of this plan gave up waiting for a peer workgroup (GPU shared or preempted?) - that step's results "
             "are invalid; the guarded Adam left the parameters untouched (Plan.status(clear=True) re-arms the plan)")
 
+    def grad_bucket_range(self):
+        """(backward op index, lo, hi): flat gradient elements [lo, hi) are final once that op has run (None: single-bucket plan)."""
+        op, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+        if self.lib.sefd_plan_grad_bucket_range(self.h, C.byref(op), C.byref(lo), C.byref(hi)) != 0:
+            return None
+        return op.value, lo.value, hi.value
+
     def run_cb(self, phase, arenas, stream, at, fn):
         """Whole phase (two-lane schedule); `fn()` runs on the host right after op `at` has been enqueued."""
         self._mark()

@@ -92,6 +92,10 @@ int32_t sefd_plan_run(const sefd_plan* p, int phase, int first, int last, void* 
 /* grad_buckets == 2: index (backward phase) of the UNPACK op that completes the first gradient bucket and the first flat element
    of that bucket; returns -1 when the plan has a single bucket. */
 int32_t sefd_plan_grad_bucket(const sefd_plan* p, int32_t* op, int64_t* elem);
+/* The same as an explicit element range [lo, hi) of the flat gradient arena: DCCRN / CRN complete the TAIL of the arena first (decoder + LSTM,
+ * hi = end), FullSubNet the FRONT (the full-band model: its weight gradients run on the main stream while the sub-band model's still
+ * occupy the second lane, lo = 0). */
+int32_t sefd_plan_grad_bucket_range(const sefd_plan* p, int32_t* op, int64_t* lo, int64_t* hi);
 /* Whole phase as sefd_plan_run(first = 0, last = -1), and `cb(ctx)` is called on the host right after op `at` has been enqueued on
    `stream` (everything up to and including that op is ordered before whatever the callback enqueues behind an event on `stream`). */
 int32_t sefd_plan_run_cb(const sefd_plan* p, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx);

@@ -94,3 +94,20 @@ def test_adam_state_dict_format_and_pending_load():
     with pytest.raises(NotImplementedError):
         models.DCCRN(rnn_units=128, win_type=None)             # rectangular window is not on the HIP path
     cfg.dccrn_kernel_num = [32, 64, 128, 256, 256, 256]
+
+
+def test_torch_library_namespace_registers_and_traces():
+    """`sefd::` custom ops (sefd_amd/ops.py): registered with the dispatcher, fake implementations give the output shapes without a GPU, and a
+    CPU tensor is refused loudly (no CPU fallback)."""
+    import pytest
+    import torch
+    import sefd_amd  # noqa: F401
+    from sefd_amd import ops  # noqa: F401
+    for name in ("loss", "loss_forward", "loss_backward", "adam_step_", "mix_snr", "plan_run"):
+        assert hasattr(torch.ops.sefd, name), name
+    e, t = torch.empty(4, 100, device="meta"), torch.empty(4, 100, device="meta")
+    assert torch.ops.sefd.loss(2, e, t).shape == ()
+    out, ws = torch.ops.sefd.loss_forward(1, e, t)
+    assert out.shape == () and ws.numel() > 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.sefd.loss(2, torch.zeros(2, 100), torch.zeros(2, 100))

@@ -243,6 +243,74 @@ def test_world2_bucketed_exchange_equals_flat_gloo():
     assert res[0][2] == res[1][2] and res[0][2] > 0               # both ranks hold the same summed gradient
 
 
+# ------------------------------------------------------------------------------------------------ FullSubNet: bucketed exchange
+def _fsn_bucket_worker(rank, world, port, q):
+    """FullSubNet plan with grad_buckets = 2 (bf16: the sub-band weight gradients ride the second lane): the FRONT of the flat gradient - the
+    full-band model - is final at the plan's bucket op, before the final fold + UNPACK of the sub-band range; its all-reduce starts there.
+    Must equal the single-bucket plan followed by one flat all-reduce, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from simutil import PHASE_BWD, PHASE_FWD, Plan, fill_params, sim_run
+    from sefd_amd.ddp import GradientExchange
+    from sefd_amd.plan import ARENA_GRAD
+    from oracle.fullsubnet import FSNConfig, fsn_state_shapes
+    from oracle.weights import formula_state_dict
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = GradientExchange()
+        hid = (64, 32)
+        P = formula_state_dict(fsn_state_shapes(FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])))
+        B, T = 1, 7
+        torch.manual_seed(11 + rank)
+        mag, gc = torch.rand(B, 257, T), torch.randn(B, 257, T, 2) * 1e-2
+        res = {}
+        for nb in (1, 2):
+            plan = Plan(B, T, model="FullSubNet", act_dtype="bf16", fsn=dict(fb_hidden=hid[0], sb_hidden=hid[1], keep=1.0), grad_buckets=nb)
+            ar = plan.alloc_arenas("cpu")
+            fill_params(plan, ar, P)
+            plan.io(ar, "mag", (B, 257, T)).copy_(mag)
+            sim_run(plan, PHASE_FWD, ar)
+            plan.io(ar, "grad_crm", (B, 257, T, 2)).copy_(gc)
+            flat = ar[ARENA_GRAD]
+            if nb == 1:
+                assert plan.grad_bucket_range() is None
+                sim_run(plan, PHASE_BWD, ar)
+                ex.all_reduce(flat)
+            else:
+                op, lo, hi = plan.grad_bucket_range()
+                sb0 = plan.params["sb_model.sequence_model.weight_ih_l0"][0]
+                assert lo == 0 and hi == sb0 and 0 < hi < flat.numel() and 0 < op < plan.num_ops(PHASE_BWD) - 1
+                flat.fill_(float("nan"))
+                sim_run(plan, PHASE_BWD, ar, 0, op + 1)
+                assert bool(torch.isfinite(flat[lo:hi]).all()) and bool(torch.isnan(flat[hi:hi + 8]).all())
+                ex.begin(flat[lo:hi])
+                sim_run(plan, PHASE_BWD, ar, op + 1, plan.num_ops(PHASE_BWD))
+                ex.begin(flat[hi:])
+                ex.finish(flat)
+            res[nb] = flat.clone()
+        q.put((rank, bool(torch.equal(res[1], res[2])), float(res[2].abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_fullsubnet_bucketed_exchange_equals_flat_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fsn_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(world)]
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][2] > 0
+
+
 # ------------------------------------------------------------------------------------------------ epoch-driver helpers (train_interface.run)
 def _driver_worker(rank, world, port, q):
     """broadcast_model (replicas start identical), all_reduce_autograd (the loss.backward() route of the direct-mapping / perceptual

@@ -26,23 +26,25 @@ def test_two_rank_bucketed_exchange_runs_on_one_gpu():
     assert "2 buckets" in d["config"]["collective"]
 
 
-def test_one_rank_exchange_runs_on_rccl():
+@pytest.mark.parametrize("model,batch", [("dccrn", 8), ("fullsubnet", 4)])
+def test_one_rank_exchange_runs_on_rccl(model, batch):
     """The driver's SCALE run is the first time this code meets RCCL with several ranks; this is the part of it one GPU can execute: bench.py
     under torchrun with ONE rank and backend "nccl" (= RCCL), SEFD_DDP_FORCE=1 - init_process_group(..., device_id=), the two-bucket plan,
     GradientExchange.begin from the sefd_plan_run_cb callback on the communication stream, finish, barrier and the MAX all-reduce of the times."""
     env = dict(os.environ, SEFD_DDP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("SEFD_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8",
-           "--no-cpu-baseline", "--no-roofline"]
+           "--master-port", "29543" if model == "dccrn" else "29545", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--batch", str(batch), "--model", model, "--no-cpu-baseline", "--no-roofline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 8
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == batch
     assert d["config"]["collective"].startswith("RCCL world 1") and "2 buckets" in d["config"]["collective"]
     assert d["final_loss"] == d["final_loss"] and abs(d["final_loss"]) < 100
     # same seed, same batch, no exchange: a one-rank sum all-reduce is the identity, so the loss after the same five steps is the same
-    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline", "--no-roofline"],
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", str(batch), "--model", model,
+                         "--no-cpu-baseline", "--no-roofline"],
                         cwd=ROOT, env={k: v for k, v in env.items() if k != "SEFD_DDP_FORCE"}, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
     d2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])

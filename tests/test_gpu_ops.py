@@ -10,7 +10,7 @@ import torch
 from oracle import losses as ol
 from oracle.dccrn import DCCRNConfig, dccrn_state_shapes
 from oracle.step import adam_update
-from oracle.weights import formula_state_dict, test_signals as make_signals
+from oracle.weights import fill_state_dict_, formula_state_dict, test_signals as make_signals
 from util import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -235,6 +235,56 @@ def test_short_row_losses_both_slots(name, L):
         assert abs(float(out) - float(ref)) < 1e-4 * max(1.0, abs(float(ref))), (name, slot, float(out), float(ref))
         gd, gr = (ed if slot == 0 else td).grad.cpu(), (e if slot == 0 else t).grad
         assert rel_err(gd, 0.5 * gr) < 1e-3, (name, slot)
+
+
+def test_torch_library_ops():
+    """`sefd::` custom ops (sefd_amd/ops.py, torch.library): the dispatcher-level surface of the same C entry points the mirrors call - same
+    values, registered backward, fake implementations that trace."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import ops, models, config as cfg, tools_for_loss as tfl  # noqa: F401
+    from sefd_amd.plan import PHASE_FWD
+    x, y = make_signals(3, 4802)
+    for kind, name in ((0, "MSE"), (1, "SDR"), (2, "SI-SNR"), (3, "SI-SDR")):
+        e = (0.9 * x).cuda().requires_grad_(True)
+        out = torch.ops.sefd.loss(kind, e, y.cuda())
+        out.backward()
+        er = (0.9 * x).clone().requires_grad_(True)
+        ref = ol.main_loss(name, er, y)
+        ref.backward()
+        assert abs(float(out) - float(ref)) < 1e-4 * max(1.0, abs(float(ref))) and rel_err(e.grad.cpu(), er.grad) < 1e-3, name
+    a, b = torch.randn(50, 2), torch.randn(50, 2)                        # short rows: gradient to the `tgt` slot as well
+    bd = b.cuda().requires_grad_(True)
+    torch.ops.sefd.loss(2, a.cuda(), bd).backward()
+    br = b.clone().requires_grad_(True)
+    ol.main_loss("SI-SNR", a, br).backward()
+    assert rel_err(bd.grad.cpu(), br.grad) < 1e-3
+    p, g = torch.randn(1000), torch.randn(1000) * 1e-2
+    pd, gd, md, vd = p.cuda(), g.cuda(), torch.zeros(1000).cuda(), torch.zeros(1000).cuda()
+    torch.ops.sefd.adam_step_(pd, gd, md, vd, 1, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+    pr, _, _ = adam_update(p, g, torch.zeros(1000), torch.zeros(1000), 1)
+    assert rel_err(pd.cpu(), pr) < 1e-6
+    # a planned model through sefd::plan_run == the module's forward
+    m = make_dccrn_small()
+    xs = x[:2, :4000].cuda().contiguous()
+    with torch.no_grad():
+        want = m(xs)[2]
+        rt = next(v for k, v in m._runtimes.items() if isinstance(k[0], int))
+        rt.wav.copy_(xs * 0.5)
+        torch.ops.sefd.plan_run(rt.plan.h.value if hasattr(rt.plan.h, "value") else int(rt.plan.h), PHASE_FWD, rt.arenas)
+        half = rt.out_wav.clone()
+        rt.wav.copy_(xs)
+        torch.ops.sefd.plan_run(rt.plan.h.value if hasattr(rt.plan.h, "value") else int(rt.plan.h), PHASE_FWD, rt.arenas)
+        assert torch.equal(rt.out_wav, want) and not torch.equal(half, want)
+    assert torch.ops.sefd.loss(2, torch.empty(4, 100, device="meta"), torch.empty(4, 100, device="meta")).shape == ()      # fake impl traces
+
+
+def make_dccrn_small():
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.act_dtype, cfg.perceptual, cfg.lstm, cfg.skip_type = [16, 32, 32, 64, 64, 64], "E", "SI-SNR", "fp32", False, "complex", True
+    m = models.DCCRN(rnn_units=128, masking_mode="E")
+    fill_state_dict_(m)
+    return m.to("cuda").eval()
 
 
 def test_adam_step_matches_torch_formula():

@@ -78,7 +78,7 @@ def train(args):
     pool_c, pool_n = make_set(1, args.pool, args.train_len)
     held_c, held_n = make_set(2, args.heldout)
     B = args.batch
-    res = {}
+    res, scores = {}, {}
     init = None
     # third leg: fp32 again with another batch order - the run-to-run spread of the metric, against which the bf16 delta is read
     # last leg: bf16 with the perceptual step (SI-SNR + PMSQE) / 2 - PMSQE is built to track PESQ, so a PESQ gain on the held-out set
@@ -117,12 +117,21 @@ def train(args):
                 o = m(torch.from_numpy(held_n[i:i + B]).cuda())
                 outs.append((o[2] if isinstance(o, (tuple, list)) else o).float().cpu().numpy())
         enh = np.concatenate(outs)
-        np.save(os.path.join(args.out, f"enhanced_{tag}.npy"), np.round(np.clip(enh, -1, 1) * 32767).astype(np.int16))
+        enh16 = np.round(np.clip(enh, -1, 1) * 32767).astype(np.int16)
+        if not args.no_wav or tag.split("_o")[-1] in args.keep_wav.split(","):
+            np.save(os.path.join(args.out, f"enhanced_{tag}.npy"), enh16)
+        if args.score:                           # the shipped C++ scorers on the box (the merged gpurun_out is capped at 64 MiB: 12 legs of int16 clips are not)
+            from sefd_amd import tools_for_estimate as est
+            c16 = np.round(held_c * 32767).astype(np.int16).astype(np.float64) / 32768.0
+            e = enh16.astype(np.float64) / 32768.0
+            scores[tag] = dict(pesq_cpp=[float(v) for v in est.cal_pesq(e, c16)], stoi=[float(v) for v in est.cal_stoi(e, c16)])
+            print(tag, "pesq_cpp", float(np.mean(scores[tag]["pesq_cpp"])), "stoi", float(np.mean(scores[tag]["stoi"])), flush=True)
         res[tag] = losses
         print(tag, "loss", losses[0], "->", losses[-1], flush=True)
     np.save(os.path.join(args.out, "clean.npy"), np.round(held_c * 32767).astype(np.int16))
     np.save(os.path.join(args.out, "noisy.npy"), np.round(held_n * 32767).astype(np.int16))
-    json.dump(dict(steps=args.steps, batch=B, lr=args.lr, pool=args.pool, heldout=args.heldout, losses=res), open(os.path.join(args.out, "train_log.json"), "w"))
+    json.dump(dict(steps=args.steps, batch=B, lr=args.lr, pool=args.pool, heldout=args.heldout, init=args.init, train_len=args.train_len, losses=res, scores=scores),
+              open(os.path.join(args.out, "train_log.json"), "w"))
 
 
 def score(args):
@@ -181,6 +190,9 @@ if __name__ == "__main__":
     t.add_argument("--heldout", type=int, default=16)
     t.add_argument("--legs", default="fp32,bf16,fp32_rerun,bf16_rerun,bf16_pmsqe")
     t.add_argument("--init", default="torch", choices=("torch", "formula"))
+    t.add_argument("--score", action="store_true", help="score every leg on the box with the C++ PESQ / STOI (train_log.json 'scores')")
+    t.add_argument("--no-wav", action="store_true", help="do not keep the enhanced clips (except --keep-wav orders)")
+    t.add_argument("--keep-wav", default="", help="comma-separated batch-order seeds whose enhanced clips are kept with --no-wav")
     t.add_argument("--train-len", type=int, default=L)
     t.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "heldout"))
     s = sub.add_parser("score")
