@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsefd_hip.so")
+# SEFD_LIB_PATH: another build of the same library (tuning A/B on one box: tools/ab_build.sh); the product loads the in-tree file
+LIB_PATH = os.environ.get("SEFD_LIB_PATH") or os.path.join(HERE, "libsefd_hip.so")
 
 
 class ModelConfig(C.Structure):
@@ -55,6 +56,7 @@ def lib():
         "sefd_plan_grad_bucket_range": (i32, [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
         "sefd_plan_run_cb": (i32, [vp, i32, C.POINTER(vp), vp, i32, vp, vp]),
         "sefd_plan_run_timed": (i32, [vp, i32, C.POINTER(vp), vp, C.POINTER(C.c_float), i32]),
+        "sefd_plan_run_flags": (i32, [vp, i32, C.POINTER(vp), vp, i32, i32, vp, vp]),
         "sefd_loss_ws_floats": (i64, [i32]),
         "sefd_loss_forward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp]),
         "sefd_loss_backward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp]),
@@ -88,6 +90,6 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_num_params", "sefd_plan_param_name", "sefd_plan_param_offset", "sefd_plan_param_numel",
             "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
-            "sefd_plan_grad_bucket", "sefd_plan_grad_bucket_range", "sefd_plan_run_cb", "sefd_plan_run_timed",
+            "sefd_plan_grad_bucket", "sefd_plan_grad_bucket_range", "sefd_plan_run_cb", "sefd_plan_run_flags", "sefd_plan_run_timed",
             "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_loss_rows_ws_floats", "sefd_loss_rows_forward", "sefd_loss_rows_backward", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
             "sefd_adam_step", "sefd_adam_step_guarded", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set"]

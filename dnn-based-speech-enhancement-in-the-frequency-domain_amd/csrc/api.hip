@@ -149,13 +149,16 @@ int32_t sefd_plan_grad_bucket_range(const sefd_plan* h, int32_t* op, int64_t* lo
 }
 
 static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
-                        std::vector<hipEvent_t>* tev = nullptr);
+                        std::vector<hipEvent_t>* tev = nullptr, int flags = 0);
 
 int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream) {
   return plan_run(h, phase, first, last, arenas, stream, -1, nullptr, nullptr);
 }
 int32_t sefd_plan_run_cb(const sefd_plan* h, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx) {
   return plan_run(h, phase, 0, -1, arenas, stream, at, cb, ctx);
+}
+int32_t sefd_plan_run_flags(const sefd_plan* h, int phase, void* const* arenas, void* stream, int flags, int at, void (*cb)(void*), void* ctx) {
+  return plan_run(h, phase, 0, -1, arenas, stream, at, cb, ctx, nullptr, flags);
 }
 // Measurement: the whole phase in its REAL two-lane schedule, with a HIP event recorded before and after every op on the stream the op
 // is launched on; synchronises, then ms[i] = duration of op i in situ (next to whatever the other lane runs).  n = number of ops.
@@ -179,7 +182,7 @@ int32_t sefd_plan_run_timed(const sefd_plan* h, int phase, void* const* arenas, 
 }  // extern "C"
 
 static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
-                        std::vector<hipEvent_t>* tev) {
+                        std::vector<hipEvent_t>* tev, int flags) {
   if (!h || !h->p->error.empty()) return -1;
   int* status = plan_status_word(h);
   if (status && __atomic_load_n(status, __ATOMIC_RELAXED) != 0) return -5;   // an earlier launch of THIS plan gave up waiting (cluster LSTM): sticky until cleared
@@ -191,7 +194,11 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   ab.status = status;
   ab.dstatus = h->dstatus;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // SEFD_RUN_WAVE_ONLY: the caller's loss reads the waveform only (the fused train step without a perceptual term): the [B, NF, T] copies of
+  // the enhanced spectrum and the accumulation of their (all-zero) gradients are not launched
+  const bool wave_only = (flags & SEFD_RUN_WAVE_ONLY) != 0;
   auto launch = [&](const Op& op, hipStream_t s) {
+    if (wave_only && (op.kind == OP_SPECOUT_FWD || op.kind == OP_SPECOUT_BWD) && op.so.mode == 0 && (op.kind == OP_SPECOUT_FWD || op.so.accumulate)) return;
     const size_t idx = (size_t)(&op - ops.data());
     if (tev) (void)hipEventRecord((*tev)[2 * idx], s);
     if (op.kind == OP_RUNGEMM) launch_rungemm(op.g, ab, s);

@@ -42,15 +42,16 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // wait until at most `allow` of this thread's DMAs are still in flight (allow is wave-uniform; rounded down to an even count)
+// (a binary decision tree: the linear ladder cost up to seven scalar compares + branches per call, twice per k16 step of every wave -
+//  round 4 counters: 5.4 SALU + 5.4 VALU instructions per MFMA in this kernel, the read phase - not the MFMAs - sets the step time)
 __device__ __forceinline__ void wait_allow(int allow) {
-  if (allow >= 14) wait_vm<14>();
-  else if (allow >= 12) wait_vm<12>();
-  else if (allow >= 10) wait_vm<10>();
-  else if (allow >= 8) wait_vm<8>();
-  else if (allow >= 6) wait_vm<6>();
-  else if (allow >= 4) wait_vm<4>();
-  else if (allow >= 2) wait_vm<2>();
-  else wait_vm<0>();
+  if (allow >= 8) {
+    if (allow >= 12) { if (allow >= 14) wait_vm<14>(); else wait_vm<12>(); }
+    else { if (allow >= 10) wait_vm<10>(); else wait_vm<8>(); }
+  } else {
+    if (allow >= 4) { if (allow >= 6) wait_vm<6>(); else wait_vm<4>(); }
+    else { if (allow >= 2) wait_vm<2>(); else wait_vm<0>(); }
+  }
 }
 
 }  // namespace
@@ -59,6 +60,8 @@ __device__ __forceinline__ void wait_allow(int allow) {
 // 32 every A chunk from the zero page (no activation traffic)
 // BNB: the kRunBnBwd epilogue as its own instantiation - the kernel sits at the 256-register cap of two waves per SIMD, and with the
 // extra epilogue state in the one body the allocator spilled inside the K loop of EVERY launch (15x slower)
+// (dbg stays a run-time argument: with the switches folded to constants the allocator of this 256-register kernel spilled 236 instead of
+//  188 bytes and the step was 0.4 ms SLOWER - measured round 4, same box: 11.26 vs 10.87 ms)
 template <bool BNB>
 __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const ArenaBases ab, const int dbg) {
   constexpr int BM = 256, BN = 256, NW = 8;
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   const uint16_t* rptr[NA];
   int jlo[NA], jhi[NA];
   int aseg = 0, ak0 = 0, aseglen = 0, a_local = 0;           // A cursor: run, position inside the run, run length, K tiles issued
+  int a_slot = 0, c_slot = 0;                                // ring slots (gk + a_local) % NAS of the issue cursor / (gk + p) % NAS of the K loop, kept incrementally
   int bseg = 0, bk0 = 0, bseglen = 0, bkoff = 0;             // B cursor (advances per 64-deep K tile)
   int kt32[3];                                               // 32-deep weight tile index of local K tiles p, p+1, p+2
   int mark_h1 = 0, mark_h1_next = 0, mark_kt = 0;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   // half `hf` (0, 1) of the next A tile: 2 of this thread's 4 instructions; the cursor advances with the second half
   auto issue_a = [&](int hf) {
     if (!(dbg & 2)) {
-      const uint32_t A = lds0 + ((gk + a_local) % NAS) * A_SLOT;
+      const uint32_t A = lds0 + a_slot * A_SLOT;
       const int j0 = ak0 + csa * 8;
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     }
     if (hf == 1) {
       ++a_local;
+      a_slot = a_slot + 1 == NAS ? 0 : a_slot + 1;
       ak0 += KT;
       if (ak0 >= aseglen && a_local < nkt) { ak0 = 0; ++aseg; enter_run(aseg); }
     }
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     }
     wb0 = w + ((int64_t)d_ntile * BN + wid * 16 + lb) * 32 + csb * 8;   // instruction q adds q * NW * 16 rows
     aseg = 0; ak0 = 0; a_local = 0;
+    a_slot = gk % NAS;
     bseg = 0; bk0 = 0; bseglen = d.seg[0].len; bkoff = d.seg[0].koff;
     enter_run(0);
     issue_a(0); issue_a(1);
@@ -230,9 +236,11 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     wait_allow(nis - mark_h1);
     wg_barrier();                                            // A(0), B(0) of this tile have landed (everyone's part)
     if (grp == 1) wg_barrier();                              // group B runs one phase behind group A
+    c_slot = gk % NAS;
     for (int p = 0; p < nkt; ++p) {
       const bool has1 = p + 1 < nkt, has2 = p + 2 < nkt;
-      const char* abase = smem + ((gk + p) % NAS) * A_SLOT + aoff;
+      const char* abase = smem + c_slot * A_SLOT + aoff;
+      c_slot = c_slot + 1 == NAS ? 0 : c_slot + 1;
       const char* bbase = smem + ((gk + p) & 1) * 2 * B_SLOT + boff;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {

@@ -15,7 +15,7 @@ from . import config as cfg
 from . import _lib
 from .frontend_consts import stft_kernels
 from .plan import (ARENA_COUNT, ARENA_CONST, ARENA_GRAD, ARENA_IO, ARENA_PARAM, ARENA_STATE, ARENA_WS, PHASE_BWD,
-                   PHASE_FWD, Plan)
+                   PHASE_FWD, RUN_WAVE_ONLY, Plan)
 from . import tools_for_loss as tfl
 
 
@@ -279,13 +279,18 @@ class _SefdModule(nn.Module):
         rt.wav.copy_(inputs)
         if rt.tgt is not None:
             rt.tgt.copy_(targets)
+        # the loss of this step reads the waveform only: no [B, NF, T] spectrum copies, no pass over their (zero) gradients (SEFD_RUN_WAVE_ONLY)
+        wave_only = RUN_WAVE_ONLY if (not perceptual and not sync and rt.plan.model_name == "DCCRN" and not str(rt.plan.masking_mode).startswith("Direct")) else 0
         if sync:
             rt.plan.run_synced(PHASE_FWD, rt.arenas, stream, exchange.all_reduce_stats)
+        elif wave_only:
+            rt.plan.run_cb(PHASE_FWD, rt.arenas, stream, -1, None, flags=wave_only)
         else:
             rt.run(PHASE_FWD)
         ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
-        rt.g_real.zero_()
-        rt.g_imag.zero_()
+        if not wave_only:
+            rt.g_real.zero_()
+            rt.g_imag.zero_()
         if perceptual:
             half = torch.full((1,), 0.5, dtype=torch.float32, device=inputs.device)
             tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, half, rt.g_wav, stream)
@@ -311,7 +316,9 @@ class _SefdModule(nn.Module):
             rt.plan.run_synced(PHASE_BWD, rt.arenas, stream, exchange.all_reduce_stats)
         elif bucket is not None:
             op, lo = bucket                                  # decoder + LSTM gradients are final at op `op`: their all-reduce starts
-            rt.plan.run_cb(PHASE_BWD, rt.arenas, stream, op, lambda: exchange.begin(self._flat_grad[lo:]))   # under the encoder backward
+            rt.plan.run_cb(PHASE_BWD, rt.arenas, stream, op, lambda: exchange.begin(self._flat_grad[lo:]), flags=wave_only)   # under the encoder backward
+        elif wave_only:
+            rt.plan.run_cb(PHASE_BWD, rt.arenas, stream, -1, None, flags=wave_only)
         else:
             rt.run(PHASE_BWD)
         if exchange is not None and exchange.active:         # DDP: sum gradients over ranks (RCCL), average inside Adam

@@ -9,6 +9,7 @@ from . import _lib
 
 ARENA_WS, ARENA_PARAM, ARENA_GRAD, ARENA_STATE, ARENA_CONST, ARENA_IO, ARENA_COUNT = 0, 1, 2, 3, 4, 5, 6
 PHASE_FWD, PHASE_BWD = 0, 1
+RUN_WAVE_ONLY = 1
 MASK_MODES = {"E": 0, "C": 1, "R": 2, "Direct(None make)": 4}
 DTYPES = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 
@@ -50,6 +51,8 @@ class Plan:
         cfg.bn_world = int(bn_world)
         cfg.grad_buckets = int(grad_buckets)
         self.cfg = cfg
+        self.model_name = model
+        self.masking_mode = masking_mode
         self.h = self.lib.sefd_plan_create(C.byref(cfg))
         err = self.lib.sefd_plan_error(self.h).decode()
         if err:
@@ -198,12 +201,13 @@ class Plan:
             return None
         return op.value, lo.value, hi.value
 
-    def run_cb(self, phase, arenas, stream, at, fn):
-        """Whole phase (two-lane schedule); `fn()` runs on the host right after op `at` has been enqueued."""
+    def run_cb(self, phase, arenas, stream, at, fn, flags=0):
+        """Whole phase (two-lane schedule); `fn()` runs on the host right after op `at` has been enqueued (fn None: no callback).
+        flags: RUN_WAVE_ONLY (include/sefd.h SEFD_RUN_WAVE_ONLY)."""
         self._mark()
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
-        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _ctx: fn())
-        rc = self.lib.sefd_plan_run_cb(self.h, phase, ptrs, C.c_void_p(stream), at, cb, None)
+        cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _ctx: fn()) if fn is not None else None
+        rc = self.lib.sefd_plan_run_flags(self.h, phase, ptrs, C.c_void_p(stream), flags, at if fn is not None else -1, cb, None)
         if rc != 0:
             raise RuntimeError(f"sefd_plan_run_cb failed ({rc})" + (self._RC5 if rc == -5 else ""))
 

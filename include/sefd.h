@@ -99,6 +99,11 @@ int32_t sefd_plan_grad_bucket_range(const sefd_plan* p, int32_t* op, int64_t* lo
 /* Whole phase as sefd_plan_run(first = 0, last = -1), and `cb(ctx)` is called on the host right after op `at` has been enqueued on
    `stream` (everything up to and including that op is ordered before whatever the callback enqueues behind an event on `stream`). */
 int32_t sefd_plan_run_cb(const sefd_plan* p, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx);
+/* The same with run flags (cb may be NULL, at = -1).  SEFD_RUN_WAVE_ONLY: the caller's loss is a function of the enhanced WAVEFORM only
+ * (trainer.py:27-39 without a perceptual term): the reference-layout copies out_real / out_imag [B][NF][T] are not produced and the
+ * (all-zero) gradient with respect to them is not accumulated - DCCRN.forward's first two return values are not valid after such a run. */
+#define SEFD_RUN_WAVE_ONLY 1
+int32_t sefd_plan_run_flags(const sefd_plan* p, int phase, void* const* arenas, void* stream, int flags, int at, void (*cb)(void*), void* ctx);
 /* Measurement only (bench.py's in-situ roofline leg): the whole phase in its real two-stream schedule with a HIP event pair around every
    op on the stream it is launched on; synchronises; ms[i] = duration of op i while the other lane runs beside it.  n >= number of ops. */
 int32_t sefd_plan_run_timed(const sefd_plan* p, int phase, void* const* arenas, void* stream, float* ms, int32_t n);

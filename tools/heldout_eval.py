@@ -179,6 +179,79 @@ def score(args):
     print(json.dumps({k: out[k] for k in ("mean", "delta_bf16_minus_fp32", "delta_fp32_rerun_minus_fp32", "delta_bf16_mean_minus_fp32_mean", "delta_bf16_pmsqe_minus_bf16_mean", "delta_bf16_pmsqe_power_minus_bf16_mean", "per_utt_abs_delta_max")}, indent=1))
 
 
+def score_vs_ref(args):
+    """HIP legs (train --init formula --score, the C++ scorers on the GPU box) against the reference-trained models of
+    tools/heldout_reference.py (same formula init, same pool, same batch orders, CPU fp32): paired by batch order.
+    delta(order) = mean over the held-out clips of (HIP score - reference score); reported: mean over orders, standard error, 95 % interval
+    (Student t), and the verdict against the two-sided +-0.02 criterion of north_star."""
+    from scipy import stats
+    ref = None
+    for rp in args.ref.split(","):                     # several reference files (the runs were split over two processes): same protocol, runs merged
+        if not os.path.exists(rp):
+            continue
+        r = json.load(open(rp))
+        if ref is None:
+            ref = r
+        else:
+            assert r["protocol"] == ref["protocol"], "reference protocols differ"
+            ref["runs"].update(r["runs"])
+    hip = json.load(open(os.path.join(args.dir, "train_log.json")))
+    for extra in sorted(os.listdir(args.dir)):         # more HIP legs from a later GPU call: train_log_*.json
+        if extra.startswith("train_log_") and extra.endswith(".json"):
+            e = json.load(open(os.path.join(args.dir, extra)))
+            assert all(e[k] == hip[k] for k in ("steps", "batch", "pool", "heldout", "train_len", "init"))
+            hip["scores"].update(e["scores"]); hip["losses"].update(e["losses"])
+    prot = ref["protocol"]
+    assert (hip["steps"], hip["batch"], hip["pool"], hip["heldout"], hip.get("train_len"), hip.get("init")) == \
+           (prot["steps"], prot["batch"], prot["pool"], prot["heldout"], prot["train_len"], "formula"), "protocols differ"
+    out = dict(protocol=prot, scorer="C++ wide-band PESQ (csrc_host/pesq.cpp) and C++ STOI on both sides; the reference leg also carries PESQ.so scores",
+               orders={}, summary={})
+    pesq_so = None
+    if os.path.exists("/root/reference/PESQ.so") and os.path.exists(os.path.join(args.dir, "clean.npy")):
+        import ctypes
+        dll = ctypes.CDLL("/root/reference/PESQ.so")
+        dll.pesq.restype = ctypes.c_double
+
+        def pesq_so(r, d):
+            r, d = np.ascontiguousarray(r, np.double), np.ascontiguousarray(d, np.double)
+            return float(dll.pesq(ctypes.c_void_p(r.ctypes.data), ctypes.c_void_p(d.ctypes.data), len(r), len(d)))
+    for o, run in sorted(ref["runs"].items(), key=lambda kv: int(kv[0])):
+        row = dict(reference={k: float(np.mean([r[k] for r in run["rows"]])) for k in ("pesq", "pesq_cpp", "stoi")},
+                   reference_final_loss=run["losses"][-1][1])
+        for dt in ("fp32", "bf16"):
+            tag = f"{dt}_o{o}"
+            if tag not in hip["scores"]:
+                continue
+            sc = hip["scores"][tag]
+            row[dt] = dict(pesq_cpp=float(np.mean(sc["pesq_cpp"])), stoi=float(np.mean(sc["stoi"])), final_loss=hip["losses"][tag][-1][1],
+                           delta_pesq_cpp=float(np.mean(sc["pesq_cpp"]) - row["reference"]["pesq_cpp"]),
+                           delta_stoi=float(np.mean(sc["stoi"]) - row["reference"]["stoi"]),
+                           per_utt_abs_delta_pesq_mean=float(np.mean(np.abs(np.array(sc["pesq_cpp"]) - np.array([r["pesq_cpp"] for r in run["rows"]])))))
+            wav = os.path.join(args.dir, f"enhanced_{tag}.npy")
+            if pesq_so and os.path.exists(wav):   # the reference's own scorer on the HIP model's clips (kept for one order: 64 MiB transfer cap)
+                clean, e = np.load(os.path.join(args.dir, "clean.npy")).astype(np.float64), np.load(wav).astype(np.float64)
+                v = float(np.mean([pesq_so(clean[i], e[i]) for i in range(len(e))]))
+                row[dt]["pesq_so"] = v
+                row[dt]["delta_pesq_so"] = v - row["reference"]["pesq"]
+        out["orders"][o] = row
+    for dt in ("fp32", "bf16"):
+        for key in ("delta_pesq_cpp", "delta_stoi"):
+            d = np.array([r[dt][key] for r in out["orders"].values() if dt in r])
+            if len(d) < 2:
+                continue
+            se = float(d.std(ddof=1) / np.sqrt(len(d)))
+            half = float(stats.t.ppf(0.975, len(d) - 1) * se)
+            lim = 0.02
+            verdict = "pass" if abs(d.mean()) + half <= lim else ("fail" if abs(d.mean()) - half > lim else "mean inside, interval straddles the limit" if abs(d.mean()) <= lim else "mean outside, interval straddles the limit")
+            out["summary"][f"{dt}.{key}"] = dict(n_orders=int(len(d)), mean=float(d.mean()), std=float(d.std(ddof=1)), se=se, ci95=[float(d.mean() - half), float(d.mean() + half)],
+                                                 criterion="+-0.02 two-sided", verdict=verdict, per_order=[float(v) for v in d])
+    d = np.array([r["bf16"]["pesq_cpp"] - r["fp32"]["pesq_cpp"] for r in out["orders"].values() if "bf16" in r and "fp32" in r])
+    if len(d) >= 2:
+        out["summary"]["bf16_minus_fp32.pesq_cpp"] = dict(mean=float(d.mean()), se=float(d.std(ddof=1) / np.sqrt(len(d))), per_order=[float(v) for v in d])
+    json.dump(out, open(args.json, "w"), indent=1)
+    print(json.dumps(out["summary"], indent=1))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -198,5 +271,9 @@ if __name__ == "__main__":
     s = sub.add_parser("score")
     s.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out", "heldout"))
     s.add_argument("--json", default=os.path.join(ROOT, "profiles", "r02_heldout_eval.json"))
+    v = sub.add_parser("score_vs_ref")
+    v.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out", "heldout_r04"))
+    v.add_argument("--ref", default=os.path.join(ROOT, "profiles", "r04_heldout_reference.json") + "," + os.path.join(ROOT, "profiles", "r04_heldout_reference_b.json"))
+    v.add_argument("--json", default=os.path.join(ROOT, "profiles", "r04_heldout_eval.json"))
     a = ap.parse_args()
-    train(a) if a.cmd == "train" else score(a)
+    {"train": train, "score": score, "score_vs_ref": score_vs_ref}[a.cmd](a)
