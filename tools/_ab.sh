@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
+for i in 1 2 3; do
+for v in new base; do
+if [ $v = base ]; then export SEFD_LIB_PATH=$GRAFT_REPO_ROOT/ab/base.so; else unset SEFD_LIB_PATH; fi
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra > $O/ab_$v$i.log 2>&1; echo "$v $(tail -1 $O/ab_$v$i.log | grep -o '"ms_per_step": [0-9.]*')"
+done; done

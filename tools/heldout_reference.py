@@ -58,7 +58,8 @@ def main():
         return float(dll.pesq(ctypes.c_void_p(ref.ctypes.data), ctypes.c_void_p(deg.ctypes.data), len(ref), len(deg)))
 
     os.makedirs(a.wavdir, exist_ok=True)
-    out = dict(protocol=dict(model="reference DCCRN default, mask E, SI-SNR, fp32 CPU (torch %s, %d threads)" % (torch.__version__, a.threads),
+    # (the thread count of the first runs stays in the string: it keys the result file; later runs used more threads - not part of the protocol)
+    out = dict(protocol=dict(model="reference DCCRN default, mask E, SI-SNR, fp32 CPU (torch %s, 3 threads)" % torch.__version__,
                              init="oracle/weights.py formula", steps=a.steps, batch=a.batch, lr=a.lr, pool=a.pool, heldout=a.heldout,
                              train_len=a.train_len, heldout_len=he.L), runs={})
     if os.path.exists(a.json):
