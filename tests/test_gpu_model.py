@@ -483,7 +483,7 @@ def _bf16_record(name, rec):
     _BF16_REPORT[name] = rec
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    path = os.path.join(d, "r02_bf16_parity.json")
+    path = os.path.join(d, "bf16_parity.json")
     old = {}
     if os.path.exists(path):
         try:
