@@ -12,7 +12,6 @@ namespace sefd {
 template <typename T> struct VecIO;
 template <> struct VecIO<float> {
   static constexpr int V = 4;
-  static __device__ __forceinline__ void load_nt(const char* base, int64_t i, float* o) { load(base, i, o); }
   static __device__ __forceinline__ void load(const char* base, int64_t i, float* o) {
     const float4 v = *reinterpret_cast<const float4*>(base + i * 4);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -23,13 +22,6 @@ template <> struct VecIO<float> {
 };
 template <> struct VecIO<bf16_t> {
   static constexpr int V = 8;
-  static __device__ __forceinline__ void load_nt(const char* base, int64_t i, float* o) {   // last use of a streamed tensor: do not keep the line
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + i * 2));
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { o[2 * k] = bf2f(w[k] & 0xffff); o[2 * k + 1] = bf2f(w[k] >> 16); }
-  }
   static __device__ __forceinline__ void load(const char* base, int64_t i, float* o) {
     const uint4 v = *reinterpret_cast<const uint4*>(base + i * 2);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -103,15 +95,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel_v(const BnApply d, const 
 }
 
 // dz for y-row (b, ql) where ql = row inside the batch item; chunk of V channels at c
-template <typename T, bool NT = false>
+template <typename T>
 __device__ __forceinline__ void load_dz_v(const BnBwdReduce& d, const char* dz0, const char* dz1, int64_t b, int ql, int c, float* g) {
   constexpr int V = VecIO<T>::V;
 #pragma unroll
   for (int e = 0; e < V; ++e) g[e] = 0.f;
-  if (ql >= d.skip) { if (NT) VecIO<T>::load_nt(dz0, (b * (d.rpb - d.skip) + ql - d.skip) * d.C + c, g); else VecIO<T>::load(dz0, (b * (d.rpb - d.skip) + ql - d.skip) * d.C + c, g); }
+  if (ql >= d.skip) VecIO<T>::load(dz0, (b * (d.rpb - d.skip) + ql - d.skip) * d.C + c, g);
   if (dz1) {
     float h[V];
-    if (NT) VecIO<T>::load_nt(dz1, (b * d.rpb + ql) * d.C + c, h); else
     VecIO<T>::load(dz1, (b * d.rpb + ql) * d.C + c, h);
 #pragma unroll
     for (int e = 0; e < V; ++e) g[e] += h[e];
@@ -200,9 +191,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel_v(const BnBwdReduce 
 }
 
 // grid: x over the chunks of one batch item, y = batch item
-// NT: y and dz are read for the last time here (non-temporal loads: their lines need not stay in L2 / MALL beside the dy this pass writes
-// for the GEMMs that follow)
-template <typename T, bool NT = false>
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel_v(const BnBwdApply d, const ArenaBases ab) {
   constexpr int V = VecIO<T>::V;
   __shared__ float sp[4 * kMaxC];
@@ -238,8 +227,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel_v(const BnBwdApply d,
       const int ql = il >> csh;
       float yv[V], gz[V], o[V];
       const int64_t gi = b * r.rpb * C + il;
-      if (NT) VecIO<T>::load_nt(y, gi, yv); else VecIO<T>::load(y, gi, yv);
-      load_dz_v<T, NT>(r, dz0, dz1, b, ql, c, gz);
+      VecIO<T>::load(y, gi, yv);
+      load_dz_v<T>(r, dz0, dz1, b, ql, c, gz);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         const float xh = (yv[e] - pm[e]) * pis[e];
@@ -290,9 +279,7 @@ void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st) {
     const int nb = (int)(d.r.R / d.r.rpb);
     const int v = d.r.dt == DT_BF16 ? 8 : 4;
     int gx = gridcap(d.r.rpb * d.r.C / v, 16384 / (nb > 0 ? nb : 1) + 1);
-    static const int nt = getenv("SEFD_BN_NT") ? atoi(getenv("SEFD_BN_NT")) : 0;
-    if (d.r.dt == DT_BF16 && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel_v<bf16_t, true>), dim3(gx, nb), dim3(256), 0, st, d, ab);
-    else if (d.r.dt == DT_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel_v<bf16_t>), dim3(gx, nb), dim3(256), 0, st, d, ab);
+    if (d.r.dt == DT_BF16) hipLaunchKernelGGL((bn_bwd_apply_kernel_v<bf16_t>), dim3(gx, nb), dim3(256), 0, st, d, ab);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel_v<float>), dim3(gx, nb), dim3(256), 0, st, d, ab);
   }
 }
