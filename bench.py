@@ -101,7 +101,7 @@ def _op_class(info):
     return None
 
 
-def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100):
+def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_bytes=0):
     """Two timing legs over every MFMA GEMM, LSTM recurrence and STFT launch of one step:
       in situ  (the headline `frac`): sefd_plan_run_timed - each phase in its REAL two-stream schedule with a HIP event pair around every
                op on the stream it runs on, i.e. the kernel's duration while the other lane's kernels share the chip (what a rocprofv3
@@ -157,6 +157,11 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100):
             detail[label] = dict(bound="hbm", gb_s=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4), gb_s_isolated=round(gbi, 1),
                                  frac_isolated=round(gbi / PEAK_HBM_GBS, 4), ms=round(v["ms_situ"], 4), ms_isolated=round(v["ms"], 4),
                                  launches=v["launches"], bytes_per_launch=int(v["bytes"] / max(v["launches"], 1)))
+            if name == "stft_fft" and algo_stft_bytes:
+                # the SURVEY 8d figure (fp32 samples in + [514, T] fp32 spectrum out per utterance = 1.185 MB at 3 s): what the transform has to
+                # move; bytes_per_launch above is what THIS kernel moves (it also writes the channel-padded bf16 copy the first conv reads)
+                ga = algo_stft_bytes * v["launches"] / (v["ms_situ"] * 1e-3) / 1e9 if v["ms_situ"] > 0 else 0.0
+                detail[label].update(algorithmic_bytes_per_launch=int(algo_stft_bytes), gb_s_algorithmic=round(ga, 1), frac_algorithmic=round(ga / PEAK_HBM_GBS, 4))
         else:
             tf = v["flops"] / (v["ms_situ"] * 1e-3) / 1e12 if v["ms_situ"] > 0 else 0.0
             tfi = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
@@ -202,9 +207,19 @@ def cpu_baseline(L, kn, ru):
         dccrn_train_step(P, cfgo, x, y, loss_kind="SI-SNR")
         ts.append(time.time() - t0)
     med = sorted(ts)[len(ts) // 2]
-    return dict(value=round(Bc / med, 3), unit="utt/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + {nsteps} timed steps "
-                       f"(median {med:.2f} s/step, min {min(ts):.2f}), fp32")
+    out = dict(value=round(Bc / med, 3), unit="utt/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + {nsteps} timed steps "
+                      f"(median {med:.2f} s/step, min {min(ts):.2f}), fp32")
+    # the bench batch itself (BASELINE.md section 4 asks for B = 32 beside B = 4): two timed steps, bounded by the budget of this leg
+    if med * 8 * 3 < 45:
+        x32, y32 = make_batch(32, L, 0, "cpu")
+        t32 = []
+        for _ in range(3):
+            t0 = time.time()
+            dccrn_train_step(P, cfgo, x32, y32, loss_kind="SI-SNR")
+            t32.append(time.time() - t0)
+        out["b32"] = dict(value=round(32 / min(t32[1:]), 3), unit="utt/s", sample=f"B=32, 1 warm-up + 2 timed steps (min {min(t32[1:]):.2f} s/step)")
+    return out
 
 
 def main():
@@ -307,7 +322,8 @@ def main():
             global PMC_SUMMARY
             if args.model != "dccrn":
                 PMC_SUMMARY = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{args.model}.json")
-            out["roofline"] = roofline(plan, arenas, pmc_ok=(B == PMC_DEFAULT_BATCH[args.model] and not args.perceptual and args.dtype == "bf16"))
+            out["roofline"] = roofline(plan, arenas, pmc_ok=(B == PMC_DEFAULT_BATCH[args.model] and not args.perceptual and args.dtype == "bf16"),
+                                       algo_stft_bytes=0 if args.model == "fullsubnet" else B * (4 * L + 4 * 514 * plan.T))
             info = [plan.op_info(ph, i) for ph in (0, 1) for i in range(plan.num_ops(ph))]
             mf = sum(o["flops"] for o in info if o["kind"] in (K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD))
             peak = PEAK_TFLOPS[1 if args.dtype == "bf16" else 0]

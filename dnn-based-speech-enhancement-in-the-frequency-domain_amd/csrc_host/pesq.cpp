@@ -271,6 +271,107 @@ static double pesq_raw(const double* refx, const double* degx, long n, double in
     }
     fda[(size_t)f] = pseudo_lp(dist, 1.0);
   }
+  // ---- bad intervals (P.862 psychoacoustic model): runs of frames whose symmetric disturbance exceeds 30 (smeared over +-2 frames, at least
+  // 5 frames long) get a local delay from the cross-correlation of the rectified signals over +-4 transform lengths; the degraded frames of the
+  // interval are re-analysed at that delay and each frame keeps the SMALLER of its two disturbances
+  {
+    std::vector<char> bad((size_t)nfr), sm((size_t)nfr, 0);
+    for (long f = 0; f < nfr; ++f) bad[(size_t)f] = fd[(size_t)f] > 30.0;
+    const long stopf = stop_frame;
+    for (long f = 2; f < stopf - 2; ++f) {
+      char l = bad[(size_t)f], r = bad[(size_t)f];
+      for (int i = -2; i <= 0; ++i) l = std::max(l, bad[(size_t)(f + i)]);
+      for (int i = 0; i <= 2; ++i) r = std::max(r, bad[(size_t)(f + i)]);
+      sm[(size_t)f] = std::min(l, r);
+    }
+    struct Iv { long f0, f1, s0, s1, delay; };
+    std::vector<Iv> ivs;
+    long f = 0;
+    while (f <= stopf) {
+      while (f <= stopf && !sm[(size_t)f]) ++f;
+      if (f <= stopf) {
+        const long f0 = f;
+        while (f <= stopf && sm[(size_t)f]) ++f;
+        if (f <= stopf && f - f0 >= 5) ivs.push_back(Iv{f0, f, 0, 0, 0});
+      }
+    }
+    if (!ivs.empty()) {
+      const long nn = maxn - kSearch * kDown + pad;          // one past the last usable sample index
+      auto tweaked = [&](long i) {                           // the degraded signal at the file delay, clamped like the standard's copy loop
+        long j = i + delay;
+        if (j < 0) j = 0;
+        if (j >= (long)deg.data.size()) j = (long)deg.data.size() - 1;
+        return deg.data[(size_t)j];
+      };
+      const long sr = 4L * kNf;
+      for (Iv& iv : ivs) {
+        iv.s0 = iv.f0 * (kNf / 2) + (long)kSearch * kDown;
+        iv.s1 = iv.f1 * (kNf / 2) + kNf + (long)kSearch * kDown;
+        const long ns = iv.s1 - iv.s0, tot = 2 * sr + ns;
+        size_t p2 = 1;
+        while ((long)p2 < 2 * tot) p2 <<= 1;
+        std::vector<std::complex<double>> a(p2), b2(p2);
+        double p1 = 0, pw2 = 0;
+        for (long i = 0; i < tot; ++i) {
+          double rv = (i >= sr && i < sr + ns) ? ref.data[(size_t)(iv.s0 + i - sr)] : 0.0;
+          long j = iv.s0 - sr + i;
+          if (j < (long)kSearch * kDown) j = (long)kSearch * kDown;
+          if (j >= nn) j = nn - 1;
+          const double dv = tweaked(j);
+          p1 += rv * rv; pw2 += dv * dv;
+          a[(size_t)i] = std::fabs(rv); b2[(size_t)i] = std::fabs(dv);
+        }
+        const double norm = std::sqrt((p1 / (double)tot) * ((double)tot / (double)p2) * (pw2 / (double)tot) * ((double)tot / (double)p2));
+        fft(a, false); fft(b2, false);
+        for (size_t i = 0; i < p2; ++i) a[i] = std::conj(a[i]) * b2[i];
+        fft(a, true);
+        double best = 0; long bd = 0;
+        for (long i = -sr; i <= -1; ++i) { const double h = std::fabs(a[(size_t)(i + (long)p2)].real()) / (norm * (double)p2); if (h > best) { best = h; bd = i; } }
+        for (long i = 0; i < sr; ++i) { const double h = std::fabs(a[(size_t)i].real()) / (norm * (double)p2); if (h > best) { best = h; bd = i; } }
+        iv.delay = best < 0.5 ? 0 : bd;
+      }
+      // doubly aligned degraded signal inside the intervals, re-analysis of their frames
+      Signal dd = deg;
+      for (size_t i = 0; i < dd.data.size(); ++i) dd.data[i] = tweaked((long)i);
+      for (const Iv& iv : ivs)
+        for (long i = iv.s0; i < iv.s1 && i < (long)dd.data.size(); ++i) {
+          long j = i + iv.delay;
+          if (j < 0) j = 0;
+          if (j >= nn) j = nn - 1;
+          dd.data[(size_t)i] = tweaked(j);
+        }
+      double old2 = 1;
+      for (const Iv& iv : ivs)
+        for (long fr2 = iv.f0; fr2 < iv.f1 && fr2 < nfr; ++fr2) {
+          const long st = (long)kSearch * kDown + fr2 * kNf / 2;
+          double* r = &pr[(size_t)fr2 * kNb];
+          double d2[kNb];
+          short_term_fft(dd, win, st, hz);
+          freq_warping(hz, d2);
+          const double ta_r = total_audible(r, 1), ta_d = total_audible(d2, 1);
+          double scale = (ta_r + 5e3) / (ta_d + 5e3);
+          if (fr2 > 0) scale = 0.2 * old2 + 0.8 * scale;
+          old2 = scale;
+          scale = std::min(5.0, std::max(3e-4, scale));
+          for (int band = 0; band < kNb; ++band) d2[band] *= scale;
+          double lr[kNb], ld[kNb], dist[kNb];
+          intensity_warping(r, lr);
+          intensity_warping(d2, ld);
+          for (int band = 0; band < kNb; ++band) {
+            const double q = ld[band] - lr[band], m = 0.25 * std::min(ld[band], lr[band]);
+            dist[band] = q > m ? q - m : (q < -m ? q + m : 0.0);
+          }
+          fd[(size_t)fr2] = std::min(fd[(size_t)fr2], pseudo_lp(dist, 2.0));
+          for (int band = 0; band < kNb; ++band) {
+            double h = std::pow((d2[band] + 50.0) / (r[band] + 50.0), 1.2);
+            if (h > 12) h = 12;
+            if (h < 3) h = 0;
+            dist[band] *= h;
+          }
+          fda[(size_t)fr2] = std::min(fda[(size_t)fr2], pseudo_lp(dist, 1.0));
+        }
+    }
+  }
   if (nfr > 1000) {
     const long nn = (maxn - 2L * kSearch * kDown) / (kNf / 2) - 1;
     double twf = std::min(0.5, ((double)nn - 1000.0) / 5500.0);
