@@ -13,8 +13,8 @@ struct sefd_plan {
   Plan* p;
   std::vector<std::string> names;
   // second stream + events for the off-critical-path lane (created on first use, owned by the plan)
-  mutable hipStream_t side = nullptr;
-  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  mutable hipStream_t side = nullptr, side2 = nullptr;   // side2: lane 3 (the layer-1 input GEMMs between the chunks of the forward recurrences)
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side2 = nullptr;
   // host-mapped status word of THIS plan (created on first use: plans are also built on hosts without a GPU).  0 = fine; sticky once set
   // by a kernel that gave up (cluster LSTM hand-over timeout) until sefd_plan_status(clear = 1)
   mutable int* status = nullptr;
@@ -48,6 +48,8 @@ sefd_plan* sefd_plan_create(const sefd_model_config* cfg) {
 void sefd_plan_destroy(sefd_plan* h) {
   if (!h) return;
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->side2) { (void)hipStreamSynchronize(h->side2); (void)hipStreamDestroy(h->side2); }
+  if (h->ev_side2) (void)hipEventDestroy(h->ev_side2);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->status) (void)hipHostFree(h->status);
@@ -215,7 +217,7 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   bool two_lane = !no_overlap && first == 0 && last == (int)ops.size();
   if (two_lane) {
     bool any1 = false, any2 = false, lstm = false;
-    for (const Op& op : ops) { any1 |= op.lane == 1; any2 |= op.lane == 2; lstm |= op.kind == OP_LSTM_BWD; }
+    for (const Op& op : ops) { any1 |= op.lane == 1; any2 |= op.lane >= 2; lstm |= op.kind == OP_LSTM_BWD; }
     two_lane = any2 || (any1 && lstm);
   }
   if (!two_lane) {                                       // program order on one stream is always a valid schedule
@@ -227,6 +229,8 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return -3;
+    if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) return -3;
+    if (hipEventCreateWithFlags(&h->ev_side2, hipEventDisableTiming) != hipSuccess) return -3;
   }
   std::vector<int> held;
   bool has_lstm_bwd = false;
@@ -235,13 +239,34 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   for (int i = 0; i < (int)ops.size(); ++i) if (ops[i].kind == OP_LSTM_BWD) last_lstm = i;
   bool forked = !has_lstm_bwd;                           // no LSTM backward in this phase: lane-1 ops are never held back
   bool side_busy = false;                                // the side stream holds work the main stream has not waited for
+  bool side2_busy = false;                               // the third stream holds work the side stream has not waited for
+  bool fork_fresh = false;                               // ev_fork was recorded and the main stream has been given nothing since
+  auto fork = [&]() { if (!fork_fresh) { (void)hipEventRecord(h->ev_fork, st); fork_fresh = true; } };
   auto side_launch = [&](const Op& op) {                 // program order up to here is satisfied on the main stream
-    (void)hipEventRecord(h->ev_fork, st);
+    fork();
     (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+    if (side2_busy) {                                    // ... and on the third stream (lane-2 ops read what lane-3 ops in front of them wrote)
+      (void)hipEventRecord(h->ev_side2, h->side2);
+      (void)hipStreamWaitEvent(h->side, h->ev_side2, 0);
+      side2_busy = false;
+    }
     launch(op, h->side);
     side_busy = true;
   };
+  // lane 3: ordered behind the main stream's work so far and behind earlier lane-3 ops only - NOT behind the side stream, so the planner
+  // gives it ops that read main-stream results alone (layer-1 input GEMM of chunk k beside layer 1's recurrence over chunk k - 1)
+  auto side2_launch = [&](const Op& op) {
+    fork();
+    (void)hipStreamWaitEvent(h->side2, h->ev_fork, 0);
+    launch(op, h->side2);
+    side2_busy = true;
+  };
   auto join = [&]() {
+    if (side2_busy) {
+      (void)hipEventRecord(h->ev_side2, h->side2);
+      (void)hipStreamWaitEvent(st, h->ev_side2, 0);
+      side2_busy = false;
+    }
     if (!side_busy) return;
     (void)hipEventRecord(h->ev_join, h->side);
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
@@ -251,10 +276,13 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     const Op& op = ops[i];
     // held: every lane-1 op in front of the first recurrence, and the ones marked kOpHold, wait for the next recurrence launch
     if (op.lane == 1 && i < last_lstm && (!forked || op.join == kOpHold)) { held.push_back(i); continue; }
+    if (op.lane == 3) { side2_launch(op); continue; }
     if (op.lane == 1 || op.lane == 2) { side_launch(op); continue; }
     if (op.kind == OP_LSTM_BWD && (!forked || !held.empty())) {
-      (void)hipEventRecord(h->ev_fork, st);              // everything the held ops read has been produced before this point
+      fork_fresh = false;
+      fork();                                            // everything the held ops read has been produced before this point
       launch(op, st);                                    // the recurrence takes its CUs first
+      fork_fresh = false;
       (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
       for (int j : held) launch(ops[j], h->side);
       side_busy = side_busy || !held.empty();
@@ -265,6 +293,7 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     if (op.join == 1 || (op.kind == OP_UNPACK && op.join != kOpNoJoin)) join();   // UNPACK gathers gradient partials: needs the side lane's results
                                                          // (kOpNoJoin: a bucket whose partials all come from the main stream - FullSubNet's full-band model)
     launch(op, st);
+    fork_fresh = false;
     if (i == at && cb) cb(ctx);                          // e.g. the first gradient bucket is complete: the caller starts its all-reduce
   }
   join();

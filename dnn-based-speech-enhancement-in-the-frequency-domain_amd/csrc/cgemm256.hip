@@ -17,8 +17,8 @@
 //     K tile p is multiplied (prefetch distance 1.5 - 2 K tiles of 2048 MFMA cycles each: covers an HBM miss), ordered by counted
 //     `s_waitcnt vmcnt(N)`: the queue is never drained inside the loop;
 //   * persistent: workgroup b works on output tiles b, b + gridDim, ...; the ring positions carry over, so the first K tiles of
-//     the next output tile are already in flight during the epilogue, which needs no workgroup barrier (each wave stages its own
-//     32 x 64 pieces through a private 4 KB of the one A slot that is free at that moment, 16-byte row-chunk stores).
+//     the next output tile are already in flight during the epilogue, which touches neither LDS nor a barrier (quad transpose in
+//     registers, 8-byte row-piece stores; dev_common.h QuadT).
 // Same descriptor (sefd_desc.h RunGemm) and epilogue contract (bias, ReLU, accumulate, BatchNorm partial sums per 128 rows) as
 // rungemm_kernel.
 #include <hip/hip_runtime.h>
@@ -293,15 +293,17 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
       // reads the same chunk of the BatchNorm layer's forward output (coalesced) and accumulates the three backward sums of its 8 columns.
       if (!(dbg & 8)) {
         char* wt = smem + wid * 16384;
+        const QuadT qt(lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            const int col = j * 32 + (lane & 31);
+            const int col = j * 32 + (lane & 28);                  // quad transpose: this lane writes 4 consecutive columns of ONE row per group
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-              *reinterpret_cast<uint16_t*>(wt + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = f2bf(acc[i][j][e] + bv[j]);
+            for (int q = 0; q < 4; ++q) {
+              const int row = i * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
+              const uint2 pk = qt.pack(acc[i][j][4 * q] + bv[j], acc[i][j][4 * q + 1] + bv[j], acc[i][j][4 * q + 2] + bv[j], acc[i][j][4 * q + 3] + bv[j]);
+              *reinterpret_cast<uint2*>(wt + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = pk;
             }
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -378,10 +380,10 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
       continue;
     }
     if (dbg & 8) continue;
-    // ---- epilogue, wave local.  Slot gk % 3 is where the next tile's A(0) goes, gk + 1 its A(1); slot gk + 2 held this tile's
-    // last K tile (all reads done: every wave is past the barrier above) and is refilled only during the next tile's K tile 0,
-    // i.e. after every wave has left this epilogue: this wave's 4 KB of it is the staging buffer.
-    char* stg = smem + ((gk + 2) % NAS) * A_SLOT + wid * 4096;
+    // ---- epilogue, wave local, no LDS: bias / ReLU / statistics on the accumulators as they sit (one column per lane), then the quad transpose
+    // of dev_common.h QuadT turns every group of 4 rows x 4 lanes into 8-byte row pieces that are stored directly (a wave instruction covers 8 rows x
+    // 64 contiguous bytes).  The LDS-staged version (128 ds_write_b16 + 16 ds_read_b128 per lane) took 28-34 % of the kernel (SEFD_CG256_DBG=8).
+    const QuadT qt(lane);
     float s1[NI], s2[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) s1[j] = s2[j] = 0.f;
@@ -389,28 +391,33 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     for (int i = 0; i < MI; ++i) {
       const int row0 = mtile * BM + wm0 + i * 32;
       if (staged) {
+        int64_t ro[4];                                       // output offsets of this lane's 4 rows after the transpose (-1: beyond M)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = row0 + 8 * q + 4 * (lane >> 5) + (lane & 3);
+          ro[q] = -1;
+          if (m < d.M) {
+            const int b = fdiv2(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv2(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+            ro[q] = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int col = j * 32 + (lane & 31);
           const bool nok = ntile * BN + wn0 + col < d.N;
+          const int n0 = ntile * BN + wn0 + j * 32 + (lane & 28);
+          float v[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            float v = acc[i][j][e] + bv[j];
-            if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
-            *reinterpret_cast<uint16_t*>(stg + row * 128 + (((col >> 3) ^ ((row >> 2) & 7)) << 4) + (col & 7) * 2) = f2bf(v);
-            if (row0 + row < d.M && nok) { s1[j] += v; s2[j] += v * v; }
+            v[e] = acc[i][j][e] + bv[j];
+            if (d.flags & kRunRelu) v[e] = fmaxf(v[e], 0.f);
+            if (row0 + row < d.M && nok) { s1[j] += v[e]; s2[j] += v[e] * v[e]; }
           }
-        }
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {                     // 32 rows x 8 chunks of 16 B = 256 chunks, 4 per lane
-          const int c = lane + 64 * c4, row = c >> 3, ch = c & 7;
-          const int m = row0 + row, n0 = ntile * BN + wn0 + ch * 8;
-          const uint4 v = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ ((row >> 2) & 7)) << 4));
-          if (m < d.M && n0 < d.N) {
-            const int b = fdiv2(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv2(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
-            const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = v;
+          for (int q = 0; q < 4; ++q) {
+            const uint2 pk = qt.pack(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            if (ro[q] >= 0 && n0 < d.N) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yb) + ro[q] + n0) = pk;   // N % 8 == 0: 4 columns are all valid or all padding
           }
         }
       } else {

@@ -30,6 +30,27 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return r;
 }
 __device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)pack_bf16x2(f, 0.f); }
+
+// Epilogue transpose of the 32x32 MFMA accumulator layout.  A lane holds ONE column (lane & 31) and, per group q, the 4 consecutive rows
+// 8q + 4 (lane >> 5) + 0..3: stored as they sit, a tile leaves as 2-byte pieces (round 4, SEFD_CG256_DBG=8: the staged epilogue of the wide
+// kernel with 128 ds_write_b16 per lane was 28-34 % of its run time).  A 4 x 4 transpose inside each quad of lanes on PACKED bf16 pairs - two
+// DPP row exchanges (lane ^ 1 with a byte permute, lane ^ 2 with selects), 11 VALU operations per 4 values - leaves lane (lane & 3) = p with
+// row 8q + 4 (lane >> 5) + p and the 4 consecutive columns (lane & 28) .. + 3: one 8-byte store.  Must run with all 64 lanes active.
+struct QuadT {
+  uint32_t sel;      // v_perm selector of the lane ^ 1 exchange: even lanes take the low halves (self, partner), odd lanes the high halves (partner, self)
+  bool hi2;          // lane & 2
+  __device__ __forceinline__ explicit QuadT(int lane) : sel((lane & 1) ? 0x03020706u : 0x05040100u), hi2((lane & 2) != 0) {}
+  __device__ __forceinline__ uint2 pack(uint32_t p01, uint32_t p23) const {                 // p01 = bf16 (row 0 | row 1 << 16), p23 = (row 2 | row 3 << 16) of this lane's column
+    const uint32_t n01 = (uint32_t)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+    const uint32_t n23 = (uint32_t)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xF, 0xF, true);
+    const uint32_t q0 = __builtin_amdgcn_perm(n01, p01, sel);      // even lane: row 0 of columns (c, c + 1); odd lane: row 1 of columns (c - 1, c)
+    const uint32_t q1 = __builtin_amdgcn_perm(n23, p23, sel);      // even lane: row 2; odd lane: row 3
+    const uint32_t send = hi2 ? q0 : q1, keep = hi2 ? q1 : q0;
+    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true); // quad_perm [2, 3, 0, 1]
+    return make_uint2(hi2 ? recv : keep, hi2 ? keep : recv);
+  }
+  __device__ __forceinline__ uint2 pack(float v0, float v1, float v2, float v3) const { return pack(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)); }
+};
 __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 template <int DT> struct Elem;

@@ -955,7 +955,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         r.t0 = t0; r.t1 = t1;
         b.push(F, OP_LSTM_FWD, 200).lstm = r;
       }
-      b.cur_lane = 2;
+      // lane 3 (third stream): the input GEMM of layer 1 for this chunk reads layer 0's chunk only, so it runs BESIDE layer 1's recurrence
+      // over the previous chunk instead of queueing behind it on the second stream (round 4 timeline: 657 -> ~520 us for the LSTM block)
+      static const bool lane3 = !(getenv("SEFD_LSTM_LANE3") && atoi(getenv("SEFD_LSTM_LANE3")) == 0);
+      b.cur_lane = lane3 ? 3 : 2;
       {
         Op& op = b.push(F, OP_COMBINE_FWD, 200);
         op.comb.h = ls[0].h; op.comb.out = ls[0].hc; op.comb.rows = BT; op.comb.H = H; op.comb.dt = adt;
@@ -969,6 +972,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
         g.y_off += t0 * g.y_tstride;
         b.push(F, OP_RUNGEMM, 201).g = g;
       }
+      b.cur_lane = 2;
       {
         LstmRec r = pipe_rec[1];
         r.t0 = t0; r.t1 = t1;

@@ -346,7 +346,9 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
   int64_t* rowoffb = rowoff + BM;                                  // [BM] row offsets into the BatchNorm layer's forward output (kRunBnBwd)
   float* stat = reinterpret_cast<float*>(smem + BM * 16);          // [NW][BN][3]
   uint16_t* otile = reinterpret_cast<uint16_t*>(smem + BM * 16 + NW * BN * 12);    // [BM][OS] bf16 staging tile (kRunYAligned)
-  constexpr int OS = BN + 8;                                       // row stride in elements: 16-byte aligned rows, rotating banks
+  // row stride in elements: 16-byte aligned rows; in dwords = 16 (mod 32), so that the 4 rows x 64 bytes a half wave writes per ds_write_b64
+  // of the quad-transposed tile (dev_common.h QuadT) fall into disjoint banks, and the 16-byte chunk reads of a row stay conflict-free
+  constexpr int OS = BN % 64 == 0 ? BN + 32 : BN;
   constexpr bool kCanStage = BM * 16 + NW * BN * 12 + BM * OS * 2 <= S * TILE_BYTES;
   const bool staged = kCanStage && (d.flags & kRunYAligned) && !(d.flags & kRunAccum);
   constexpr bool bnb = BNB;
@@ -396,19 +398,31 @@ __global__ __launch_bounds__(NW * 64) void rungemm_kernel(const RunGemm d, const
     if (staged) {
       // bf16 output through LDS: the 32x32 accumulator layout gives every lane ONE column, i.e. 2-byte global stores in
       // 64-byte pieces; staged, the tile leaves as whole 16-byte chunks of contiguous rows (8x fewer store instructions)
+      // (round 4: written as 8-byte row pieces after the quad transpose - 4 x fewer LDS stores than one 2-byte store per accumulator element)
+      const QuadT qt(lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-          float v = acc[i][j][e] + bv;
-          if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
-          const uint16_t hv = f2bf(v);
-          otile[row * OS + nl] = hv;
-          if (!bnb_chunk && mtile * BM + row < d.M && n < d.N) {
-            if (bnb) bnb_accum(bc, bslope, bf2f(hv), ld_elem(ybn, d.ydt, rowoffb[row] + n), s1, s2, s3);
-            else { s1 += v; s2 += v * v; }
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][4 * q + r] + bv;
+            if (d.flags & kRunRelu) v[r] = fmaxf(v[r], 0.f);
           }
+          const uint32_t p01 = pack_bf16x2(v[0], v[1]), p23 = pack_bf16x2(v[2], v[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = wm0 + i * 32 + r + 8 * q + 4 * (lane >> 5);
+            if (!bnb_chunk && mtile * BM + row < d.M && n < d.N) {
+              const uint16_t hv = (uint16_t)((r < 2 ? p01 : p23) >> (16 * (r & 1)));
+              if (bnb) bnb_accum(bc, bslope, bf2f(hv), ld_elem(ybn, d.ydt, rowoffb[row] + n), s1, s2, s3);
+              else { s1 += v[r]; s2 += v[r] * v[r]; }
+            }
+          }
+          const uint2 pk = qt.pack(p01, p23);
+          const int trow = wm0 + i * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
+          *reinterpret_cast<uint2*>(otile + trow * OS + wn0 + j * 32 + (lane & 28)) = pk;
         }
       }
     } else {

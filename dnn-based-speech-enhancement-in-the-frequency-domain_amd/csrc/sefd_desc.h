@@ -381,7 +381,8 @@ struct Op {
   int32_t tag;                 // layer id for profiling / debugging
   int32_t lane;                // 0: critical path.  2: second stream, issued at its program position (waits for everything the main
                                // stream has been given so far); a lane-0 op with `join` set makes the main stream wait for the
-                               // second one first.  1: off the critical path (weight gradients, their folds, the early UNPACK): a
+                               // second one first.  3: third stream, behind the main stream's work so far and earlier lane-3 ops
+                               // only; the next lane-2 op (and any join) waits for it.  1: off the critical path (weight gradients, their folds, the early UNPACK): a
                                // full-phase run holds the ones in front of the first LSTM backward back and runs them on a second HIP
                                // stream next to it (the recurrence occupies 32 of the 256 CUs); see api.hip plan_run
   int32_t join;                // lane 0: 1 = wait for the second stream first.  lane 1: kOpHold = issue behind the NEXT recurrence launch
