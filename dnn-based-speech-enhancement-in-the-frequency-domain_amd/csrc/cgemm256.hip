@@ -62,7 +62,10 @@ __device__ __forceinline__ void wait_allow(int allow) {
 // extra epilogue state in the one body the allocator spilled inside the K loop of EVERY launch (15x slower)
 // (dbg stays a run-time argument: with the switches folded to constants the allocator of this 256-register kernel spilled 236 instead of
 //  188 bytes and the step was 0.4 ms SLOWER - measured round 4, same box: 11.26 vs 10.87 ms)
-template <bool BNB>
+// NB (experiment, SEFD_CG256_NB=1): ONE workgroup barrier per K tile instead of the two per k16 step of the staggered groups - the two waves of a
+// SIMD interleave on their own; B(p+1) is issued in steps 0-1 and A(p+2) in steps 2-3 of K tile p, so that at the top of K tile p + 1 only A(p+2)
+// may still be in flight (vmcnt(4)).
+template <bool BNB, bool NB = false>
 __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const ArenaBases ab, const int dbg) {
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int KT = 64;                                     // K tile of the A operand and of the loop (two 32-deep B tiles)
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     issue_b(0, 0, kt32[0]);
     issue_b(0, 1, kt32[0]);
     mark_h1 = nis;                                           // everything up to here lands before step 2 of K tile 0
-    if (nkt > 1) { issue_a(0); issue_a(1); issue_b(1, 0, kt32[1]); }
+    if (nkt > 1) { issue_a(0); issue_a(1); if (!NB) issue_b(1, 0, kt32[1]); }
     mark_kt = nis;                                           // everything up to here lands before K tile 1 begins
     mark_h1_next = nis;
   };
@@ -233,15 +236,44 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     for (int i = 0; i < MI; ++i) af[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NI; ++j) bf[j] = make_uint4(0, 0, 0, 0);
-    wait_allow(nis - mark_h1);
-    wg_barrier();                                            // A(0), B(0) of this tile have landed (everyone's part)
-    if (grp == 1) wg_barrier();                              // group B runs one phase behind group A
+    if constexpr (!NB) {
+      wait_allow(nis - mark_h1);
+      wg_barrier();                                          // A(0), B(0) of this tile have landed (everyone's part)
+      if (grp == 1) wg_barrier();                            // group B runs one phase behind group A
+    }
     c_slot = gk % NAS;
     for (int p = 0; p < nkt; ++p) {
       const bool has1 = p + 1 < nkt, has2 = p + 2 < nkt;
       const char* abase = smem + c_slot * A_SLOT + aoff;
       c_slot = c_slot + 1 == NAS ? 0 : c_slot + 1;
       const char* bbase = smem + ((gk + p) & 1) * 2 * B_SLOT + boff;
+      if constexpr (NB) {
+        if (has1 && !(dbg & 2)) wait_vm<NA>(); else wait_vm<0>();   // A(p), B(p) have landed (this thread's part); only A(p+1) may be in flight
+        wg_barrier();                                        // ... everyone's part; and every wave has finished K tile p - 1: its slots may be refilled
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if (!(dbg & 4)) {
+#pragma unroll
+            for (int ii = 0; ii < MI; ++ii) af[ii] = *reinterpret_cast<const uint4*>(abase + ii * (32 * 128) + (ca0 ^ (32 * s)));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(bbase + (s >> 1) * B_SLOT + j * (32 * 64) + (cb0 ^ (32 * (s & 1))));
+          }
+          if (s == 0) { if (has1) issue_b(p + 1, 0, kt32[1]); }
+          else if (s == 1) { if (has1) issue_b(p + 1, 1, kt32[1]); }
+          else if (s == 2) { if (has2) issue_a(0); }
+          else { if (has2) issue_a(1); }
+          if (!(dbg & 1)) {
+#pragma unroll
+            for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+              for (int j = 0; j < NI; ++j)
+                acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ii]), __builtin_bit_cast(bf16x8, bf[j]),
+                                                                     acc[ii][j], 0, 0, 0);
+          }
+        }
+        kt32[0] = kt32[1]; kt32[1] = kt32[2]; kt32[2] = b_tile32(); b_advance();
+        continue;
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         // ---- read phase of step s (the other group multiplies): 6 fragments, then two DMAs of a later K tile
@@ -281,7 +313,8 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
       }
       kt32[0] = kt32[1]; kt32[1] = kt32[2]; kt32[2] = b_tile32(); b_advance();
     }
-    if (grp == 0) wg_barrier();
+    if (!NB && grp == 0) wg_barrier();
+    if (NB && BNB) wg_barrier();                             // the kRunBnBwd epilogue writes LDS: every wave must be past the last K tile
     gk += nkt;
     // the next tile's first K tiles are in flight during this epilogue - except in the BNB instantiation, where the epilogue needs the
     // registers of that DMA state (it starts the next tile after the epilogue instead)
@@ -466,8 +499,15 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int total = ((d.M + 255) / 256) * (d.Npad / 256);
-  if (d.flags & kRunBnBwd) hipLaunchKernelGGL(cgemm256_kernel<true>, dim3(total < ncu ? total : ncu), dim3(512), 0, st, d, ab, dbg);
-  else hipLaunchKernelGGL(cgemm256_kernel<false>, dim3(total < ncu ? total : ncu), dim3(512), 0, st, d, ab, dbg);
+  static const bool nb = getenv("SEFD_CG256_NB") && atoi(getenv("SEFD_CG256_NB")) != 0;
+  const dim3 grid(total < ncu ? total : ncu);
+  if (nb) {
+    if (d.flags & kRunBnBwd) hipLaunchKernelGGL((cgemm256_kernel<true, true>), grid, dim3(512), 0, st, d, ab, dbg);
+    else hipLaunchKernelGGL((cgemm256_kernel<false, true>), grid, dim3(512), 0, st, d, ab, dbg);
+    return true;
+  }
+  if (d.flags & kRunBnBwd) hipLaunchKernelGGL((cgemm256_kernel<true>), grid, dim3(512), 0, st, d, ab, dbg);
+  else hipLaunchKernelGGL((cgemm256_kernel<false>), grid, dim3(512), 0, st, d, ab, dbg);
   return true;
 }
 
