@@ -4,18 +4,19 @@
 // L2 -> LDS per 2.1 MFLOP and the LDS-DMA stream it sustains next to the MFMAs (~24 B/clk/CU) caps it near 1 PFLOP/s; every
 // K tile ends in a barrier behind which DMA issue, fragment reads and MFMAs run one after the other.  This kernel:
 //   * 256 x 256 output tile per 512-thread workgroup: 128 FLOP per operand byte, the activation operand is streamed once per M tile;
-//   * the 8 waves (2 x 4 grid, 128 x 64 accumulators each) form two groups of 4, one wave of each group per SIMD, that run one
-//     phase apart: while group A multiplies a k16 step out of registers (8 MFMAs), group B reads its 6 fragments of that step
-//     from LDS and issues two of its LDS-DMAs, then they swap - the matrix pipe of every SIMD always has a wave in its MFMA
-//     phase, and a wave is held at DMA issue only while its partner multiplies (measured: with the DMAs switched off this loop
-//     runs at the MFMA rate);
+//   * 8 waves in a 2 x 4 grid, 128 x 64 accumulators each, two per SIMD.  ONE workgroup barrier per 64-deep K tile; inside it a wave runs its
+//     four k16 steps (6 fragment reads, 8 MFMAs, two LDS-DMAs behind the fourth MFMA) at its own pace and the two waves of a SIMD
+//     interleave on their own.  (Rounds 2-3 ran the waves as two groups one phase apart with two barriers per k16 step: the slowest wave -
+//     the one held longest at a DMA issue - then paced all eight twice per step.  Round 4, same box: 10.55 -> 10.44 ms per step, 19.0 -> 18.8
+//     at B = 64, DCCRN-large 54.2 -> 54.1, FullSubNet 66.8 -> 66.7; two fragment register sets inside the loop measured no better.)
 //   * every DMA instruction moves whole 128-byte lines: the A operand is staged in 64-deep K tiles (8 rows x 128 B per
 //     instruction), the weights are packed K-tile major (kRunWTile32) so that a 32-deep B tile is one contiguous 16 KB block.
 //     With 64-byte row pieces (first version) every line was fetched twice from L2 and the DMA stream alone took 1250-1480
 //     cycles per 32-deep K tile against 1024 cycles of MFMAs; with whole lines ~800;
-//   * LDS ring: 3 A slots of 32 KB + 4 B sub-slots of 16 KB = exactly 160 KB.  A(p+2), Bh1(p+1) and Bh0(p+2) are issued while
-//     K tile p is multiplied (prefetch distance 1.5 - 2 K tiles of 2048 MFMA cycles each: covers an HBM miss), ordered by counted
-//     `s_waitcnt vmcnt(N)`: the queue is never drained inside the loop;
+//   * LDS ring: 3 A slots of 32 KB + 4 B sub-slots of 16 KB = exactly 160 KB.  While K tile p is multiplied, B(p+1) is issued in its steps 0-1
+//     (into the sub-slots of K tile p-1) and A(p+2) in steps 2-3 (into the slot of K tile p-1): at the top of K tile p+1 a thread waits with
+//     `s_waitcnt vmcnt(4)` - only its four A(p+2) instructions may still be in flight - and the barrier behind that wait both publishes
+//     everyone's part of A(p+1), B(p+1) and frees the slots of K tile p.  The queue is never drained inside the loop;
 //   * persistent: workgroup b works on output tiles b, b + gridDim, ...; the ring positions carry over, so the first K tiles of
 //     the next output tile are already in flight during the epilogue, which touches neither LDS nor a barrier (quad transpose in
 //     registers, 8-byte row-piece stores; dev_common.h QuadT).
@@ -41,19 +42,6 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// wait until at most `allow` of this thread's DMAs are still in flight (allow is wave-uniform; rounded down to an even count)
-// (a binary decision tree: the linear ladder cost up to seven scalar compares + branches per call, twice per k16 step of every wave -
-//  round 4 counters: 5.4 SALU + 5.4 VALU instructions per MFMA in this kernel, the read phase - not the MFMAs - sets the step time)
-__device__ __forceinline__ void wait_allow(int allow) {
-  if (allow >= 8) {
-    if (allow >= 12) { if (allow >= 14) wait_vm<14>(); else wait_vm<12>(); }
-    else { if (allow >= 10) wait_vm<10>(); else wait_vm<8>(); }
-  } else {
-    if (allow >= 4) { if (allow >= 6) wait_vm<6>(); else wait_vm<4>(); }
-    else { if (allow >= 2) wait_vm<2>(); else wait_vm<0>(); }
-  }
-}
-
 }  // namespace
 
 // dbg (tuning runs only, SEFD_CG256_DBG): 1 skip the MFMAs, 2 skip the DMAs, 4 skip the fragment reads, 8 skip the epilogue,
@@ -62,10 +50,7 @@ __device__ __forceinline__ void wait_allow(int allow) {
 // extra epilogue state in the one body the allocator spilled inside the K loop of EVERY launch (15x slower)
 // (dbg stays a run-time argument: with the switches folded to constants the allocator of this 256-register kernel spilled 236 instead of
 //  188 bytes and the step was 0.4 ms SLOWER - measured round 4, same box: 11.26 vs 10.87 ms)
-// NB (experiment, SEFD_CG256_NB=1): ONE workgroup barrier per K tile instead of the two per k16 step of the staggered groups - the two waves of a
-// SIMD interleave on their own; B(p+1) is issued in steps 0-1 and A(p+2) in steps 2-3 of K tile p, so that at the top of K tile p + 1 only A(p+2)
-// may still be in flight (vmcnt(4)).
-template <bool BNB, bool NB = false>
+template <bool BNB>
 __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const ArenaBases ab, const int dbg) {
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int KT = 64;                                     // K tile of the A operand and of the loop (two 32-deep B tiles)
@@ -81,7 +66,6 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid >> 2;                                  // 0: group A, 1: group B (one phase behind)
   const int nn = d.Npad / BN;
   const int nm = (d.M + BM - 1) / BM;
   const int total = nm * nn;
@@ -117,7 +101,6 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   const float bslope = BNB ? *reinterpret_cast<const float*>(rp(ab, d.bnb_slope)) : 0.f;
 
   int gk = 0;                                                // K tiles finished by this workgroup so far (ring positions carry over)
-  int nis = 0;                                               // DMA instructions issued so far by this thread
   // ---- DMA state of the output tile being loaded (set up, and its first K tiles issued, before the previous tile's epilogue)
   int d_ntile = 0, d_mtile = 0;
   int64_t rb0[NA], rb1[NA];
@@ -130,7 +113,6 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   int a_slot = 0, c_slot = 0;                                // ring slots (gk + a_local) % NAS of the issue cursor / (gk + p) % NAS of the K loop, kept incrementally
   int bseg = 0, bk0 = 0, bseglen = 0, bkoff = 0;             // B cursor (advances per 64-deep K tile)
   int kt32[3];                                               // 32-deep weight tile index of local K tiles p, p+1, p+2
-  int mark_h1 = 0, mark_h1_next = 0, mark_kt = 0;
   auto enter_run = [&](int sgi) {
     const Seg sg = d.seg[sgi];
     aseglen = sg.len;
@@ -162,7 +144,6 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
         const uint16_t* src = (j0 >= jlo[q] && j0 + 8 <= jhi[q] && !(dbg & 32)) ? rptr[q] + j0 : zp;
         dma16(src, A + (q * NW + wid) * 1024);
       }
-      nis += 2;
     }
     if (hf == 1) {
       ++a_local;
@@ -178,12 +159,11 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
       const uint16_t* src = wb0 + ((int64_t)koff32 + h) * wtile;
 #pragma unroll
       for (int q = 0; q < NBH; ++q) dma16(src + q * (NW * 16 * 32), B + (q * NW + wid) * 1024);
-      nis += NBH;
     }
   };
   auto b_tile32 = [&]() { return (bkoff + bk0) >> 5; };
   auto b_advance = [&]() { bk0 += KT; if (bk0 >= bseglen && bseg + 1 < d.nseg) { bk0 = 0; ++bseg; bseglen = d.seg[bseg].len; bkoff = d.seg[bseg].koff; } };
-  // set up output tile t and put its first K tiles in flight: A(0), Bh0(0), Bh1(0) [, A(1), Bh0(1)].  Called with gk = the ring
+  // set up output tile t and put its first K tiles in flight: A(0), Bh0(0), Bh1(0) [, A(1)].  Called with gk = the ring
   // position the tile starts at: its slots (gk, gk + 1; both B pairs) are free as soon as the previous tile's K loop is over.
   auto begin_tile = [&](int t) {
     const int tile = xcd_remap2(t, total);
@@ -210,10 +190,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     kt32[2] = b_tile32(); b_advance();
     issue_b(0, 0, kt32[0]);
     issue_b(0, 1, kt32[0]);
-    mark_h1 = nis;                                           // everything up to here lands before step 2 of K tile 0
-    if (nkt > 1) { issue_a(0); issue_a(1); if (!NB) issue_b(1, 0, kt32[1]); }
-    mark_kt = nis;                                           // everything up to here lands before K tile 1 begins
-    mark_h1_next = nis;
+    if (nkt > 1) { issue_a(0); issue_a(1); }
   };
   if ((int)blockIdx.x < total) begin_tile(blockIdx.x);
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
@@ -236,85 +213,48 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     for (int i = 0; i < MI; ++i) af[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < NI; ++j) bf[j] = make_uint4(0, 0, 0, 0);
-    if constexpr (!NB) {
-      wait_allow(nis - mark_h1);
-      wg_barrier();                                          // A(0), B(0) of this tile have landed (everyone's part)
-      if (grp == 1) wg_barrier();                            // group B runs one phase behind group A
-    }
     c_slot = gk % NAS;
     for (int p = 0; p < nkt; ++p) {
       const bool has1 = p + 1 < nkt, has2 = p + 2 < nkt;
       const char* abase = smem + c_slot * A_SLOT + aoff;
       c_slot = c_slot + 1 == NAS ? 0 : c_slot + 1;
       const char* bbase = smem + ((gk + p) & 1) * 2 * B_SLOT + boff;
-      if constexpr (NB) {
-        if (has1 && !(dbg & 2)) wait_vm<NA>(); else wait_vm<0>();   // A(p), B(p) have landed (this thread's part); only A(p+1) may be in flight
-        wg_barrier();                                        // ... everyone's part; and every wave has finished K tile p - 1: its slots may be refilled
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          if (!(dbg & 4)) {
-#pragma unroll
-            for (int ii = 0; ii < MI; ++ii) af[ii] = *reinterpret_cast<const uint4*>(abase + ii * (32 * 128) + (ca0 ^ (32 * s)));
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(bbase + (s >> 1) * B_SLOT + j * (32 * 64) + (cb0 ^ (32 * (s & 1))));
-          }
-          if (s == 0) { if (has1) issue_b(p + 1, 0, kt32[1]); }
-          else if (s == 1) { if (has1) issue_b(p + 1, 1, kt32[1]); }
-          else if (s == 2) { if (has2) issue_a(0); }
-          else { if (has2) issue_a(1); }
-          if (!(dbg & 1)) {
-#pragma unroll
-            for (int ii = 0; ii < MI; ++ii)
-#pragma unroll
-              for (int j = 0; j < NI; ++j)
-                acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ii]), __builtin_bit_cast(bf16x8, bf[j]),
-                                                                     acc[ii][j], 0, 0, 0);
-          }
-        }
-        kt32[0] = kt32[1]; kt32[1] = kt32[2]; kt32[2] = b_tile32(); b_advance();
-        continue;
-      }
+      if (has1 && !(dbg & 2)) wait_vm<NA>(); else wait_vm<0>();   // A(p), B(p) have landed (this thread's part); only A(p+1) may be in flight
+      wg_barrier();                                        // ... everyone's part; and every wave has finished K tile p - 1: its slots may be refilled
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        // ---- read phase of step s (the other group multiplies): 6 fragments, then two DMAs of a later K tile
         if (!(dbg & 4)) {
 #pragma unroll
           for (int ii = 0; ii < MI; ++ii) af[ii] = *reinterpret_cast<const uint4*>(abase + ii * (32 * 128) + (ca0 ^ (32 * s)));
 #pragma unroll
           for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const uint4*>(bbase + (s >> 1) * B_SLOT + j * (32 * 64) + (cb0 ^ (32 * (s & 1))));
         }
-        if (s == 0) { if (has1) issue_b(p + 1, 1, kt32[1]); }        // sub-slot last read in step 3 of K tile p-1
-        else if (s == 1) { if (has2) issue_a(0); }                   // slot last read in step 3 of K tile p-1
-        else if (s == 2) { if (has2) issue_b(p + 2, 0, kt32[2]); }   // sub-slot last read in step 1 of this K tile
-        else { if (has2) issue_a(1); }
-        if (s == 0) mark_h1_next = nis;                      // Bh1(p+1) has just been issued: it must land before step 2 of K tile p+1
-        if (grp == 1) {                                      // group B is in its read phase when the landing deadlines fall
-          if (s == 1) wait_allow(nis - mark_h1);             // Bh1(p) lands before anyone's step 2
-          if (s == 3 && has1) wait_allow(nis - mark_kt);     // A(p+1), Bh0(p+1) land before K tile p+1 begins
-        }
-        lds_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- multiply phase of step s
         if (!(dbg & 1)) {
 #pragma unroll
-          for (int ii = 0; ii < MI; ++ii)
+          for (int ii = 0; ii < MI; ++ii) {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
               acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ii]), __builtin_bit_cast(bf16x8, bf[j]),
                                                                    acc[ii][j], 0, 0, 0);
+            if (ii == 1) {                                 // this step's two DMAs behind the first four MFMAs: the wave is held at their issue while its
+              __builtin_amdgcn_sched_barrier(0);           // own MFMAs drain (in front of / behind all eight: +0.04 ms per step, same box)
+              if (s == 0) { if (has1) issue_b(p + 1, 0, kt32[1]); }
+              else if (s == 1) { if (has1) issue_b(p + 1, 1, kt32[1]); }
+              else if (s == 2) { if (has2) issue_a(0); }
+              else { if (has2) issue_a(1); }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        } else {
+          if (s == 0) { if (has1) issue_b(p + 1, 0, kt32[1]); }
+          else if (s == 1) { if (has1) issue_b(p + 1, 1, kt32[1]); }
+          else if (s == 2) { if (has2) issue_a(0); }
+          else { if (has2) issue_a(1); }
         }
-        if (grp == 0) {                                      // group A meets the same deadlines at the end of its multiply phase
-          if (s == 1) wait_allow(nis - mark_h1);
-          if (s == 3 && has1) wait_allow(nis - mark_kt);
-        }
-        if (s == 1) mark_h1 = mark_h1_next;
-        if (s == 3) mark_kt = nis;                           // everything of K tiles <= p+2 issued so far lands before K tile p+2
-        wg_barrier();
       }
       kt32[0] = kt32[1]; kt32[1] = kt32[2]; kt32[2] = b_tile32(); b_advance();
     }
-    if (!NB && grp == 0) wg_barrier();
-    if (NB && BNB) wg_barrier();                             // the kRunBnBwd epilogue writes LDS: every wave must be past the last K tile
+    if (BNB) wg_barrier();                             // the kRunBnBwd epilogue writes LDS: every wave must be past the last K tile
     gk += nkt;
     // the next tile's first K tiles are in flight during this epilogue - except in the BNB instantiation, where the epilogue needs the
     // registers of that DMA state (it starts the next tile after the epilogue instead)
@@ -499,13 +439,7 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int total = ((d.M + 255) / 256) * (d.Npad / 256);
-  static const bool nb = getenv("SEFD_CG256_NB") && atoi(getenv("SEFD_CG256_NB")) != 0;
   const dim3 grid(total < ncu ? total : ncu);
-  if (nb) {
-    if (d.flags & kRunBnBwd) hipLaunchKernelGGL((cgemm256_kernel<true, true>), grid, dim3(512), 0, st, d, ab, dbg);
-    else hipLaunchKernelGGL((cgemm256_kernel<false, true>), grid, dim3(512), 0, st, d, ab, dbg);
-    return true;
-  }
   if (d.flags & kRunBnBwd) hipLaunchKernelGGL((cgemm256_kernel<true>), grid, dim3(512), 0, st, d, ab, dbg);
   else hipLaunchKernelGGL((cgemm256_kernel<false>), grid, dim3(512), 0, st, d, ab, dbg);
   return true;
