@@ -48,10 +48,9 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 // 32 every A chunk from the zero page (no activation traffic)
 // BNB: the kRunBnBwd epilogue as its own instantiation - the kernel sits at the 256-register cap of two waves per SIMD, and with the
 // extra epilogue state in the one body the allocator spilled inside the K loop of EVERY launch (15x slower)
-// (dbg stays a run-time argument: with the switches folded to constants the allocator of this 256-register kernel spilled 236 instead of
-//  188 bytes and the step was 0.4 ms SLOWER - measured round 4, same box: 11.26 vs 10.87 ms)
-template <bool BNB>
-__global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const ArenaBases ab, const int dbg) {
+// (dbg is a template argument; only the switch values the tuning runs use are instantiated)
+template <bool BNB, int dbg = 0>
+__global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int KT = 64;                                     // K tile of the A operand and of the loop (two 32-deep B tiles)
   constexpr int A_SLOT = BM * 128, B_SLOT = BN * 64;        // 32 KB, 16 KB
@@ -440,8 +439,21 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int total = ((d.M + 255) / 256) * (d.Npad / 256);
   const dim3 grid(total < ncu ? total : ncu);
-  if (d.flags & kRunBnBwd) hipLaunchKernelGGL((cgemm256_kernel<true>), grid, dim3(512), 0, st, d, ab, dbg);
-  else hipLaunchKernelGGL((cgemm256_kernel<false>), grid, dim3(512), 0, st, d, ab, dbg);
+  const bool bnb = (d.flags & kRunBnBwd) != 0;
+#define SEFD_CG256_LAUNCH(DBG)                                                                                              \
+  do {                                                                                                                      \
+    if (bnb) hipLaunchKernelGGL((cgemm256_kernel<true, DBG>), grid, dim3(512), 0, st, d, ab);                               \
+    else hipLaunchKernelGGL((cgemm256_kernel<false, DBG>), grid, dim3(512), 0, st, d, ab);                                  \
+  } while (0)
+  switch (dbg) {
+    case 1: SEFD_CG256_LAUNCH(1); break;
+    case 2: SEFD_CG256_LAUNCH(2); break;
+    case 4: SEFD_CG256_LAUNCH(4); break;
+    case 8: SEFD_CG256_LAUNCH(8); break;
+    case 32: SEFD_CG256_LAUNCH(32); break;
+    default: SEFD_CG256_LAUNCH(0); break;
+  }
+#undef SEFD_CG256_LAUNCH
   return true;
 }
 
