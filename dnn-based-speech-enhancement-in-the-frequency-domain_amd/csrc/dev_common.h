@@ -166,6 +166,7 @@ void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);
 void launch_istft_fft(const IstftFft& d, const ArenaBases& ab, hipStream_t st);
 void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st);
+void launch_cbn(const Op& op, const ArenaBases& ab, hipStream_t st);       // ComplexBatchNorm (cbn.hip)
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);
 void launch_lstm_cluster(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);   // H > 128 (lstm_cluster.hip)
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);      // impl == 1 (lstm_rows.hip)

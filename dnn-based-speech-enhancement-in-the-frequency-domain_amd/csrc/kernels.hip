@@ -1027,6 +1027,8 @@ void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_BN_BWD_REDUCE:
     case OP_BN_BWD_APPLY:
       launch_bn(op, ab, st); break;
+    case OP_CBN_STATS: case OP_CBN_FINALIZE: case OP_CBN_APPLY: case OP_CBN_BWD_REDUCE: case OP_CBN_BWD_FINALIZE: case OP_CBN_BWD_APPLY:
+      launch_cbn(op, ab, st); break;
     case OP_BN_BWD_FINALIZE: {
       FinScratch fs; dim3 grid;
       if (fin_two_level(op.bnb.r.nblk, op.bnb.r.C, st, &fs, &grid))

@@ -541,17 +541,50 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
 
   // ------------------------------------------------------------------ parameters (reference registration order)
+  const bool cbn = cfg.use_cbn != 0;
+  if (cbn && cfg.bn_world > 1) { P->error = "ComplexBatchNorm has no SyncBN plan"; return P; }
+  // the normalisation + PReLU behind a conv: nn.BatchNorm2d(C) or ComplexBatchNorm(C) (tools_for_model.py:441-467: 5 parameters and 5 buffers of C / 2)
+  auto add_norm = [&](const std::string& p, int C) {
+    if (cbn) {
+      for (const char* w : {"Wrr", "Wri", "Wii", "Br", "Bi"}) b.add_param(p + ".1." + w, {C / 2}, true);
+      for (const char* w : {"RMr", "RMi", "RVrr", "RVri", "RVii"}) b.add_param(p + ".1." + w, {C / 2}, false);
+    } else {
+      b.add_param(p + ".1.weight", {C}, true);
+      b.add_param(p + ".1.bias", {C}, true);
+      b.add_param(p + ".1.running_mean", {C}, false);
+      b.add_param(p + ".1.running_var", {C}, false);
+    }
+    b.add_param(p + ".2.weight", {1}, true);
+  };
+  // forward of that layer: y [Rr][C] -> z
+  auto cbn_fwd = [&](int tag, const std::string& pp, const std::string& nm, Ptr y, Ptr z, int C, int64_t Rr) -> Ptr {
+    if ((C / 2) % 4 != 0) { P->error = "ComplexBatchNorm: channel pairs per layer must be a multiple of 4"; return b.none(); }
+    CbnFwd c;
+    std::memset(&c, 0, sizeof(c));
+    const int h = C / 2;
+    const int64_t rpbk = std::max<int64_t>(64, (Rr + 2047) / 2048);
+    c.y = y; c.z = z; c.R = Rr; c.C = C; c.dt = adt; c.nblk = (int)((Rr + rpbk - 1) / rpbk); c.rows_per_blk = (int)rpbk;
+    c.training = cfg.training; c.count = (double)Rr; c.eps = 1e-5f; c.momentum = 0.1f;
+    c.part = cfg.training ? b.ws(nm + ".cstat", (int64_t)c.nblk * 5 * h, DT_F32) : b.none();
+    c.coef = b.ws(nm + ".ccoef", 14 * h, DT_F32);
+    const char* wn[3] = {"Wrr", "Wri", "Wii"};
+    const char* rvn[3] = {"RVrr", "RVri", "RVii"};
+    for (int q = 0; q < 3; ++q) { c.W[q] = b.pptr(pp + ".1." + wn[q]); c.RV[q] = b.sptr(pp + ".1." + rvn[q]); }
+    c.Bv[0] = b.pptr(pp + ".1.Br"); c.Bv[1] = b.pptr(pp + ".1.Bi");
+    c.RM[0] = b.sptr(pp + ".1.RMr"); c.RM[1] = b.sptr(pp + ".1.RMi");
+    c.slope = b.pptr(pp + ".2.weight");
+    if (cfg.training) b.push(P->fwd, OP_CBN_STATS, tag).cbf = c;
+    b.push(P->fwd, OP_CBN_FINALIZE, tag).cbf = c;
+    b.push(P->fwd, OP_CBN_APPLY, tag).cbf = c;
+    return c.coef;
+  };
   for (int i = 0; i < n; ++i) {
     const std::string p = "encoder." + std::to_string(i);
     for (const char* part : {"real_conv", "imag_conv"}) {
       b.add_param(p + ".0." + part + ".weight", {ch[i + 1] / 2, ch[i] / 2, KS, 2}, true);
       b.add_param(p + ".0." + part + ".bias", {ch[i + 1] / 2}, true);
     }
-    b.add_param(p + ".1.weight", {ch[i + 1]}, true);
-    b.add_param(p + ".1.bias", {ch[i + 1]}, true);
-    b.add_param(p + ".1.running_mean", {ch[i + 1]}, false);
-    b.add_param(p + ".1.running_var", {ch[i + 1]}, false);
-    b.add_param(p + ".2.weight", {1}, true);
+    add_norm(p, ch[i + 1]);
   }
   for (int d = 0; d < n; ++d) {
     const int idx = n - d;
@@ -561,13 +594,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.add_param(p + ".0." + part + ".weight", {cin / 2, cout / 2, KS, 2}, true);
       b.add_param(p + ".0." + part + ".bias", {cout / 2}, true);
     }
-    if (idx != 1) {
-      b.add_param(p + ".1.weight", {cout}, true);
-      b.add_param(p + ".1.bias", {cout}, true);
-      b.add_param(p + ".1.running_mean", {cout}, false);
-      b.add_param(p + ".1.running_var", {cout}, false);
-      b.add_param(p + ".2.weight", {1}, true);
-    }
+    if (idx != 1) add_norm(p, cout);
   }
   const int hid = D * Cl;                    // LSTM feature size real+imag
   if (!cx) {                                  // nn.LSTM(hid, rnn_units, num_layers=2) then nn.Linear(rnn_units, hid)
@@ -612,7 +639,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // ------------------------------------------------------------------ constants: STFT bases, OLA normaliser
   // analysis basis (tools_for_model.py:16-33): K[part*NF+k][j] = w[j]*{cos,-sin}(2 pi k j / NFFT); periodic Hann
   std::vector<double> win(W);
-  for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  for (int j = 0; j < W; ++j) win[j] = cfg.window == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);    // win_type None: np.ones (tools_for_model.py:17-18)
   auto Kun = [&](int part, int k, int j) {
     const double ang = 2.0 * kPi * (double)(((int64_t)k * j) % NFFT) / NFFT;
     return part == 0 ? std::cos(ang) : -std::sin(ang);
@@ -727,16 +754,19 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     const int nblk = (int)((g.M + kBM - 1) / kBM);
     Ptr part = b.ws(nm + ".stat", (int64_t)nblk * 2 * g.Npad, DT_F32);
     g.y = ency[i]; g.y_bstride = (int64_t)T * Fo * Co; g.y_tstride = Fo * Co; g.y_fstride = Co; g.y_off = 0;
-    g.stats = cfg.training ? part : b.none();
+    g.stats = cfg.training && !cbn ? part : b.none();
     b.push(F, OP_RUNGEMM, 100 + i).g = g;
-    {
+    if (cbn) {
+      enc_mi[i] = cbn_fwd(100 + i, pp, nm, ency[i], encz[i], Co, Rr);       // the layer's coefficient table takes the place of (mean, invstd)
+      if (!P->error.empty()) return P;
+    } else {
       Op& op = b.push(F, OP_BN_FINALIZE, 100 + i);
       op.bnf.part = part; op.bnf.mean_invstd = enc_mi[i];
       op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
       op.bnf.nblk = cfg.training ? nblk : -1; op.bnf.C = Co; op.bnf.Cpad = g.Npad; op.bnf.count = (double)Rr;
       op.bnf.eps = 1e-5f; op.bnf.momentum = 0.1f;
     }
-    {
+    if (!cbn) {
       Op& op = b.push(F, OP_BN_APPLY, 100 + i);
       op.bna.y = ency[i]; op.bna.z = encz[i]; op.bna.mean_invstd = enc_mi[i];
       op.bna.gamma = b.pptr(pp + ".1.weight"); op.bna.beta = b.pptr(pp + ".1.bias"); op.bna.slope = b.pptr(pp + ".2.weight");
@@ -1111,7 +1141,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.pack_weights(F, g, coef, nm + ".p" + std::to_string(par), 400 + d, par == 0 ? &bias : nullptr);
       if (par == 1) g.bias = dec[d].f[0].bias;
       g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Cob; g.y_tstride = Fo * Cob; g.y_fstride = 2 * Cob; g.y_off = par * Cob;
-      if (!last && cfg.training) g.stats = b.mk(A_WS, part.off + (int64_t)par * nblk1 * 2 * g.Npad * 4);
+      if (!last && cfg.training && !cbn) g.stats = b.mk(A_WS, part.off + (int64_t)par * nblk1 * 2 * g.Npad * 4);
       b.push(F, OP_RUNGEMM, 400 + d).g = g;
       dec[d].f[par] = g; dec[d].coef[par] = coef;
     }
@@ -1131,7 +1161,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       std::function<void(int, int32_t*)> bias2 = [=](int nn, int32_t* o) { if (nn >= 2 * cob) { o[0] = o[1] = 0; } else bias(nn % cob, o); };
       b.pack_weights(F, g, coef, nm + ".pm", 400 + d, &bias2);
       g.y = decy[d]; g.y_bstride = (int64_t)(T + 1) * Fo * Cob; g.y_tstride = Fo * Cob; g.y_fstride = 2 * Cob; g.y_off = 0;
-      if (!last && cfg.training) {
+      if (!last && cfg.training && !cbn) {
         if ((int64_t)nblk1 * 2 * g.Npad > (int64_t)2 * nblk1 * 2 * npad_stat) { P->error = "merged sub-pixel GEMM: statistics pitch"; return P; }
         g.stats = part;
         fin_nblk = nblk1; fin_cpad = g.Npad; fin_nsub = 2;
@@ -1139,7 +1169,11 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       b.push(F, OP_RUNGEMM, 400 + d).g = g;
     }
     dec[d].bias = bias; dec[d].C = Co; dec[d].Fq = Fo; dec[d].R = Rr;
-    if (!last) {
+    if (!last && cbn) {
+      dec_mi[d] = cbn_fwd(400 + d, pp, nm, decy[d], decz[d], Co, Rr);
+      if (!P->error.empty()) return P;
+      dprev = DecSrc{decz[d], (int64_t)(T + 1) * Fo * Co, Fo * Co, Fo * Co, Co};
+    } else if (!last) {
       Op& op = b.push(F, OP_BN_FINALIZE, 400 + d);
       op.bnf.part = part; op.bnf.mean_invstd = dec_mi[d];
       op.bnf.running_mean = b.sptr(pp + ".1.running_mean"); op.bnf.running_var = b.sptr(pp + ".1.running_var");
@@ -1248,7 +1282,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // So by default only the layers whose producers all run on the wide-tile kernel are fused (bf16, C % 256 == 0).
     // SEFD_BN_FUSE=0: none; SEFD_BN_FUSE=2: every layer (the per-op tests run the epilogue of all three GEMM kernels that way).
     const int bn_fuse_mode = getenv("SEFD_BN_FUSE") ? atoi(getenv("SEFD_BN_FUSE")) : 1;
-    const bool bn_fuse = bn_fuse_mode != 0;
+    const bool bn_fuse = bn_fuse_mode != 0 && !cbn;
     auto bn_fuse_layer = [&](int C, int64_t Rr) { return bn_fuse_mode == 2 || (adt == DT_BF16 && C % 256 == 0 && Rr >= 8192); };
     struct BnbAcc { Ptr part; int rows = 0, cap = 0, ldp = 0; bool on = false; Ptr y, mi; std::string pp; };
     std::vector<BnbAcc> bnb_dec(n), bnb_enc(n);
@@ -1278,6 +1312,23 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
                       const std::string& nm, const BnbAcc* fused) {
       int64_t rpbk = std::max<int64_t>(64, (Rr + 2047) / 2048);
       const int nblk = (int)((Rr + rpbk - 1) / rpbk);
+      if (cbn) {                                  // `mi` is the layer's coefficient table (cbn_fwd)
+        const int h = C / 2;
+        CbnBwd c;
+        std::memset(&c, 0, sizeof(c));
+        c.y = y; c.dz0 = dz0; c.dz1 = dz1; c.dy = dy; c.coef = mi;
+        c.coefb = b.ws(nm + ".ccoefb", 9 * h, DT_F32);
+        c.part = b.ws(nm + ".cbnpart", (int64_t)nblk * 7 * h, DT_F32);
+        const char* wn[3] = {"Wrr", "Wri", "Wii"};
+        for (int q = 0; q < 3; ++q) { c.W[q] = b.pptr(pp + ".1." + wn[q]); c.dW[q] = b.pptr(pp + ".1." + wn[q], A_GRAD); }
+        c.dB[0] = b.pptr(pp + ".1.Br", A_GRAD); c.dB[1] = b.pptr(pp + ".1.Bi", A_GRAD);
+        c.slope = b.pptr(pp + ".2.weight"); c.dslope = b.pptr(pp + ".2.weight", A_GRAD);
+        c.R = Rr; c.rpb = rpb; c.C = C; c.dt = adt; c.nblk = nblk; c.rows_per_blk = (int)rpbk; c.skip = skip; c.count = (double)Rr;
+        b.push(R, OP_CBN_BWD_REDUCE, tag).cbb = c;
+        b.push(R, OP_CBN_BWD_FINALIZE, tag).cbb = c;
+        b.push(R, OP_CBN_BWD_APPLY, tag).cbb = c;
+        return;
+      }
       BnBwdReduce r;
       std::memset(&r, 0, sizeof(r));
       r.y = y; r.dz0 = dz0; r.dz1 = dz1; r.mean_invstd = mi;
@@ -1851,7 +1902,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   Ptr io_tgt = b.io("tgt", (int64_t)B * L);
 
   std::vector<double> win(W);
-  for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  for (int j = 0; j < W; ++j) win[j] = cfg.window == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);    // win_type None: np.ones (tools_for_model.py:17-18)
   auto Kun = [&](int part, int k, int j) {
     const double ang = 2.0 * kPi * (double)(((int64_t)k * j) % NFFT) / NFFT;
     return part == 0 ? std::cos(ang) : -std::sin(ang);
@@ -2334,7 +2385,7 @@ Plan* build_frontend_plan(const ModelConfig& cfg) {
   Ptr io_or = b.io("out_real", (int64_t)B * NF * T);
   Ptr io_oi = b.io("out_imag", (int64_t)B * NF * T);
   std::vector<double> win(W);
-  for (int j = 0; j < W; ++j) win[j] = 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);
+  for (int j = 0; j < W; ++j) win[j] = cfg.window == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);    // win_type None: np.ones (tools_for_model.py:17-18)
   Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
   if (!b.stft_fft(P->fwd, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win)) {
   RunGemm g = Builder::gemm0();

@@ -23,6 +23,8 @@ struct ModelConfig {
   int32_t training;         // 1: BatchNorm batch statistics + running update ; 0: eval (running stats)
   int32_t bn_world;         // > 1: SyncBN over that many ranks (sync points, counts scaled)
   int32_t grad_buckets;     // 2: decoder + LSTM gradients unpacked before the encoder backward (DDP overlap)
+  int32_t use_cbn;          // DCCRN: ComplexBatchNorm instead of BatchNorm2d
+  int32_t window;           // 0 periodic Hann, 1 rectangular (ConvSTFT win_type None)
 };
 
 struct ParamInfo {

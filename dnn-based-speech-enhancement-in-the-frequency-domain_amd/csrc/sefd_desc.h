@@ -166,6 +166,30 @@ struct BnBwdApply {            // FINALIZE: partials -> totals [3][C] + paramete
   double count;
 };
 
+// ComplexBatchNorm (tools_for_model.py:430-607; DCCRN(use_cbn=True)) + PReLU on channels-last rows [R][C]: channel k < h = C / 2 is the real part and
+// channel k + h the imaginary part of complex channel k.  Statistics (2 means, 3 covariances per complex channel) come from a pass of their own
+// (the GEMM epilogues give per-column sums, not the real x imaginary cross term); everything downstream is a per-complex-channel 2 x 2 affine map.
+//   coef  fp32 [14][h]: Zrr Zri Zir Zii | br' bi' (y = Z x + b', b' = B - Z M) | Mr Mi | Urr Uri Uii (V^-1/2) | Vrr+eps Vri Vii+eps (backward finalize)
+//   coefb fp32 [9][h]:  Zrr Zri Zir Zii | mean(dbn_r) mean(dbn_i) | 2 dVrr / N, dVri / N, 2 dVii / N
+struct CbnFwd {                // OP_CBN_STATS (y -> part), OP_CBN_FINALIZE (part -> coef, running statistics), OP_CBN_APPLY (y, coef -> z)
+  Ptr y, z, part, coef;        // part fp32 [nblk][5][h]: sum xr, sum xi, sum xr^2, sum xi^2, sum xr xi
+  Ptr W[3], Bv[2], slope;      // Wrr Wri Wii, Br Bi (A_PARAM), PReLU slope
+  Ptr RM[2], RV[3];            // RMr RMi, RVrr RVri RVii (A_STATE)
+  int64_t R;
+  int32_t C, dt, nblk, rows_per_blk, training, pad_;
+  double count;
+  float eps, momentum;
+};
+struct CbnBwd {                // OP_CBN_BWD_REDUCE (-> part), OP_CBN_BWD_FINALIZE (part -> coefb, parameter gradients), OP_CBN_BWD_APPLY (-> dy)
+  Ptr y, dz0, dz1, dy;         // dz0 / dz1 / rpb / skip as in BnBwdReduce
+  Ptr coef, coefb, part;       // part fp32 [nblk][7][h]: sum dbr, dbi, dbr x~r, dbr x~i, dbi x~r, dbi x~i, slope-gradient share (dbn = PReLU'(bn) dz, x~ = x - M)
+  Ptr W[3], slope;
+  Ptr dW[3], dB[2], dslope;    // A_GRAD
+  int64_t R, rpb;
+  int32_t C, dt, nblk, rows_per_blk, skip, pad_;
+  double count;
+};
+
 // LSTM recurrence (input GEMM hoisted).  G independent groups, group g uses weight set g % nset.
 // gx   [G][B][T][4H] fp32 gate pre-activations from the input GEMM (bias included), PyTorch gate order i,f,g,o
 // whh  [nset][4H][H]  (param arena, fp32, reference layout weight_hh_l0)
@@ -371,6 +395,7 @@ enum OpKind : int32_t {
   OP_PACKMULTI,
   OP_ISTFT_FFT,
   OP_FSN_NORMSTAT, OP_FSN_NORMBWD,   // cfg.norm_type other than offline_laplace_norm (struct Fsn)
+  OP_CBN_STATS, OP_CBN_FINALIZE, OP_CBN_APPLY, OP_CBN_BWD_REDUCE, OP_CBN_BWD_FINALIZE, OP_CBN_BWD_APPLY,   // ComplexBatchNorm (CbnFwd / CbnBwd)
 };
 
 constexpr int kOpHold = 2;     // Op::join of a lane-1 op
@@ -408,6 +433,8 @@ struct Op {
     StftFft fft;
     IstftFft ifft;
     PackMulti packm;
+    CbnFwd cbf;
+    CbnBwd cbb;
   };
 };
 

@@ -68,6 +68,31 @@ class ComplexConvTranspose2d(nn.Module):
             nn.init.constant_(c.bias, 0.)
 
 
+class ComplexBatchNorm(nn.Module):
+    """Parameter / buffer holder of the reference's ComplexBatchNorm (tools_for_model.py:430-480): Wrr, Wri, Wii, Br, Bi and the running
+    RMr, RMi, RVrr, RVri, RVii over num_features // 2 complex channels; `reset_parameters` as there (Wri ~ U(-0.9, 0.9)).  The arithmetic is
+    csrc/cbn.hip."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features // 2, eps, momentum
+        h = self.num_features
+        for name in ("Wrr", "Wri", "Wii", "Br", "Bi"):
+            setattr(self, name, nn.Parameter(torch.empty(h)))
+        self.register_buffer("RMr", torch.zeros(h))
+        self.register_buffer("RMi", torch.zeros(h))
+        self.register_buffer("RVrr", torch.ones(h))
+        self.register_buffer("RVri", torch.zeros(h))
+        self.register_buffer("RVii", torch.ones(h))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        with torch.no_grad():
+            self.Br.zero_()
+            self.Bi.zero_()
+            self.Wrr.fill_(1)
+            self.Wri.uniform_(-.9, +.9)
+            self.Wii.fill_(1)
+
+
 class NavieComplexLSTM(nn.Module):
     """Parameter holder (tools_for_model.py:141-160)."""
 
@@ -153,10 +178,8 @@ class _SefdModule(nn.Module):
         ref = weakref.ref(self)
         for p in self.parameters():              # lets sefd_amd.optim.Adam(model.parameters()) find the model (optim.py)
             p._sefd_owner = ref
-        if getattr(self, "win_type", "hanning") not in ("hanning", "hann"):
-            # the kernels window with the periodic Hann of cfg.window = 'hanning' (config.py:61); a rectangular-window module
-            # (win_type None) would register buffers the computation does not use
-            raise NotImplementedError(f"win_type {self.win_type!r}: only the Hann window ('hanning') is on the HIP path")
+        if getattr(self, "win_type", "hanning") not in ("hanning", "hann", None, "None"):
+            raise NotImplementedError(f"win_type {self.win_type!r}: the HIP path has the periodic Hann window ('hanning') and the rectangular one (None)")
 
     def flatten_parameters(self):
         pass
@@ -165,7 +188,7 @@ class _SefdModule(nn.Module):
         return [(n, p) for n, p in self.named_parameters()]
 
     def _bn_buffers(self):
-        return [(n, b) for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var"))]
+        return [(n, b) for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var", ".RMr", ".RMi", ".RVrr", ".RVri", ".RVii"))]
 
     def _flat_ok(self, device):
         fp = self._flat_param
@@ -339,8 +362,8 @@ class DCCRN(_SefdModule):
     def __init__(self, rnn_layers=cfg.rnn_layers, rnn_units=cfg.rnn_units, win_len=cfg.win_len, win_inc=cfg.win_inc,
                  fft_len=cfg.fft_len, win_type=cfg.window, masking_mode=cfg.masking_mode, use_cbn=False, kernel_size=5):
         super().__init__()
-        if use_cbn:
-            raise NotImplementedError("ComplexBatchNorm (use_cbn=True) is not on the HIP path")
+        self.use_cbn = bool(use_cbn)
+        norm = ComplexBatchNorm if use_cbn else nn.BatchNorm2d         # models.py:76, 120
         self.win_len, self.win_inc, self.fft_len, self.win_type = win_len, win_inc, fft_len, win_type
         self.rnn_units = rnn_units
         self.input_dim = self.output_dim = win_len
@@ -360,7 +383,7 @@ class DCCRN(_SefdModule):
         for idx in range(len(kn) - 1):
             self.encoder.append(nn.Sequential(
                 ComplexConv2d(kn[idx], kn[idx + 1], kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 1)),
-                nn.BatchNorm2d(kn[idx + 1]), nn.PReLU()))
+                norm(kn[idx + 1]), nn.PReLU()))
         hidden_dim = fft_len // (2 ** len(kn))
         if cfg.lstm == 'complex':
             rnns = []
@@ -378,7 +401,7 @@ class DCCRN(_SefdModule):
             mods = [ComplexConvTranspose2d(kn[idx] * mult, kn[idx - 1], kernel_size=(kernel_size, 2), stride=(2, 1),
                                            padding=(2, 0), output_padding=(1, 0))]
             if idx != 1:
-                mods += [nn.BatchNorm2d(kn[idx - 1]), nn.PReLU()]
+                mods += [norm(kn[idx - 1]), nn.PReLU()]
             self.decoder.append(nn.Sequential(*mods))
         # state_dict order of the reference: stft, istft, encoder, decoder, enhance
         enh = self._modules.pop('enhance')
@@ -391,7 +414,7 @@ class DCCRN(_SefdModule):
         return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=self.hidden_layers, rnn_units=self.rnn_units,
                     win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, masking_mode=self.masking_mode,
                     lstm=self._lstm_kind, skip_type=self._skip, act_dtype=self.act_dtype, training=training, model="DCCRN",
-                    bn_world=getattr(self, "_bn_world", 1), grad_buckets=getattr(self, "_grad_buckets", 1))
+                    bn_world=getattr(self, "_bn_world", 1), grad_buckets=getattr(self, "_grad_buckets", 1), use_cbn=self.use_cbn, win_type=self.win_type)
 
     # ---- reference surface ----------------------------------------------------------------------------------
     def forward(self, inputs, targets=0):
@@ -487,7 +510,9 @@ class CRN(_SefdModule):
         self.enhance = nn.LSTM(input_size=rnn_input_size, hidden_size=self.rnn_units, dropout=0.0, bidirectional=False, batch_first=False)
         self.tranform = nn.Linear(self.rnn_units, rnn_input_size)
         if not cfg.skip_type:
-            raise NotImplementedError("CRN without skip connections uses full-width nn.ConvTranspose2d in the reference: not on the HIP path")
+            # the reference's own forward fails there: its full-width decoder (models.py:432-462) expects kernel_num[idx] input channels but is fed
+            # kernel_num[idx] // 2 ("expected input[1, 128, 4, 43] to have 256 channels", checked in the build container) - nothing to mirror
+            raise NotImplementedError("CRN with cfg.skip_type = False: the reference's own forward raises a channel mismatch (models.py:432-462, 490-493)")
         for idx in range(len(kn) - 1, 0, -1):
             mods = [RealConvTranspose2d(kn[idx], kn[idx - 1] // 2, kernel_size=(kernel_size, 2), stride=(2, 1), padding=(2, 0),
                                         output_padding=(1, 0))]
@@ -504,7 +529,7 @@ class CRN(_SefdModule):
         mode = self.masking_mode if self.masking_mode == 'Direct(None make)' else "E"
         return Plan(B, L, kernel_num=tuple(self.kernel_num[1:]), rnn_layers=1, rnn_units=2 * self.rnn_units, win_len=self.win_len,
                     win_inc=self.win_inc, fft_len=self.fft_len, masking_mode=mode, lstm="real", skip_type=self._skip,
-                    act_dtype=self.act_dtype, training=training, model="CRN", bn_world=getattr(self, "_bn_world", 1))
+                    act_dtype=self.act_dtype, training=training, model="CRN", bn_world=getattr(self, "_bn_world", 1), win_type=self.win_type)
 
     def forward(self, inputs, targets=0):
         """models.py:467-532: returns (est_mags, target_mags, out_wav).  est_mags (the network's magnitude output: mask x noisy
@@ -543,6 +568,20 @@ class SequenceModel(nn.Module):
         self.output_activate_function = output_activate_function
 
 
+def _weight_init(m):
+    """BaseModel.weight_init (tools_for_model.py:1120-1184) for the module types a FullSubNet holds: Linear -> xavier_normal_ weight, normal_ bias;
+    LSTM / GRU -> orthogonal_ matrices, normal_ vectors.  `Module.apply` visits children first, as the reference's call does: same draws in the same order."""
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_normal_(m.weight.data)
+        nn.init.normal_(m.bias.data)
+    elif isinstance(m, (nn.LSTM, nn.GRU)):
+        for param in m.parameters():
+            if len(param.shape) >= 2:
+                nn.init.orthogonal_(param.data)
+            else:
+                nn.init.normal_(param.data)
+
+
 class _FSNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, rt, noisy_mag, *params):
@@ -579,8 +618,6 @@ class FullSubNet(_SefdModule):
         from .plan import FSN_NORMS
         if norm_type not in FSN_NORMS:                # norm_wrapper (tools_for_model.py:1106-1118)
             raise NotImplementedError("You must set up a type of Norm. e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
-        if weight_init:
-            raise NotImplementedError("weight_init=True is not mirrored (config.py default is False)")
         self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model, fb_output_activate_function)
         self.sb_model = SequenceModel((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), 2, sb_model_hidden_size, 2, False,
                                       sequence_model, sb_output_activate_function)
@@ -588,6 +625,8 @@ class FullSubNet(_SefdModule):
         self._fsn = dict(sb_num_neighbors=sb_num_neighbors, fb_num_neighbors=fb_num_neighbors, look_ahead=look_ahead,
                          fb_hidden=fb_model_hidden_size, sb_hidden=sb_model_hidden_size, fb_act=fb_output_activate_function,
                          sb_act=sb_output_activate_function, sequence_model=sequence_model, norm_type=norm_type)
+        if weight_init:                              # models.py:623-624: self.apply(self.weight_init)
+            self.apply(_weight_init)
         self.dropout_keep = 0.2                      # nn.LSTM(dropout=0.8); tests set 1.0 to compare with the dropout-free goldens
         self.masking_mode, self.act_dtype = "cIRM", cfg.act_dtype
         self._init_runtime_state()

@@ -20,7 +20,7 @@ FSN_NORMS = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_g
 class Plan:
     def __init__(self, B, L, kernel_num=(32, 64, 128, 256, 256, 256), rnn_layers=2, rnn_units=256, win_len=400,
                  win_inc=100, fft_len=512, masking_mode="E", lstm="complex", skip_type=True, act_dtype="fp32",
-                 kernel_size=5, training=True, model="DCCRN", fsn=None, bn_world=1, grad_buckets=1):
+                 kernel_size=5, training=True, model="DCCRN", fsn=None, bn_world=1, grad_buckets=1, use_cbn=False, win_type="hanning"):
         self.lib = _lib.lib()
         if masking_mode not in MASK_MODES:
             raise NotImplementedError(f"masking_mode {masking_mode!r} is not on the HIP path yet")
@@ -50,6 +50,10 @@ class Plan:
         cfg.training = 1 if training else 0
         cfg.bn_world = int(bn_world)
         cfg.grad_buckets = int(grad_buckets)
+        cfg.use_cbn = 1 if use_cbn else 0
+        if win_type not in (None, "None", "hanning", "hann"):
+            raise NotImplementedError(f"window {win_type!r}: the HIP path has the periodic Hann window and the rectangular one (win_type None)")
+        cfg.window = 1 if win_type in (None, "None") else 0
         self.cfg = cfg
         self.model_name = model
         self.masking_mode = masking_mode

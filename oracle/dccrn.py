@@ -31,6 +31,8 @@ class DCCRNConfig:
     lstm: str = "complex"
     skip_type: bool = True
     kernel_size: int = 5
+    win_type: object = "hanning"  # ConvSTFT / ConviSTFT window: 'hanning' (cfg.window) or None = rectangular (tools_for_model.py:17-18)
+    use_cbn: bool = False        # DCCRN(use_cbn=True): ComplexBatchNorm (tools_for_model.py:430-607) instead of nn.BatchNorm2d
 
     @property
     def chans(self):
@@ -39,6 +41,17 @@ class DCCRNConfig:
     @property
     def hidden_dim(self):
         return self.fft_len // (2 ** (len(self.kernel_num) + 1))
+
+
+CBN_PARAMS = ("Wrr", "Wri", "Wii", "Br", "Bi")
+CBN_BUFFERS = ("RMr", "RMi", "RVrr", "RVri", "RVii")
+
+
+def _norm_leaves(cfg, C):
+    """(leaf, shape) of the normalisation behind a conv, registration order (BatchNorm2d, or ComplexBatchNorm tools_for_model.py:441-467)."""
+    if cfg.use_cbn:
+        return [(leaf, (C // 2,)) for leaf in CBN_PARAMS + CBN_BUFFERS]
+    return [(leaf, (C,)) for leaf in ("weight", "bias", "running_mean", "running_var")]
 
 
 def dccrn_state_shapes(cfg: DCCRNConfig) -> "OrderedDict[str, tuple]":
@@ -55,8 +68,8 @@ def dccrn_state_shapes(cfg: DCCRNConfig) -> "OrderedDict[str, tuple]":
         for part in ("real_conv", "imag_conv"):
             s[f"encoder.{i}.0.{part}.weight"] = (co, ci, cfg.kernel_size, 2)
             s[f"encoder.{i}.0.{part}.bias"] = (co,)
-        for leaf in ("weight", "bias", "running_mean", "running_var"):
-            s[f"encoder.{i}.1.{leaf}"] = (ch[i + 1],)
+        for leaf, shp in _norm_leaves(cfg, ch[i + 1]):
+            s[f"encoder.{i}.1.{leaf}"] = shp
         s[f"encoder.{i}.1.num_batches_tracked"] = ()
         s[f"encoder.{i}.2.weight"] = (1,)
     # registration order in DCCRN.__init__: encoder and decoder ModuleLists exist before `enhance` is assigned
@@ -68,8 +81,8 @@ def dccrn_state_shapes(cfg: DCCRNConfig) -> "OrderedDict[str, tuple]":
             s[f"decoder.{d}.0.{part}.weight"] = (cin // 2, cout // 2, cfg.kernel_size, 2)
             s[f"decoder.{d}.0.{part}.bias"] = (cout // 2,)
         if idx != 1:
-            for leaf in ("weight", "bias", "running_mean", "running_var"):
-                s[f"decoder.{d}.1.{leaf}"] = (cout,)
+            for leaf, shp in _norm_leaves(cfg, cout):
+                s[f"decoder.{d}.1.{leaf}"] = shp
             s[f"decoder.{d}.1.num_batches_tracked"] = ()
             s[f"decoder.{d}.2.weight"] = (1,)
     hid = cfg.hidden_dim * ch[-1]
@@ -99,7 +112,7 @@ def dccrn_state_shapes(cfg: DCCRNConfig) -> "OrderedDict[str, tuple]":
     return s
 
 
-BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked") + CBN_BUFFERS
 
 
 def is_trainable(name: str) -> bool:
@@ -149,6 +162,39 @@ def batch_norm_train(x, w, b, rm, rv, eps=1e-5, momentum=0.1):
 def batch_norm_eval(x, w, b, rm, rv, eps=1e-5):
     y = (x - rm[None, :, None, None]) / torch.sqrt(rv[None, :, None, None] + eps)
     return y * w[None, :, None, None] + b[None, :, None, None]
+
+
+def complex_batch_norm(x, P, pfx, train, eps=1e-5, momentum=0.1):
+    """ComplexBatchNorm.forward (tools_for_model.py:487-601) on NCHW x = [real C/2 | imag C/2]; returns (y, new running statistics or {}).
+    Whitening by the inverse square root of the per-channel 2 x 2 covariance (closed form), then y = W U (x - M) + B."""
+    xr, xi = torch.chunk(x, 2, dim=1)
+    v = lambda t: t.view(1, -1, 1, 1)
+    new = {}
+    if train:
+        Mr, Mi = xr.mean((0, 2, 3), keepdim=True), xi.mean((0, 2, 3), keepdim=True)
+    else:
+        Mr, Mi = v(P[pfx + ".RMr"]), v(P[pfx + ".RMi"])
+    xr, xi = xr - Mr, xi - Mi
+    if train:
+        Vrr, Vri, Vii = (xr * xr).mean((0, 2, 3), keepdim=True), (xr * xi).mean((0, 2, 3), keepdim=True), (xi * xi).mean((0, 2, 3), keepdim=True)
+        with torch.no_grad():                     # Tensor.lerp_(batch value, momentum); covariance biased and WITHOUT eps (lines 541-556)
+            for leaf, val in (("RMr", Mr), ("RMi", Mi), ("RVrr", Vrr), ("RVri", Vri), ("RVii", Vii)):
+                old = P[pfx + "." + leaf]
+                new[pfx + "." + leaf] = old + momentum * (val.detach().reshape(-1) - old)
+    else:
+        Vrr, Vri, Vii = v(P[pfx + ".RVrr"]), v(P[pfx + ".RVri"]), v(P[pfx + ".RVii"])
+    Vrr, Vii = Vrr + eps, Vii + eps
+    tau, delta = Vrr + Vii, Vrr * Vii - Vri * Vri
+    s = delta.sqrt()
+    t = (tau + 2 * s).sqrt()
+    rst = (s * t).reciprocal()
+    Urr, Uii, Uri = (s + Vii) * rst, (s + Vrr) * rst, -Vri * rst
+    Wrr, Wri, Wii = v(P[pfx + ".Wrr"]), v(P[pfx + ".Wri"]), v(P[pfx + ".Wii"])
+    Zrr, Zri = Wrr * Urr + Wri * Uri, Wrr * Uri + Wri * Uii
+    Zir, Zii = Wri * Urr + Wii * Uri, Wri * Uri + Wii * Uii
+    yr = Zrr * xr + Zri * xi + v(P[pfx + ".Br"])
+    yi = Zir * xr + Zii * xi + v(P[pfx + ".Bi"])
+    return torch.cat([yr, yi], 1), new
 
 
 def prelu(x, a):
@@ -226,13 +272,17 @@ def dccrn_forward(P, inputs, cfg: DCCRNConfig, targets=None, train=True, taps=No
     """
     nfreq = cfg.fft_len // 2 + 1
     new_stats = {}
-    specs = conv_stft(inputs, cfg.win_len, cfg.win_inc, cfg.fft_len)
+    specs = conv_stft(inputs, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.win_type)
     real, imag = specs[:, :nfreq], specs[:, nfreq:]
     out = torch.stack([real, imag], 1)[:, :, 1:]
     if taps is not None:
         taps["spec"] = specs
 
     def bn(x, pfx):
+        if cfg.use_cbn:
+            y, nst = complex_batch_norm(x, P, pfx, train)
+            new_stats.update(nst)
+            return y
         if train:
             y, nrm, nrv = batch_norm_train(x, P[pfx + ".weight"], P[pfx + ".bias"],
                                            P[pfx + ".running_mean"], P[pfx + ".running_var"])
@@ -291,10 +341,10 @@ def dccrn_forward(P, inputs, cfg: DCCRNConfig, targets=None, train=True, taps=No
     m_r = F.pad(out[:, 0], [0, 0, 1, 0])
     m_i = F.pad(out[:, 1], [0, 0, 1, 0])
     if cfg.masking_mode == "Direct(None make)":
-        tspec = conv_stft(targets, cfg.win_len, cfg.win_inc, cfg.fft_len)
-        wav = conv_istft(torch.cat([m_r, m_i], 1), cfg.win_len, cfg.win_inc, cfg.fft_len).squeeze(1).clamp(-1, 1)
+        tspec = conv_stft(targets, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.win_type)
+        wav = conv_istft(torch.cat([m_r, m_i], 1), cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.win_type).squeeze(1).clamp(-1, 1)
         return (m_r, tspec[:, :nfreq], m_i, tspec[:, nfreq:], wav), new_stats
     o_r, o_i = apply_mask(cfg.masking_mode, real, imag, m_r, m_i)
-    wav = conv_istft(torch.cat([o_r, o_i], 1), cfg.win_len, cfg.win_inc, cfg.fft_len).squeeze(1)
+    wav = conv_istft(torch.cat([o_r, o_i], 1), cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.win_type).squeeze(1)
     wav = torch.clamp(wav, -1, 1)
     return (o_r, o_i, wav), new_stats

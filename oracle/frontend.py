@@ -17,34 +17,39 @@ def periodic_hann(win_len: int) -> np.ndarray:
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_len)
 
 
-def analysis_kernel(win_len=400, fft_len=512, window=True) -> np.ndarray:
+def window_of(win_len: int, win_type="hanning") -> np.ndarray:
+    """init_kernels' window (tools_for_model.py:17-20): np.ones for win_type None / 'None', else scipy's periodic window."""
+    return np.ones(win_len) if win_type in (None, "None") else periodic_hann(win_len)
+
+
+def analysis_kernel(win_len=400, fft_len=512, window=True, win_type="hanning") -> np.ndarray:
     """K[2*(N/2+1), win_len] float64: rows 0..N/2 = w*cos, rows N/2+1.. = -w*sin (tools_for_model.py:22-26,31)."""
     n = np.arange(win_len, dtype=np.float64)[None, :]
     k = np.arange(fft_len // 2 + 1, dtype=np.float64)[:, None]
     ang = 2.0 * np.pi * k * n / fft_len
     K = np.concatenate([np.cos(ang), -np.sin(ang)], 0)
     if window:
-        K = K * periodic_hann(win_len)[None, :]
+        K = K * window_of(win_len, win_type)[None, :]
     return K
 
 
-def synthesis_kernel(win_len=400, fft_len=512) -> np.ndarray:
+def synthesis_kernel(win_len=400, fft_len=512, win_type="hanning") -> np.ndarray:
     """pinv(K_unwindowed).T * w  (tools_for_model.py:28-31)."""
     K = analysis_kernel(win_len, fft_len, window=False)
-    return np.linalg.pinv(K).T * periodic_hann(win_len)[None, :]
+    return np.linalg.pinv(K).T * window_of(win_len, win_type)[None, :]
 
 
-def conv_stft(wav: torch.Tensor, win_len=400, hop=100, fft_len=512) -> torch.Tensor:
+def conv_stft(wav: torch.Tensor, win_len=400, hop=100, fft_len=512, win_type="hanning") -> torch.Tensor:
     """[B, L] -> [B, 2*(N/2+1), T] (real rows then imag rows)."""
-    K = torch.from_numpy(analysis_kernel(win_len, fft_len).astype(np.float32))[:, None, :]
+    K = torch.from_numpy(analysis_kernel(win_len, fft_len, win_type=win_type).astype(np.float32))[:, None, :]
     x = F.pad(wav[:, None, :], [win_len - hop, win_len - hop])
     return F.conv1d(x, K, stride=hop)
 
 
-def conv_istft(spec: torch.Tensor, win_len=400, hop=100, fft_len=512) -> torch.Tensor:
+def conv_istft(spec: torch.Tensor, win_len=400, hop=100, fft_len=512, win_type="hanning") -> torch.Tensor:
     """[B, 2*(N/2+1), T] -> [B, 1, L]."""
-    Kinv = torch.from_numpy(synthesis_kernel(win_len, fft_len).astype(np.float32))[:, None, :]
-    w = torch.from_numpy(periodic_hann(win_len).astype(np.float32))[None, :, None]
+    Kinv = torch.from_numpy(synthesis_kernel(win_len, fft_len, win_type).astype(np.float32))[:, None, :]
+    w = torch.from_numpy(window_of(win_len, win_type).astype(np.float32))[None, :, None]
     out = F.conv_transpose1d(spec, Kinv, stride=hop)
     t = w.repeat(1, 1, spec.size(-1)) ** 2
     coff = F.conv_transpose1d(t, torch.eye(win_len)[:, None, :], stride=hop)

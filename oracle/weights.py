@@ -34,7 +34,17 @@ def formula_tensor(name: str, index: int, shape) -> torch.Tensor | None:
     in_block = parts[0] in ("encoder", "decoder") and len(parts) == 4
     is_bn = in_block and parts[2] == "1"
     is_prelu = in_block and parts[2] == "2"
-    if leaf == "running_var":
+    if is_bn and leaf in ("Wrr", "Wii"):                          # ComplexBatchNorm (use_cbn=True): W and the running covariance stay positive definite
+        v = 1.0 + 0.1 * u
+    elif is_bn and leaf == "Wri":
+        v = 0.3 * u
+    elif is_bn and leaf in ("Br", "Bi", "RMr", "RMi"):
+        v = 0.01 * u
+    elif is_bn and leaf in ("RVrr", "RVii"):
+        v = 1.0 + 0.1 * u * u
+    elif is_bn and leaf == "RVri":
+        v = 0.05 * u
+    elif leaf == "running_var":
         v = 1.0 + 0.1 * u * u
     elif leaf == "running_mean":
         v = 0.01 * u

@@ -67,11 +67,12 @@ def flat(d, prefix):
 
 
 SMALL_PARAMS = lambda name: (name.startswith("encoder.0.0.") or name.endswith(".2.weight") or ".1.weight" in name
-                             or ".1.bias" in name or name.endswith("r_trans.bias") or name.endswith("i_trans.bias")
+                             or ".1.bias" in name or ".1.W" in name or ".1.B" in name or name.endswith("r_trans.bias") or name.endswith("i_trans.bias")
                              or name.startswith("decoder.5.0.") or name.endswith("bias_hh_l0"))
 
 
-def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True, lstm="complex", skip=True, gstride=53, scale=1.0):
+def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual, B, L, store_taps=True, lstm="complex", skip=True, gstride=53, scale=1.0,
+               use_cbn=False, win_type="hann"):
     cfg.dccrn_kernel_num = list(kernel_num)
     cfg.masking_mode = mask
     cfg.loss = loss
@@ -79,7 +80,7 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
     cfg.lstm = lstm
     cfg.skip_type = skip
     torch.manual_seed(0)
-    m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask)
+    m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask, use_cbn=use_cbn, win_type=win_type)
     cfg.skip_type = True            # read at construction AND in forward (models.py:107, 222): restored after the forward below
     fill_state_dict_(m)
     m.train()
@@ -121,7 +122,7 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
     opt.step()
     sd = m.state_dict()
     rec = dict(
-        meta=dict(B=B, L=L, kernel_num=np.array(kernel_num), rnn_units=rnn_units, skip=int(skip), gstride=gstride, scale=float(scale),
+        meta=dict(B=B, L=L, kernel_num=np.array(kernel_num), rnn_units=rnn_units, skip=int(skip), gstride=gstride, scale=float(scale), use_cbn=int(use_cbn), rect_window=int(win_type is None),
                   mask=np.array(mask), loss=np.array(loss), perceptual=np.array(str(perceptual))),
         out_real=o_r.detach().numpy(), out_imag=o_i.detach().numpy(), out_wav=wav.detach().numpy(),
         loss=float(lossv), main_loss=float(main), perc_loss=float(perc),
@@ -130,7 +131,7 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
         grad={k: v.numpy() for k, v in g.items() if SMALL_PARAMS(k)},
         grad_samp={k: sample(v, gstride)["samp"] for k, v in g.items() if not SMALL_PARAMS(k)},
         after_adam={k: sd[k].numpy().copy() for k in g if SMALL_PARAMS(k)},
-        running={k: v.numpy().copy() for k, v in sd.items() if "running_" in k},
+        running={k: v.numpy().copy() for k, v in sd.items() if "running_" in k or ".1.RM" in k or ".1.RV" in k},
     )
     np.savez_compressed(os.path.join(HERE, f"dccrn_{name}.npz"), **flat(rec, "g"))
     print(f"dccrn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
@@ -246,6 +247,19 @@ def fsn_losses(cfg, models, tfm):
     fsn_case(cfg, models, tfm, "small_sisdr", 2, 6000, hidden=(128, 64), loss="SI-SDR")
 
 
+def fsn_weight_init(cfg, models):
+    """FullSubNet(weight_init=True) (models.py:623-624, tools_for_model.py:1120-1184): a digest of every parameter after construction under seed 0."""
+    rec = {}
+    for seq in ("LSTM", "GRU"):
+        torch.manual_seed(0)
+        m = models.FullSubNet(fb_model_hidden_size=64, sb_model_hidden_size=32, sequence_model=seq, weight_init=True)
+        for k, p in m.named_parameters():
+            v = p.detach().double().reshape(-1)
+            rec[f"{seq}/{k}"] = np.array([float(v.sum()), float(v.abs().sum())] + [float(t) for t in v[:6]])
+    np.savez_compressed(os.path.join(HERE, "fsn_weight_init.npz"), **flat(rec, "g"))
+    print("fsn_weight_init:", len(rec), "tensors")
+
+
 def fsn_variants(cfg, models, tfm):
     fsn_case(cfg, models, tfm, "small_gru_mse", 2, 6000, hidden=(128, 64), sequence_model="GRU")
     fsn_case(cfg, models, tfm, "small_cumlaplace_mse", 2, 6000, hidden=(128, 64), norm_type="cumulative_laplace_norm")
@@ -311,7 +325,7 @@ def frontend_and_losses(cfg, models, tfm, tfl):
     print("frontend_losses: q4", out["q4"], "lms", out["lms_loss"])
 
 
-def dccrn_eval_case(cfg, models, name, kernel_num, rnn_units, mask, loss, B, L, Bv, Lv):
+def dccrn_eval_case(cfg, models, name, kernel_num, rnn_units, mask, loss, B, L, Bv, Lv, use_cbn=False):
     """Validation path (trainer.py:188-241 `model_validate` minus the PESQ/STOI scorers): one training-mode forward, then
     `model.eval()` + `torch.no_grad()` forward and loss on a different batch - BatchNorm uses the UPDATED running
     statistics, so this pins the eval plans and the running-stat update together."""
@@ -322,7 +336,7 @@ def dccrn_eval_case(cfg, models, name, kernel_num, rnn_units, mask, loss, B, L, 
     cfg.lstm = "complex"
     cfg.skip_type = True
     torch.manual_seed(0)
-    m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask)
+    m = models.DCCRN(rnn_units=rnn_units, masking_mode=mask, use_cbn=use_cbn)
     fill_state_dict_(m)
     m.train()
     x, y = test_signals(B, L)
@@ -338,7 +352,7 @@ def dccrn_eval_case(cfg, models, name, kernel_num, rnn_units, mask, loss, B, L, 
     with torch.no_grad():
         o_r, o_i, wv = m(xv, yv)
         vloss = m.loss(wv, yv)
-    rec = dict(meta=dict(B=B, L=L, Bv=Bv, Lv=Lv, kernel_num=np.array(kernel_num), rnn_units=rnn_units, mask=np.array(mask), loss=np.array(loss)),
+    rec = dict(meta=dict(B=B, L=L, Bv=Bv, Lv=Lv, kernel_num=np.array(kernel_num), rnn_units=rnn_units, mask=np.array(mask), loss=np.array(loss), use_cbn=int(use_cbn)),
                train_loss=float(lossv), val_loss=float(vloss), val_wav=wv.numpy(), val_real=sample(o_r), val_imag=sample(o_i))
     np.savez_compressed(os.path.join(HERE, f"dccrn_{name}.npz"), **flat(rec, "g"))
     print(f"dccrn_{name}: train loss {float(lossv):.6f} val loss {float(vloss):.6f}")
@@ -359,11 +373,21 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "large":         # BASELINE configs[4]: DCCRN-large (2x channels, rnn_units 512), short clip
         dccrn_case(cfg, models, "large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", False, 2, 1600, store_taps=False, gstride=997, scale=0.125)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rectwin":       # ConvSTFT(win_type=None): rectangular window (tools_for_model.py:17-18)
+        dccrn_case(cfg, models, "rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False, 2, 4000, store_taps=False, win_type=None)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cbn":           # DCCRN(use_cbn=True): ComplexBatchNorm (tools_for_model.py:430-607), train step + eval forward
+        dccrn_case(cfg, models, "cbn_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False, 2, 4000, use_cbn=True)
+        dccrn_eval_case(cfg, models, "cbn_eval", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", 2, 4000, 3, 2400, use_cbn=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "noskip":        # cfg.skip_type = False (models.py:107-137, 222-223)
         dccrn_case(cfg, models, "noskip_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False, 2, 3000, store_taps=False, skip=False)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fsn_variants":  # cfg.sequence_model == 'GRU' and the three other norm_type choices
         fsn_variants(cfg, models, tfm)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fsn_weight_init":
+        fsn_weight_init(cfg, models)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "fsn_losses":    # FullSubNet.loss with SDR / SI-SNR / SI-SDR
         fsn_losses(cfg, models, tfm)

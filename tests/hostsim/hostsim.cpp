@@ -169,6 +169,20 @@ inline void load_dz(const BnBwdReduce& d, const AB& ab, int64_t r, int c, double
 }
 
 
+inline double load_dz_c(const CbnBwd& d, const AB& ab, int64_t r, int c) {
+  const int64_t b = r / d.rpb, q = r - b * d.rpb;
+  double g = 0.0;
+  if (q >= d.skip) g = ld(rp(ab, d.dz0), d.dt, (b * (d.rpb - d.skip) + q - d.skip) * d.C + c);
+  if (d.dz1.arena >= 0) g += ld(rp(ab, d.dz1), d.dt, r * d.C + c);
+  return g;
+}
+// V^-1/2 of a symmetric positive definite 2 x 2 matrix (tools_for_model.py:567-576)
+inline void inv_sqrt_2x2(double vrr, double vri, double vii, double& urr, double& uri, double& uii, double& s, double& t, double& rst) {
+  const double tau = vrr + vii, delta = vrr * vii - vri * vri;
+  s = std::sqrt(delta); t = std::sqrt(tau + 2 * s); rst = 1.0 / (s * t);
+  urr = (s + vii) * rst; uii = (s + vrr) * rst; uri = -vri * rst;
+}
+
 inline float sgm(double x) { return (float)(1.0 / (1.0 + std::exp(-x))); }
 inline uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x632BE5ABu) * 0xC2B2AE3Du;
@@ -688,6 +702,157 @@ void run_op(const Op& op, const AB& ab) {
           const float bn = gamma[c] * xh + beta[c];
           const double dbn = bn > 0.f ? g : a * g;
           st(rp(ab, d.dy), r.dt, row * C + c, (float)(gamma[c] * mi[C + c] * (dbn - tot[c] / d.count - xh * tot[C + c] / d.count)));
+        }
+      break;
+    }
+    // ---- ComplexBatchNorm (csrc/cbn.hip): same per-block partial sums (fp32 rows), fp64 finalize
+    case OP_CBN_STATS: {
+      const CbnFwd& d = op.cbf;
+      const int h = d.C / 2;
+      float* part = (float*)rp(ab, d.part);
+      for (int blk = 0; blk < d.nblk; ++blk) {
+        std::vector<double> s(5 * h, 0.0);
+        const int64_t r0 = (int64_t)blk * d.rows_per_blk, r1 = std::min<int64_t>(d.R, r0 + d.rows_per_blk);
+        for (int64_t r = r0; r < r1; ++r)
+          for (int k = 0; k < h; ++k) {
+            const double xr = ld(rp(ab, d.y), d.dt, r * d.C + k), xi = ld(rp(ab, d.y), d.dt, r * d.C + h + k);
+            s[k] += xr; s[h + k] += xi; s[2 * h + k] += xr * xr; s[3 * h + k] += xi * xi; s[4 * h + k] += xr * xi;
+          }
+        for (int i = 0; i < 5 * h; ++i) part[(int64_t)blk * 5 * h + i] = (float)s[i];
+      }
+      break;
+    }
+    case OP_CBN_FINALIZE: {
+      const CbnFwd& d = op.cbf;
+      const int h = d.C / 2;
+      float* coef = (float*)rp(ab, d.coef);
+      for (int k = 0; k < h; ++k) {
+        double mr, mi, vrr, vri, vii;
+        if (d.training) {
+          const float* part = (const float*)rp(ab, d.part);
+          double t[5] = {0, 0, 0, 0, 0};
+          for (int b = 0; b < d.nblk; ++b)
+            for (int j = 0; j < 5; ++j) t[j] += part[(int64_t)b * 5 * h + j * h + k];
+          mr = t[0] / d.count; mi = t[1] / d.count;
+          vrr = std::max(0.0, t[2] / d.count - mr * mr); vii = std::max(0.0, t[3] / d.count - mi * mi); vri = t[4] / d.count - mr * mi;
+          if (d.RM[0].arena >= 0) {
+            float* rm[2] = {(float*)rp(ab, d.RM[0]), (float*)rp(ab, d.RM[1])};
+            float* rv[3] = {(float*)rp(ab, d.RV[0]), (float*)rp(ab, d.RV[1]), (float*)rp(ab, d.RV[2])};
+            rm[0][k] += d.momentum * ((float)mr - rm[0][k]); rm[1][k] += d.momentum * ((float)mi - rm[1][k]);
+            rv[0][k] += d.momentum * ((float)vrr - rv[0][k]); rv[1][k] += d.momentum * ((float)vri - rv[1][k]); rv[2][k] += d.momentum * ((float)vii - rv[2][k]);
+          }
+        } else {
+          mr = ((const float*)rp(ab, d.RM[0]))[k]; mi = ((const float*)rp(ab, d.RM[1]))[k];
+          vrr = ((const float*)rp(ab, d.RV[0]))[k]; vri = ((const float*)rp(ab, d.RV[1]))[k]; vii = ((const float*)rp(ab, d.RV[2]))[k];
+        }
+        vrr += d.eps; vii += d.eps;
+        double urr, uri, uii, s_, t_, rst;
+        inv_sqrt_2x2(vrr, vri, vii, urr, uri, uii, s_, t_, rst);
+        const double wrr = ((const float*)rp(ab, d.W[0]))[k], wri = ((const float*)rp(ab, d.W[1]))[k], wii = ((const float*)rp(ab, d.W[2]))[k];
+        const double zrr = wrr * urr + wri * uri, zri = wrr * uri + wri * uii, zir = wri * urr + wii * uri, zii = wri * uri + wii * uii;
+        const double br = ((const float*)rp(ab, d.Bv[0]))[k], bi = ((const float*)rp(ab, d.Bv[1]))[k];
+        const double v[14] = {zrr, zri, zir, zii, br - zrr * mr - zri * mi, bi - zir * mr - zii * mi, mr, mi, urr, uri, uii, vrr, vri, vii};
+        for (int j = 0; j < 14; ++j) coef[j * h + k] = (float)v[j];
+      }
+      break;
+    }
+    case OP_CBN_APPLY: {
+      const CbnFwd& d = op.cbf;
+      const int h = d.C / 2;
+      const float* cf = (const float*)rp(ab, d.coef);
+      const float a = *(const float*)rp(ab, d.slope);
+      for (int64_t r = 0; r < d.R; ++r)
+        for (int k = 0; k < h; ++k) {
+          const float xr = ld(rp(ab, d.y), d.dt, r * d.C + k), xi = ld(rp(ab, d.y), d.dt, r * d.C + h + k);
+          const float yr = cf[k] * xr + cf[h + k] * xi + cf[4 * h + k], yi = cf[2 * h + k] * xr + cf[3 * h + k] * xi + cf[5 * h + k];
+          st(rp(ab, d.z), d.dt, r * d.C + k, yr > 0.f ? yr : a * yr);
+          st(rp(ab, d.z), d.dt, r * d.C + h + k, yi > 0.f ? yi : a * yi);
+        }
+      break;
+    }
+    case OP_CBN_BWD_REDUCE: {
+      const CbnBwd& d = op.cbb;
+      const int h = d.C / 2;
+      const float* cf = (const float*)rp(ab, d.coef);
+      const float a = *(const float*)rp(ab, d.slope);
+      float* part = (float*)rp(ab, d.part);
+      for (int blk = 0; blk < d.nblk; ++blk) {
+        std::vector<double> s(6 * h, 0.0);
+        double sa = 0;
+        const int64_t r0 = (int64_t)blk * d.rows_per_blk, r1 = std::min<int64_t>(d.R, r0 + d.rows_per_blk);
+        for (int64_t r = r0; r < r1; ++r)
+          for (int k = 0; k < h; ++k) {
+            const float xr = ld(rp(ab, d.y), d.dt, r * d.C + k), xi = ld(rp(ab, d.y), d.dt, r * d.C + h + k);
+            const double gr = load_dz_c(d, ab, r, k), gi = load_dz_c(d, ab, r, h + k);
+            const float yr = cf[k] * xr + cf[h + k] * xi + cf[4 * h + k], yi = cf[2 * h + k] * xr + cf[3 * h + k] * xi + cf[5 * h + k];
+            const double dr = yr > 0.f ? gr : a * gr, di = yi > 0.f ? gi : a * gi;
+            if (!(yr > 0.f)) sa += yr * gr;
+            if (!(yi > 0.f)) sa += yi * gi;
+            const double cr = xr - cf[6 * h + k], ci = xi - cf[7 * h + k];
+            s[k] += dr; s[h + k] += di; s[2 * h + k] += dr * cr; s[3 * h + k] += dr * ci; s[4 * h + k] += di * cr; s[5 * h + k] += di * ci;
+          }
+        for (int i = 0; i < 6 * h; ++i) part[(int64_t)blk * 7 * h + i] = (float)s[i];
+        part[(int64_t)blk * 7 * h + 6 * h] = (float)sa;
+        for (int k = 1; k < h; ++k) part[(int64_t)blk * 7 * h + 6 * h + k] = 0.f;
+      }
+      break;
+    }
+    case OP_CBN_BWD_FINALIZE: {
+      const CbnBwd& d = op.cbb;
+      const int h = d.C / 2;
+      const float* cf = (const float*)rp(ab, d.coef);
+      const float* part = (const float*)rp(ab, d.part);
+      float* cb = (float*)rp(ab, d.coefb);
+      double sa = 0;
+      for (int b = 0; b < d.nblk; ++b) sa += part[(int64_t)b * 7 * h + 6 * h];
+      ((float*)rp(ab, d.dslope))[0] = (float)sa;
+      const double N = d.count;
+      for (int k = 0; k < h; ++k) {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < d.nblk; ++b)
+          for (int j = 0; j < 6; ++j) t[j] += part[(int64_t)b * 7 * h + j * h + k];
+        const double dbr = t[0], dbi = t[1], dzrr = t[2], dzri = t[3], dzir = t[4], dzii = t[5];
+        const double urr = cf[8 * h + k], uri = cf[9 * h + k], uii = cf[10 * h + k];
+        const double wrr = ((const float*)rp(ab, d.W[0]))[k], wri = ((const float*)rp(ab, d.W[1]))[k], wii = ((const float*)rp(ab, d.W[2]))[k];
+        ((float*)rp(ab, d.dB[0]))[k] = (float)dbr; ((float*)rp(ab, d.dB[1]))[k] = (float)dbi;
+        ((float*)rp(ab, d.dW[0]))[k] = (float)(dzrr * urr + dzri * uri);
+        ((float*)rp(ab, d.dW[1]))[k] = (float)(dzrr * uri + dzri * uii + dzir * urr + dzii * uri);
+        ((float*)rp(ab, d.dW[2]))[k] = (float)(dzir * uri + dzii * uii);
+        const double durr = wrr * dzrr + wri * dzir, duii = wri * dzri + wii * dzii, duri = (wrr * dzri + wri * dzii) + (wri * dzrr + wii * dzir);
+        const double vrr = cf[11 * h + k], vri = cf[12 * h + k], vii = cf[13 * h + k];
+        double u0, u1, u2, s_, t_, rst;
+        inv_sqrt_2x2(vrr, vri, vii, u0, u1, u2, s_, t_, rst);
+        double dvrr = 0, dvri = 0, dvii = 0;
+        const double d_rst = durr * (s_ + vii) + duii * (s_ + vrr) + duri * (-vri);
+        double d_s = (durr + duii) * rst;
+        dvii += durr * rst; dvrr += duii * rst; dvri += -duri * rst;
+        const double d_st = -d_rst * rst * rst;
+        d_s += d_st * t_;
+        const double d_t = d_st * s_;
+        const double d_u = d_t / (2 * t_);
+        d_s += 2 * d_u;
+        const double d_delta = d_s / (2 * s_);
+        dvrr += d_delta * vii + d_u; dvii += d_delta * vrr + d_u; dvri += -2 * vri * d_delta;
+        const double v[9] = {cf[k], cf[h + k], cf[2 * h + k], cf[3 * h + k], dbr / N, dbi / N, 2 * dvrr / N, dvri / N, 2 * dvii / N};
+        for (int j = 0; j < 9; ++j) cb[j * h + k] = (float)v[j];
+      }
+      break;
+    }
+    case OP_CBN_BWD_APPLY: {
+      const CbnBwd& d = op.cbb;
+      const int h = d.C / 2;
+      const float* cf = (const float*)rp(ab, d.coef);
+      const float* cb = (const float*)rp(ab, d.coefb);
+      const float a = *(const float*)rp(ab, d.slope);
+      for (int64_t r = 0; r < d.R; ++r)
+        for (int k = 0; k < h; ++k) {
+          const float xr = ld(rp(ab, d.y), d.dt, r * d.C + k), xi = ld(rp(ab, d.y), d.dt, r * d.C + h + k);
+          const float gr = (float)load_dz_c(d, ab, r, k), gi = (float)load_dz_c(d, ab, r, h + k);
+          const float yr = cf[k] * xr + cf[h + k] * xi + cf[4 * h + k], yi = cf[2 * h + k] * xr + cf[3 * h + k] * xi + cf[5 * h + k];
+          const float dr = (yr > 0.f ? gr : a * gr) - cb[4 * h + k], di = (yi > 0.f ? gi : a * gi) - cb[5 * h + k];
+          const float cr = xr - cf[6 * h + k], ci = xi - cf[7 * h + k];
+          st(rp(ab, d.dy), d.dt, r * d.C + k, cf[k] * dr + cf[2 * h + k] * di + cb[6 * h + k] * cr + cb[7 * h + k] * ci);
+          st(rp(ab, d.dy), d.dt, r * d.C + h + k, cf[h + k] * dr + cf[3 * h + k] * di + cb[7 * h + k] * cr + cb[8 * h + k] * ci);
         }
       break;
     }

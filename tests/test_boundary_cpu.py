@@ -111,3 +111,36 @@ def test_torch_library_namespace_registers_and_traces():
     assert out.shape == () and ws.numel() > 0
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         torch.ops.sefd.loss(2, torch.zeros(2, 100), torch.zeros(2, 100))
+
+
+@pytest.mark.parametrize("seq", ["LSTM", "GRU"])
+def test_fullsubnet_weight_init_draws_the_reference_values(seq):
+    """FullSubNet(weight_init=True) (reference models.py:623-624 -> BaseModel.weight_init, tools_for_model.py:1120-1184): same module tree, same
+    traversal, same torch.nn.init calls -> the parameters the reference holds after construction under the same seed (digest captured by
+    tests/golden/make_golden.py fsn_weight_init)."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import models
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fsn_weight_init.npz"))
+    torch.manual_seed(0)
+    m = models.FullSubNet(fb_model_hidden_size=64, sb_model_hidden_size=32, sequence_model=seq, weight_init=True)
+    names = [k for k, _ in m.named_parameters()]
+    assert [k[len(f"g/{seq}/"):] for k in g.files if k.startswith(f"g/{seq}/")] == names
+    for k, p in m.named_parameters():
+        v = p.detach().double().reshape(-1)
+        got = np.array([float(v.sum()), float(v.abs().sum())] + [float(t) for t in v[:6]])
+        assert np.allclose(got, g[f"g/{seq}/{k}"], rtol=1e-6, atol=1e-7), k
+
+
+def test_dccrn_complex_batch_norm_state_dict_layout():
+    """DCCRN(use_cbn=True): the reference's ComplexBatchNorm keys (tools_for_model.py:441-467) in registration order, Wri ~ U(-0.9, 0.9)."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    cfg.dccrn_kernel_num = [16, 32, 32, 64, 64, 64]
+    torch.manual_seed(0)
+    m = models.DCCRN(rnn_units=128, use_cbn=True)
+    keys = [k for k in m.state_dict() if k.startswith("encoder.1.1.")]
+    assert keys == ["encoder.1.1." + n for n in ("Wrr", "Wri", "Wii", "Br", "Bi", "RMr", "RMi", "RVrr", "RVri", "RVii", "num_batches_tracked")]
+    sd = m.state_dict()
+    assert sd["encoder.1.1.Wrr"].shape == (16,) and float(sd["encoder.1.1.Wrr"].min()) == 1.0 and float(sd["encoder.1.1.RVii"].max()) == 1.0
+    assert float(sd["encoder.1.1.Wri"].abs().max()) <= 0.9 and float(sd["encoder.1.1.Wri"].abs().max()) > 0.1
+    assert "decoder.5.1.Wrr" not in sd and "decoder.4.1.Wrr" in sd            # the mask layer has no normalisation (models.py:140-153)

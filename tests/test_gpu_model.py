@@ -23,6 +23,8 @@ CASES = [
     ("real_E_sisnr", (16, 32, 32, 64, 64, 64), 256, "E", "SI-SNR"),   # cfg.lstm == 'real': nn.LSTM(2 layers) + tranform
     ("large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR"),   # BASELINE configs[4]: DCCRN-large (2x channels, rnn_units 512)
     ("noskip_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR"),       # cfg.skip_type = False (models.py:107-137, 222-223)
+    ("cbn_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR"),          # DCCRN(use_cbn=True): ComplexBatchNorm (tools_for_model.py:430-607)
+    ("rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR"),      # win_type=None: rectangular window (tools_for_model.py:17-18)
 ]
 
 
@@ -32,7 +34,7 @@ def case_meta(g):
             int(g["g/meta/gstride"]) if "g/meta/gstride" in g else 53)
 
 
-def make_model(kn, ru, mask, loss, lstm="complex", skip=True, dtype="fp32"):
+def make_model(kn, ru, mask, loss, lstm="complex", skip=True, dtype="fp32", use_cbn=False, win_type="hanning"):
     import sefd_amd
     from sefd_amd import config as cfg, models
     cfg.dccrn_kernel_num = list(kn)
@@ -43,7 +45,7 @@ def make_model(kn, ru, mask, loss, lstm="complex", skip=True, dtype="fp32"):
     cfg.skip_type = skip
     cfg.act_dtype = dtype
     try:
-        m = models.DCCRN(rnn_units=ru, masking_mode=mask)
+        m = models.DCCRN(rnn_units=ru, masking_mode=mask, use_cbn=use_cbn, win_type=win_type)
     finally:
         cfg.skip_type = True
     fill_state_dict_(m)
@@ -59,7 +61,8 @@ def test_module_step_against_reference_golden(name, kn, ru, mask, loss):
     g = load_golden("dccrn_" + name)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     skip, scale, gstride = case_meta(g)
-    m = make_model(kn, ru, mask, loss, lstm="real" if name.startswith("real") else "complex", skip=skip)
+    m = make_model(kn, ru, mask, loss, lstm="real" if name.startswith("real") else "complex", skip=skip, use_cbn=name.startswith("cbn"),
+                   win_type=None if name.startswith("rectwin") else "hanning")
     m.train()
     x, y = make_signals(B, L)
     x, y = (x * scale).cuda(), (y * scale).cuda()
@@ -170,13 +173,14 @@ def test_full_length_clip_and_properties():
     assert rel_err(full[1:2], one) < 1e-5
 
 
-def test_validation_path_against_reference_golden(tmp_path):
+@pytest.mark.parametrize("gold", ["dccrn_small_eval", "dccrn_cbn_eval"])
+def test_validation_path_against_reference_golden(tmp_path, gold):
     """`trainer.model_validate` (reference trainer.py:188-241): eval-mode plans with the running statistics a
-    training-mode forward just updated, no gradients; enhanced waveform and loss vs the reference golden."""
+    training-mode forward just updated, no gradients; enhanced waveform and loss vs the reference golden (BatchNorm2d and ComplexBatchNorm)."""
     from sefd_amd import trainer
-    g = load_golden("dccrn_small_eval")
+    g = load_golden(gold)
     kn = tuple(int(k) for k in g["g/meta/kernel_num"])
-    m = make_model(kn, int(g["g/meta/rnn_units"]), "C", "SI-SNR")
+    m = make_model(kn, int(g["g/meta/rnn_units"]), str(g["g/meta/mask"]), str(g["g/meta/loss"]), use_cbn=gold.endswith("cbn_eval"))
     m.train()
     x, y = make_signals(int(g["g/meta/B"]), int(g["g/meta/L"]))
     with torch.no_grad():
@@ -519,12 +523,13 @@ def _grad_report(grads, g, gstride):
 
 @pytest.mark.parametrize("name,kn,ru,mask,loss", [("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR"),
                                                   ("large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR"),
-                                                  ("small_C_sdr", (16, 32, 32, 64, 64, 64), 128, "C", "SDR")])
+                                                  ("small_C_sdr", (16, 32, 32, 64, 64, 64), 128, "C", "SDR"),
+                                                  ("cbn_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")])
 def test_bf16_dccrn_step_against_reference_golden(name, kn, ru, mask, loss):
     g = load_golden("dccrn_" + name)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     skip, scale, gstride = case_meta(g)
-    m = make_model(kn, ru, mask, loss, skip=skip, dtype="bf16")
+    m = make_model(kn, ru, mask, loss, skip=skip, dtype="bf16", use_cbn=name.startswith("cbn"))
     m.train()
     x, y = make_signals(B, L)
     x, y = (x * scale).cuda(), (y * scale).cuda()

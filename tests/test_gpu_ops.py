@@ -43,6 +43,8 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 1024, "bf16"),    # H = 512: 8 workgroups per cluster
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "fp32"),     # wide LSTM in fp32: per-step path
                                                         ("DCCRN", 2, 7000, "C", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # T = 71: chunked two-lane LSTM forward
+                                                        ("DCCRN_CBN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),  # DCCRN(use_cbn=True): the six ComplexBatchNorm ops (cbn.hip)
+                                                        ("DCCRN_CBN", 2, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
                                                         ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("FullSubNet", 2, 13, "E", (128, 64), 0, "fp32"),
@@ -92,9 +94,9 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         from oracle.crn import CRNConfig, crn_state_shapes
         P = formula_state_dict(crn_state_shapes(CRNConfig(kernel_num=kn, rnn_units=ru, rnn_input_size=4 * (kn[-1] // 2))))
     else:
-        P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru)))
+        P = formula_state_dict(dccrn_state_shapes(DCCRNConfig(masking_mode=mode, kernel_num=kn, rnn_units=ru, use_cbn=model == "DCCRN_CBN")))
     if model != "FullSubNet":
-        plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model)
+        plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model.split("_")[0], use_cbn=model == "DCCRN_CBN")
     os.environ.pop("SEFD_BN_FUSE", None)
     os.environ.pop("SEFD_CG256_MINM", None)        # the plan is built: later tests get the default thresholds again
     os.environ.pop("SEFD_WG256_MINM", None)

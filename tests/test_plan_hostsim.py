@@ -107,6 +107,20 @@ def test_hostsim_without_skip_connections():
     _check_plan_vs_oracle("E", "SI-SNR", dict(SMALL, skip_type=False), 2, 3000)
 
 
+def test_hostsim_complex_batch_norm():
+    """DCCRN(use_cbn=True): ComplexBatchNorm (tools_for_model.py:430-607) - statistics pass, 2 x 2 whitening, backward through the covariance."""
+    _check_plan_vs_oracle("E", "SI-SNR", dict(SMALL, use_cbn=True), 2, 3000)
+    with pytest.raises(ValueError):
+        Plan(2, 3000, kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128, use_cbn=True, bn_world=2)      # no SyncBN plan for it
+
+
+def test_hostsim_rectangular_window():
+    """ConvSTFT / ConviSTFT with win_type None (tools_for_model.py:17-18): np.ones in the analysis and synthesis bases and in the OLA normaliser."""
+    _check_plan_vs_oracle("C", "SI-SNR", dict(SMALL, win_type=None), 2, 3000)
+    with pytest.raises(NotImplementedError):
+        Plan(2, 3000, kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128, win_type="hamming")
+
+
 def test_hostsim_forced_per_step_lstm_matches_too(monkeypatch):
     monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
     _check_plan_vs_oracle("E", "SI-SNR", SMALL, 2, 4000)
