@@ -92,7 +92,7 @@ def test_adam_state_dict_format_and_pending_load():
     with pytest.raises(RuntimeError):
         opt.step()                                             # no CPU path
     with pytest.raises(NotImplementedError):
-        models.DCCRN(rnn_units=128, win_type=None)             # rectangular window is not on the HIP path
+        models.DCCRN(rnn_units=128, win_type="hamming")        # only the periodic Hann and the rectangular (None) windows are on the HIP path
     cfg.dccrn_kernel_num = [32, 64, 128, 256, 256, 256]
 
 
