@@ -117,8 +117,8 @@ def test_default_scorers_of_the_validation_loop_score_for_real(tmp_path):
 
 
 def test_pesq_cpp_matches_reference_binary_goldens():
-    """|MOS-LQO - PESQ.so| <= 0.01 on all 34 pairs (VERDICT r2 criterion; measured worst 0.0033): noise over 40 dB of SNR, coloured noise,
-    low-pass (a few samples of delay), clipping, an over-subtracting enhancement gain, silent edges, 1-4 s."""
+    """|MOS-LQO - PESQ.so| <= 1e-3 on all 34 pairs (measured worst 4.5e-5 since round 4's input-filter fix; 0.0033 before): noise over 40 dB of
+    SNR, coloured noise, low-pass (a few samples of delay), clipping, an over-subtracting enhancement gain, silent edges, 1-4 s."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pesq_golden.npz"))
     pairs = pesq_pairs()
     assert [p[0] for p in pairs] == [str(n) for n in g["names"]]
@@ -126,7 +126,7 @@ def test_pesq_cpp_matches_reference_binary_goldens():
     for (name, clean, deg), gold in zip(pairs, g["mos_lqo"]):
         got = te.cal_pesq(deg[None], clean[None], nthreads=1)[0]
         worst = max(worst, abs(got - float(gold)))
-        assert abs(got - float(gold)) <= 0.01, (name, got, float(gold))
+        assert abs(got - float(gold)) <= 1e-3, (name, got, float(gold))
     assert 1.0 < float(g["mos_lqo"].min()) < 1.3 and float(g["mos_lqo"].max()) > 3.9      # the goldens span the scale
     # batch == per-utterance, scale invariance, identical signals score the ceiling
     c = np.stack([pairs[0][1], pairs[8][1]]); d = np.stack([pairs[1][2], pairs[9][2]])
@@ -151,12 +151,13 @@ def test_pesq_of_a_silent_clip_is_the_floor_not_nan():
 
 
 def test_pesq_cpp_on_heldout_model_outputs():
-    """Three utterances of the held-out evaluation (clean / noisy / fp32-trained DCCRN output, int16) with the reference binary's scores: the
-    noisy inputs agree to 0.002; on enhanced speech the one-delay-per-file alignment of the port differs from the binary's per-utterance
-    delays by up to 0.067 MOS on some files (utt 12 here, the worst of 224; mean |difference| 0.005) - bound 0.08, stated in INTEGRATION.md."""
+    """Three utterances of the held-out evaluation (clean / noisy / fp32-trained DCCRN output, int16) with the reference binary's scores.  Until
+    round 4 the enhanced ones differed by up to 0.067 MOS (utt 12 here was the worst of 224): not an alignment effect - the binary fades the
+    first and last 15 samples and filters exactly the file's samples before its wide-band input filter (csrc_host/pesq.cpp wb_input_filter);
+    with both restated the three agree to 0.0014 (576 reference-enhanced clips: mean 0.0004, worst 0.0025)."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pesq_heldout.npz"))
     clean = g["clean"].astype(np.float32) / 32768.0
-    for key, gold, tol in (("noisy", g["mos_noisy"], 0.005), ("enhanced", g["mos_enhanced"], 0.08)):
+    for key, gold, tol in (("noisy", g["mos_noisy"], 1e-3), ("enhanced", g["mos_enhanced"], 5e-3)):
         got = np.array(te.cal_pesq(g[key].astype(np.float32) / 32768.0, clean))
         assert np.all(np.abs(got - gold) <= tol), (key, got, gold)
-    assert abs(te.cal_pesq(g["enhanced"][2:3].astype(np.float32) / 32768.0, clean[2:3])[0] - float(g["mos_enhanced"][2])) < 0.015
+    assert abs(te.cal_pesq(g["enhanced"][2:3].astype(np.float32) / 32768.0, clean[2:3])[0] - float(g["mos_enhanced"][2])) < 5e-3
