@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r04_heldout_reference.json"))
     ap.add_argument("--wavdir", default=os.path.join(ROOT, "gpurun_out", "heldout_ref"))
+    ap.add_argument("--rescore", action="store_true", help="no training: recompute pesq_cpp / stoi of every stored run from its kept enhanced_reference_o*.npy "
+                                                           "(after a change of the C++ scorers)")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     from make_golden import import_reference
@@ -67,6 +69,22 @@ def main():
         if old.get("protocol") == out["protocol"]:
             out = old
     clean16 = np.round(held_c * 32767).astype(np.int16).astype(np.float64)
+    if a.rescore:
+        for key, run in out["runs"].items():
+            f = os.path.join(a.wavdir, f"enhanced_reference_o{key}.npy")
+            if not os.path.exists(f):
+                print("order", key, ": no kept output, scores unchanged")
+                continue
+            e = np.load(f).astype(np.float64)
+            pc = est.cal_pesq([e[i] / 32768.0 for i in range(len(e))], [clean16[i] / 32768.0 for i in range(len(e))])
+            st = est.cal_stoi([e[i] / 32768.0 for i in range(len(e))], [clean16[i] / 32768.0 for i in range(len(e))])
+            for i, row in enumerate(run["rows"]):
+                row["pesq_cpp"], row["stoi"] = float(pc[i]), float(st[i])
+            run["mean"] = {k: float(np.mean([r[k] for r in run["rows"]])) for k in ("pesq", "pesq_cpp", "stoi")}
+            print("order", key, run["mean"], flush=True)
+        out["scorer_note"] = "pesq_cpp / stoi re-scored with the round-4 C++ scorers (PESQ input-stage fix); pesq = the reference's PESQ.so at training time"
+        json.dump(out, open(a.json, "w"), indent=1)
+        return
     for order_seed in [int(s) for s in a.orders.split(",")]:
         key = str(order_seed)
         if key in out["runs"]:
