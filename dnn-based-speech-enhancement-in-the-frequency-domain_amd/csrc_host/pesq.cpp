@@ -189,7 +189,7 @@ static double pesq_raw(const double* refx, const double* degx, long n, double in
   wb_input_filter(ref);
   wb_input_filter(deg);
 
-  // one delay for the whole file: arg max of the cross-correlation (FFT), lags -256 .. 256
+  // one delay for the whole file: arg max of |cross-correlation| (FFT), lags -256 .. 256
   long delay = 0;
   {
     const long na = maxn + pad;
@@ -200,9 +200,11 @@ static double pesq_raw(const double* refx, const double* degx, long n, double in
     fft(fr, false); fft(fd2, false);
     for (size_t i = 0; i < p2; ++i) fr[i] = std::conj(fr[i]) * fd2[i];          // r[lag] = sum_t ref[t] deg[t + lag]
     fft(fr, true);
-    double best = fr[0].real();
+    // |r|: the psychoacoustic model works on power spectra, so an enhanced signal of inverted polarity scores like the upright one (SI-SNR does
+    // not see the sign: one of 18 reference-trained models came out negated) - with the signed maximum the search locked half a pitch period off
+    double best = std::fabs(fr[0].real());
     for (long lag = -256; lag <= 256; ++lag) {
-      const double v = fr[(size_t)((lag + (long)p2) % (long)p2)].real();
+      const double v = std::fabs(fr[(size_t)((lag + (long)p2) % (long)p2)].real());
       if (v > best * (1.0 + 1e-9)) { best = v; delay = lag; }
     }
   }
