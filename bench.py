@@ -2,6 +2,7 @@
 """Train-step throughput on MI355X (BASELINE.json metric), with roofline and CPU-baseline legs.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus N ...            (no launcher: re-executes itself as N ranks under torch.distributed.run on a free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = forward + SI-SNR loss + backward + fused Adam (+ RCCL gradient all-reduce when N > 1) on a synthetic batch of
@@ -222,11 +223,39 @@ def cpu_baseline(L, kn, ru):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it (the driver's command shape): become N ranks.  Re-executes this file under
+    `torch.distributed.run --nproc-per-node N` on 127.0.0.1 and a free port, one rank per GPU over RCCL; rank 0's JSON line is this
+    process's output and its exit code this process's.  Refuses when the box has fewer than N GPUs instead of aliasing devices (several
+    ranks on one GPU only with SEFD_DIST_BACKEND=gloo: the single-GPU control-flow test, never a reported number)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("SEFD_DIST_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {args.gpus} but this box has {ndev} GPU(s); refusing to alias devices", file=sys.stderr)
+        raise SystemExit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and "WORLD_SIZE" in os.environ and os.environ.get("SEFD_DDP_FORCE", "0") != "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    ndev = max(torch.cuda.device_count(), 1)
+    if world > ndev and os.environ.get("SEFD_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s): one rank per GPU (RCCL refuses duplicate devices)")
+    local = int(os.environ.get("LOCAL_RANK", "0")) % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist

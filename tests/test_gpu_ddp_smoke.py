@@ -49,3 +49,26 @@ def test_one_rank_exchange_runs_on_rccl(model, batch):
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
     d2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
     assert abs(d2["final_loss"] - d["final_loss"]) < 2e-3 * max(1.0, abs(d2["final_loss"])), (d["final_loss"], d2["final_loss"])
+
+
+def test_plain_bench_gpus2_launches_two_ranks_itself():
+    """The driver's command shape is `python bench.py --gpus N ...` with NO launcher around it (BENCH_r04.json.cmd): bench.py must become N ranks
+    by itself.  Two ranks on the box's one GPU over gloo (control flow only); with the RCCL backend the same command must refuse rather
+    than alias the device."""
+    env = dict(os.environ, SEFD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and len(d["config"]["per_rank_ms"]) == 2
+    assert d["config"]["parallelism"] == "dp2" and "world 2" in d["config"]["collective"]
+    assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("SEFD_DIST_BACKEND")
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "refusing to alias" in r.stderr
