@@ -60,6 +60,8 @@ def lib():
         "sefd_loss_ws_floats": (i64, [i32]),
         "sefd_loss_forward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp]),
         "sefd_loss_backward": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp]),
+        "sefd_loss_dp_offset": (i64, [i64, i32]),
+        "sefd_loss_dp_finish": (i32, [i32, i64, vp, i32, vp, vp]),
         "sefd_loss_rows_ws_floats": (i64, [i64]),
         "sefd_loss_rows_forward": (i32, [i32, vp, vp, i64, i32, vp, vp, vp]),
         "sefd_loss_rows_backward": (i32, [i32, vp, vp, i64, i32, vp, vp, vp, vp, vp]),
@@ -91,5 +93,5 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_param_shape", "sefd_plan_buffer", "sefd_plan_num_buffers", "sefd_plan_buffer_name",
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
             "sefd_plan_grad_bucket", "sefd_plan_grad_bucket_range", "sefd_plan_run_cb", "sefd_plan_run_flags", "sefd_plan_run_timed",
-            "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_loss_rows_ws_floats", "sefd_loss_rows_forward", "sefd_loss_rows_backward", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
+            "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_loss_rows_ws_floats", "sefd_loss_rows_forward", "sefd_loss_rows_backward", "sefd_loss_dp_offset", "sefd_loss_dp_finish", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
             "sefd_adam_step", "sefd_adam_step_guarded", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set"]

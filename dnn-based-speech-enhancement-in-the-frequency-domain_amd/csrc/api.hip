@@ -389,7 +389,12 @@ __global__ void loss_finalize_kernel(int kind, int B, int L, float* ws, float* l
     const float m = total / B;
     const float g = -k10 / (m + eps) / B;
     for (int b = threadIdx.x; b < B; b += blockDim.x) { coef[2 * b] *= g; coef[2 * b + 1] *= g; }
-    if (threadIdx.x == 0) loss_out[0] = -k10 * logf(m + eps);
+    if (threadIdx.x == 0) {
+      loss_out[0] = -k10 * logf(m + eps);
+      // data parallel (sefd_loss_dp_finish): this rank's (sum of ratios, rows), once to be all-reduced in place and once to stay
+      float* dp = term + B;
+      dp[0] = total; dp[1] = (float)B; dp[2] = total; dp[3] = (float)B;
+    }
   } else if (threadIdx.x == 0) {
     loss_out[0] = total;
   }
@@ -479,6 +484,7 @@ __global__ void loss_rows_finalize_kernel(int kind, int64_t R, int nblk, float* 
       const float m = red[0] / (float)R;
       loss_out[0] = -k10 * logf(m + eps);
       ws[nblk] = -k10 / (m + eps) / (float)R;
+      ws[nblk + 1] = red[0]; ws[nblk + 2] = (float)R; ws[nblk + 3] = red[0]; ws[nblk + 4] = (float)R;     // see sefd_loss_dp_finish
     } else {
       loss_out[0] = red[0];
       ws[nblk] = 1.f;
@@ -499,6 +505,17 @@ __global__ __launch_bounds__(256) void loss_rows_grad_kernel(int kind, const flo
       if (gtgt) gtgt[r * L + i] = gs * (q.fset * e[i] + 2.f * q.fstt * t[i]);
     }
   }
+}
+// SI-SDR over data-parallel ranks: tools_for_loss.py:91-94 takes the mean of the ratios over the WHOLE batch before the log, so the
+// per-rank loss is not a term of a sum.  dp = { global sum of ratios, global rows (all-reduced in place by the host), this rank's sum, this rank's
+// rows }.  Loss <- -10 log10(global mean + eps); the row coefficients, already scaled with the rank's own mean by the finalize kernel, are
+// re-scaled to (d loss / d ratio) * world - the exchange sums the ranks' gradients and Adam multiplies by 1 / world.
+__global__ void loss_dp_finish_kernel(float* coef, int64_t ncoef, const float* dp, float world, float* loss_out) {
+  const float eps = 1e-8f, k10 = 4.342944819032518f;
+  const float m = dp[0] / dp[1], ml = dp[2] / dp[3];
+  const float f = ((ml + eps) * dp[3] * world) / ((m + eps) * dp[1]);
+  for (int64_t i = threadIdx.x; i < ncoef; i += blockDim.x) coef[i] *= f;
+  if (threadIdx.x == 0 && loss_out) loss_out[0] = -k10 * logf(m + eps);
 }
 static int rows_blocks(int64_t R) { const int64_t n = (R + 255) / 256; return (int)(n < kRowsMaxBlk ? n : kRowsMaxBlk); }
 
@@ -551,6 +568,15 @@ int32_t sefd_loss_rows_backward(int kind, const float* est, const float* tgt, in
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nblk = rows_blocks(R);
   hipLaunchKernelGGL(loss_rows_grad_kernel, dim3(nblk), dim3(256), 0, st, kind, est, tgt, R, L, ws, nblk, grad_scale, grad_est, grad_tgt);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int64_t sefd_loss_dp_offset(int64_t n, int32_t rows) { return rows ? (int64_t)rows_blocks(n) + 1 : n * kLossBlk * 3 + 3 * n; }
+int32_t sefd_loss_dp_finish(int32_t rows, int64_t n, float* ws, int32_t world, float* loss_out, void* stream) {
+  if (n < 1 || world < 1) return -1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* dp = ws + sefd_loss_dp_offset(n, rows);
+  if (rows) hipLaunchKernelGGL(loss_dp_finish_kernel, dim3(1), dim3(64), 0, st, ws + rows_blocks(n), (int64_t)1, dp, (float)world, loss_out);
+  else hipLaunchKernelGGL(loss_dp_finish_kernel, dim3(1), dim3(256), 0, st, ws + n * kLossBlk * 3, 2 * n, dp, (float)world, loss_out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,

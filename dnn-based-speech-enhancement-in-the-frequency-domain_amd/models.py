@@ -280,11 +280,6 @@ class _SefdModule(nn.Module):
         if not isinstance(optimizer, Adam):
             raise TypeError("train_step needs sefd_amd.optim.Adam (flat fused Adam)")
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
-        if exchange is not None and exchange.world > 1 and (loss_kind or cfg.loss) == 'SI-SDR':  # (one forced rank: exact)
-            # tools_for_loss.py:91-94 takes the batch mean of the ratios INSIDE the log: rank-averaged gradients of per-rank losses are not
-            # the gradient of the global-batch loss; every other loss is a mean of per-utterance terms and shards exactly
-            raise NotImplementedError("cfg.loss == 'SI-SDR' does not decompose over data-parallel ranks (mean of ratios inside the log); "
-                                      "train it on one GPU or use SI-SNR / SDR / MSE")
         inputs = inputs.float()
         targets = targets.float().contiguous()
         B, L = inputs.shape
@@ -310,7 +305,13 @@ class _SefdModule(nn.Module):
             rt.plan.run_cb(PHASE_FWD, rt.arenas, stream, -1, None, flags=wave_only)
         else:
             rt.run(PHASE_FWD)
-        ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
+        # sharded batch: SI-SDR's mean of ratios inside the log (tools_for_loss.py:91-94) is taken over all ranks (two floats all-reduced
+        # between the loss kernels); the other losses shard exactly
+        prev_dp = tfl.set_data_parallel(exchange)
+        try:
+            ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
+        finally:
+            tfl.set_data_parallel(prev_dp)
         if not wave_only:
             rt.g_real.zero_()
             rt.g_imag.zero_()
@@ -693,6 +694,7 @@ class FullSubNet(_SefdModule):
         plan.view(ar, "io.seed").view(torch.int32)[:1].add_(1)
         plan.run(PHASE_FWD, ar, stream)
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
+        prev_dp = tfl.set_data_parallel(exchange)            # SI-SDR: mean of the row ratios over ALL ranks' rows inside the log
         if kind == 0:
             crm = plan.io(ar, "crm", (B, F * T * 2))
             ws, loss = tfl.loss_forward_raw(0, crm, cirm.view(B, -1), stream)
@@ -703,6 +705,7 @@ class FullSubNet(_SefdModule):
             crm = plan.io(ar, "crm", (B * F * T, 2))
             ws, loss = tfl.loss_rows_forward_raw(kind, cirm.view(-1, 2), crm, stream)
             tfl.loss_rows_backward_raw(kind, cirm.view(-1, 2), crm, ws, None, None, plan.io(ar, "grad_crm", (B * F * T, 2)), stream)
+        tfl.set_data_parallel(prev_dp)
         bucket = plan.grad_bucket_range() if self._grad_buckets == 2 else None
         if bucket is not None:
             op, lo, hi = bucket

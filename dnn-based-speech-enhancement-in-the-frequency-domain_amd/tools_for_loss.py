@@ -20,6 +20,31 @@ def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_DP = None           # the active data-parallel exchange (sefd_amd.ddp.GradientExchange) or None: set_data_parallel
+
+
+def set_data_parallel(exchange):
+    """Tell the losses that the batch is sharded over `exchange`'s ranks.  Only SI-SDR cares: tools_for_loss.py:91-94 averages the per-row
+    ratios over the WHOLE batch before the log, so each rank's (sum of ratios, rows) pair is sum-all-reduced between the loss's forward
+    and backward kernels (two floats, on the current stream) and the loss / gradient are those of the global batch (the gradient times
+    `world`: the exchange sums the ranks' gradients and the step applies 1 / world).  MSE / SDR / SI-SNR are means of per-row terms and
+    shard exactly without it.  Returns the previous setting."""
+    global _DP
+    prev, _DP = _DP, (exchange if (exchange is not None and getattr(exchange, "active", False) and exchange.world > 1) else None)
+    return prev
+
+
+def _dp_finish(kind, rows, n, ws, out, stream):
+    if kind != LOSS_KINDS["SI-SDR"] or _DP is None:
+        return
+    L_ = _lib.lib()
+    off = L_.sefd_loss_dp_offset(n, rows)
+    _DP.all_reduce_stats(ws[off:off + 2])
+    rc = L_.sefd_loss_dp_finish(rows, n, _vp(ws), _DP.world, _vp(out), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"sefd_loss_dp_finish failed ({rc})")
+
+
 def loss_forward_raw(kind, est, tgt, stream):
     L_ = _lib.lib()
     B, L = est.shape
@@ -28,6 +53,7 @@ def loss_forward_raw(kind, est, tgt, stream):
     rc = L_.sefd_loss_forward(kind, _vp(est), _vp(tgt), B, L, _vp(ws), _vp(out), C.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"sefd_loss_forward failed ({rc})")
+    _dp_finish(kind, 0, B, ws, out, stream)
     return ws, out
 
 
@@ -51,6 +77,7 @@ def loss_rows_forward_raw(kind, est, tgt, stream):
     rc = L_.sefd_loss_rows_forward(kind, _vp(est), _vp(tgt), R, L, _vp(ws), _vp(out), C.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"sefd_loss_rows_forward failed ({rc})")
+    _dp_finish(kind, 1, R, ws, out, stream)
     return ws, out
 
 

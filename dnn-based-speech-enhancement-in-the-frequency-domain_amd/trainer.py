@@ -3,14 +3,31 @@
 `model_train(model, optimizer, train_loader, DEVICE)` has the reference's signature and epoch semantics (mean of the
 per-batch losses).  With `sefd_amd.optim.Adam` the whole batch step is the fused HIP path (`model.train_step`);
 with any other optimizer it is the literal reference loop (autograd Functions over the same HIP kernels)."""
+import functools
 import os
 
 import torch
 
 from . import config as cfg
+from . import tools_for_loss as tfl
 from .optim import Adam
 
 
+def _sharded(fn):
+    """A train function under `exchange`: for its duration the losses know the batch is sharded (tools_for_loss.set_data_parallel: SI-SDR's
+    mean of ratios inside the log runs over all ranks).  Validation runs outside it - every rank scores its own, possibly ragged, shard."""
+    @functools.wraps(fn)
+    def run(model, optimizer, train_loader, DEVICE, exchange=None):
+        prev = tfl.set_data_parallel(exchange)
+        try:
+            return fn(model, optimizer, train_loader, DEVICE, exchange=exchange)
+        finally:
+            tfl.set_data_parallel(prev)
+    return run
+
+
+
+@_sharded
 def model_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:15-42.  `exchange` (sefd_amd.ddp.GradientExchange, optional, not in the reference): data-parallel run."""
     train_loss = torch.zeros((), device=DEVICE)
@@ -34,6 +51,7 @@ def model_train(model, optimizer, train_loader, DEVICE, exchange=None):
     return train_loss / max(batch_num, 1)
 
 
+@_sharded
 def model_perceptual_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:45-82: loss = (main + perceptual) / 2, forward called without targets.  With `sefd_amd.optim.Adam` the batch is the
     fused `train_step(perceptual=cfg.perceptual)` (same numbers as the autograd route below, tests/test_gpu_validate.py), which is also
@@ -69,13 +87,12 @@ def _exchange_grads(model, exchange, optimizer=None):
     """Data-parallel step of the `loss.backward()` route: p.grad <- mean over ranks (ddp.GradientExchange.all_reduce_autograd).  The mean is
     formed here, so a fused-step 1/world left in the sefd Adam (models.train_step sets optimizer.grad_scale) must not be applied again."""
     if exchange is not None and exchange.active:
-        if cfg.loss == 'SI-SDR' and exchange.world > 1:
-            raise NotImplementedError("cfg.loss == 'SI-SDR' does not decompose over data-parallel ranks (tools_for_loss.py:91-94)")
         exchange.all_reduce_autograd(list(model.parameters()))
         if optimizer is not None and hasattr(optimizer, "grad_scale"):
             optimizer.grad_scale = 1.0
 
 
+@_sharded
 def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:85-118."""
     from . import tools_for_model as tools
@@ -104,6 +121,7 @@ def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
     return train_loss / max(batch_num, 1)
 
 
+@_sharded
 def dccrn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:121-150 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra.  Autograd route (the loss is on the
     spectra, not on the waveform the fused step differentiates); under `exchange` the gradients are averaged after the backward."""
@@ -126,6 +144,7 @@ def dccrn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
     return train_loss / max(batch_num, 1)
 
 
+@_sharded
 def crn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:150-181: CRN spectral mapping ('Direct(None make)'): the loss compares the mapped magnitudes (first output
     of `CRN.forward`) with the target magnitudes; the waveform output carries no loss."""

@@ -127,6 +127,15 @@ int32_t sefd_loss_rows_forward(int kind, const float* est, const float* tgt, int
 int32_t sefd_loss_rows_backward(int kind, const float* est, const float* tgt, int64_t R, int32_t L, const float* ws, const float* grad_scale,
                                 float* grad_est, float* grad_tgt, void* stream);
 
+/* SI-SDR under data parallelism (no counterpart in the reference, which is single-process; the arithmetic it must reproduce is
+ * tools_for_loss.py:91-94: `ratio = torch.mean(ratio)` over the WHOLE batch, then the log).  After sefd_loss_forward / sefd_loss_rows_forward
+ * with kind SI-SDR, ws + sefd_loss_dp_offset(n, rows) holds this rank's { sum of ratios, row count } (n = B, or R with rows = 1): the host
+ * sum-all-reduces those TWO floats in place over the ranks and calls sefd_loss_dp_finish, which rewrites loss_out[0] to the global-batch
+ * loss and re-scales the saved row coefficients so that the following sefd_loss_*_backward yields world x d(global loss)/d(est) for this
+ * rank's rows (the gradient exchange sums over ranks, Adam applies 1 / world). */
+int64_t sefd_loss_dp_offset(int64_t n, int32_t rows);
+int32_t sefd_loss_dp_finish(int32_t rows, int64_t n, float* ws, int32_t world, float* loss_out, void* stream);
+
 /* ---- LMS log-mel perceptual loss (tools_for_loss.py:120-249 + the magnitude step of models.py:306-312) ------------
  * clean_* / est_*: fp32 [B][NF][T] device (reference layout).  If the *_i pointers are NULL the *_r arrays are magnitudes
  * already (get_array_lms_loss(clean_mags, est_mags) signature); otherwise mag = sqrt(r^2 + i^2 + 1e-7) is fused in.

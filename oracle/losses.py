@@ -37,6 +37,23 @@ def si_sdr(reference, estimation, eps=1e-8):
     return 10 * torch.log10(torch.mean(ratio) + eps)
 
 
+def si_sdr_sharded(reference, estimation, all_reduce_sum, world, eps=1e-8):
+    """si_sdr over a batch sharded across `world` ranks, as csrc/api.hip `loss_dp_finish_kernel` forms it (there is no distributed code in
+    the reference; the arithmetic to reproduce is tools_for_loss.py:91-94 on the WHOLE batch): every rank all-reduces (sum of its ratios,
+    its rows), the value is that of the global batch, and the gradient is `world` x the global-batch gradient for this rank's rows (the
+    gradient exchange then sums over ranks and the step multiplies by 1 / world).  all_reduce_sum(t): in-place sum of a 1-d tensor over ranks."""
+    re = torch.sum(reference ** 2, -1, keepdim=True)
+    a = torch.sum(reference * estimation, -1, keepdim=True) / re + eps
+    proj = a * reference
+    noise = estimation - proj
+    ratio = torch.sum(proj ** 2, -1) / torch.sum(noise ** 2, -1) + eps
+    S = ratio.sum()
+    tot = torch.stack([S.detach().double(), torch.tensor(float(ratio.numel()), dtype=torch.float64)])
+    all_reduce_sum(tot)
+    m = (S - S.detach()) * (world / float(tot[1])) + float(tot[0] / tot[1])
+    return 10 * torch.log10(m + eps)
+
+
 def main_loss(kind: str, estimated, target):
     """models.py:315-323 (argument order matters)."""
     if kind == "MSE":

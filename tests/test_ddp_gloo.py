@@ -82,7 +82,7 @@ def test_shard_batch_partitions():
 SMALL = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128)
 
 
-def _syncbn_worker(rank, world, port, q):
+def _syncbn_worker(rank, world, port, q, sisdr=False):
     """Each rank interprets a SyncBN plan (bn_world = 2) for its half of the batch with the host simulator; the statistics
     buffers are all-reduced over gloo at the plan's sync points - the same call sequence models.py issues on the GPUs."""
     import sys
@@ -101,8 +101,20 @@ def _syncbn_worker(rank, world, port, q):
         x, _ = make_signals(B, L)
         torch.manual_seed(7)
         gw = torch.randn(B, L)
+        _, clean = make_signals(B, L)
 
-        def run(plan, xs, gs, synced):
+        def loss_grad(wav, tgt, sharded):
+            """sisdr: the upstream gradient is that of -si_sdr(target, output) (models.py:322-323) - over the global batch on the single
+            process, in its sharded form (two all-reduced floats between forward and backward, oracle.losses.si_sdr_sharded) on the ranks."""
+            est = wav.clone().requires_grad_(True)
+            if sharded:
+                loss = -ol.si_sdr_sharded(tgt, est, dist.all_reduce, world)
+            else:
+                loss = ol.main_loss("SI-SDR", est, tgt)
+            loss.backward()
+            return est.grad, float(loss)
+
+        def run(plan, xs, gs, synced, tgt=None):
             ar = plan.alloc_arenas("cpu")
             fill_params(plan, ar, P)
             plan.io(ar, "wav", xs.shape).copy_(xs)
@@ -123,6 +135,8 @@ def _syncbn_worker(rank, world, port, q):
 
             phase(PHASE_FWD)
             wav = plan.io(ar, "out_wav", xs.shape).clone()
+            if tgt is not None:
+                gs, run.loss = loss_grad(wav, tgt, synced)
             plan.io(ar, "grad_wav", xs.shape).copy_(gs)
             plan.io(ar, "grad_real", (xs.shape[0], plan.NF, plan.T)).zero_()
             plan.io(ar, "grad_imag", (xs.shape[0], plan.NF, plan.T)).zero_()
@@ -132,20 +146,25 @@ def _syncbn_worker(rank, world, port, q):
         lo, hi = rank * Bl, (rank + 1) * Bl
         plan = Plan(Bl, L, masking_mode="C", bn_world=world, **SMALL)
         assert len(plan.sync_points()) == 2 * 11                 # 11 BatchNorm layers, forward and backward
-        wav, grads, state = run(plan, x[lo:hi], gw[lo:hi], True)
+        wav, grads, state = run(plan, x[lo:hi], gw[lo:hi], True, clean[lo:hi] if sisdr else None)
         flat = torch.cat([grads[k].reshape(-1) for k in grads])
         dist.all_reduce(flat)                                    # the DDP gradient exchange (sum; upstream gradient given directly)
+        if sisdr:
+            flat /= world                                        # the sharded loss hands back world x the global gradient (Adam's 1 / world)
+            sharded_loss = run.loss
         res = None
         if rank == 0:
             full = Plan(B, L, masking_mode="C", **SMALL)
             assert len(full.sync_points()) == 0
-            fwav, fgrads, fstate = run(full, x, gw, False)
+            fwav, fgrads, fstate = run(full, x, gw, False, clean if sisdr else None)
             fflat = torch.cat([fgrads[k].reshape(-1) for k in fgrads])
             keep = torch.cat([torch.full((fgrads[k].numel(),), not (k.endswith("conv.bias") and not k.startswith("decoder.5.")))
                               for k in fgrads])                  # biases in front of BatchNorm: analytically zero, noise on both sides
             res = dict(wav=float((wav - fwav[lo:hi]).abs().max() / fwav.abs().max()),
                        grad=float(((flat - fflat)[keep]).abs().max() / fflat[keep].abs().max()),
                        state=max(float((state[k] - fstate[k]).abs().max() / (fstate[k].abs().max() + 1e-12)) for k in fstate))
+            if sisdr:
+                res["loss"] = abs(sharded_loss - run.loss) / abs(run.loss)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -168,6 +187,25 @@ def test_world2_syncbn_equals_single_process_big_batch():
     r0 = res[0]
     assert r0["wav"] < 2e-5 and r0["state"] < 2e-5, r0
     assert r0["grad"] < 2e-4, r0
+
+
+def test_world2_sisdr_sharded_equals_single_process_big_batch():
+    """tools_for_loss.py:91-94 takes the batch mean of the ratios INSIDE the log: under data parallelism the (sum of ratios, rows) pair is
+    all-reduced between the loss's forward and backward (sefd_loss_dp_finish; here its oracle restatement around SyncBN host-simulator
+    plans).  2 ranks x 2 utterances == the single process with batch 4: loss, and every gradient after the sum exchange and the 1 / world."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    r0 = res[0]
+    assert r0["wav"] < 2e-5 and r0["loss"] < 1e-5 and r0["grad"] < 2e-4, r0
 
 
 # ------------------------------------------------------------------------------------------------ bucketed exchange (DDP overlap)
@@ -314,7 +352,7 @@ def test_world2_fullsubnet_bucketed_exchange_equals_flat_gloo():
 # ------------------------------------------------------------------------------------------------ epoch-driver helpers (train_interface.run)
 def _driver_worker(rank, world, port, q):
     """broadcast_model (replicas start identical), all_reduce_autograd (the loss.backward() route of the direct-mapping / perceptual
-    trainers under DDP == the global-batch gradient), mean_scalars (validation losses), and the SI-SDR refusal."""
+    trainers under DDP == the global-batch gradient), mean_scalars (validation losses), and the sharded-loss switch."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, trainer
     from sefd_amd.ddp import GradientExchange
@@ -340,15 +378,12 @@ def _driver_worker(rank, world, port, q):
         err = max(float((a.grad - b.grad).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
         means = ex.mean_scalars([torch.tensor(float(rank + 1)), 10.0 * (rank + 1)])
         means += ex.mean_scalars([float(rank + 1)], weight=3 - 2 * rank)          # ragged shards: rank 0 ran 3 batches, rank 1 ran 1
-        cfg.loss = 'SI-SDR'
-        try:
-            trainer._exchange_grads(net, ex)
-            refused = False
-        except NotImplementedError:
-            refused = True
-        finally:
-            cfg.loss = 'SDR'
-        q.put((rank, same, err, means, refused))
+        # SI-SDR is no longer refused under DDP: the train functions run inside tools_for_loss.set_data_parallel(exchange)
+        from sefd_amd import tools_for_loss as tfl
+        prev = tfl.set_data_parallel(ex)
+        on = tfl._DP is ex and prev is None
+        tfl.set_data_parallel(None)
+        q.put((rank, same, err, means, on and tfl._DP is None))
     finally:
         dist.destroy_process_group()
 
@@ -370,6 +405,6 @@ def test_world2_epoch_driver_helpers_gloo():
         p.join(120)
         assert p.exitcode == 0
     res = [q.get(timeout=5) for _ in range(world)]
-    for rank, same, err, means, refused in res:
-        assert same and err < 1e-6 and refused, res
+    for rank, same, err, means, dp_switch in res:
+        assert same and err < 1e-6 and dp_switch, res
         assert means == [1.5, 15.0, 1.25], means          # (3 * 1 + 1 * 2) / 4: the mean over all four batches
