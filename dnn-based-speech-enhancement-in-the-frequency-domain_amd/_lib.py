@@ -75,6 +75,8 @@ def lib():
         "sefd_pmsqe_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
         "sefd_adam_step": (i32, [vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "sefd_adam_step_guarded": (i32, [vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]),
+        "sefd_adam_step_guarded_dp": (i32, [vp, vp, vp, vp, i64, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]),
+        "sefd_plan_status_poison": (i32, [vp, vp, vp]),
         "sefd_plan_status_word": (vp, [vp]),
         "sefd_plan_status": (i32, [vp, i32]),
         "sefd_plan_status_set": (i32, [vp]),
@@ -94,4 +96,4 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
             "sefd_plan_grad_bucket", "sefd_plan_grad_bucket_range", "sefd_plan_run_cb", "sefd_plan_run_flags", "sefd_plan_run_timed",
             "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_loss_rows_ws_floats", "sefd_loss_rows_forward", "sefd_loss_rows_backward", "sefd_loss_dp_offset", "sefd_loss_dp_finish", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
-            "sefd_adam_step", "sefd_adam_step_guarded", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set"]
+            "sefd_adam_step", "sefd_adam_step_guarded", "sefd_adam_step_guarded_dp", "sefd_plan_status_poison", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set"]

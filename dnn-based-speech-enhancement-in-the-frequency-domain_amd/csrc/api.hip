@@ -517,10 +517,16 @@ __global__ void loss_dp_finish_kernel(float* coef, int64_t ncoef, const float* d
   for (int64_t i = threadIdx.x; i < ncoef; i += blockDim.x) coef[i] *= f;
   if (threadIdx.x == 0 && loss_out) loss_out[0] = -k10 * logf(m + eps);
 }
+__global__ void status_poison_kernel(const int32_t* dstatus, float* elem) {
+  if (__hip_atomic_load(dstatus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) *elem = __builtin_nanf("");
+}
 static int rows_blocks(int64_t R) { const int64_t n = (R + 255) / 256; return (int)(n < kRowsMaxBlk ? n : kRowsMaxBlk); }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float bc2_sqrt,
-                                                  float b1, float b2, float eps, float gscale, const int32_t* skip) {
+                                                  float b1, float b2, float eps, float gscale, const int32_t* skip, const float* skip_nan) {
+  // skip_nan (data parallel): an element of the all-reduced gradient that a rank whose plan status was set replaced by NaN before the
+  // exchange (status_poison_kernel) - the sum carries it to every rank, so ALL replicas skip the same step and stay identical
+  if (skip_nan) { const float q = *skip_nan; if (q != q) return; }
   // skip: the device copy of the status word of the plan that produced g.  Set = a kernel of this step gave up and g is garbage:
   // parameters and moments stay as they are (the host raises at its next look at the host-mapped copy)
   if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
@@ -585,12 +591,21 @@ int32_t sefd_adam_step(float* param, const float* grad, float* exp_avg, float* e
 }
 int32_t sefd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                                float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_if_set, void* stream) {
+  return sefd_adam_step_guarded_dp(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, skip_if_set, nullptr, stream);
+}
+int32_t sefd_plan_status_poison(const sefd_plan* h, float* grad_elem, void* stream) {
+  if (!h || !grad_elem || !plan_status_word(h)) return -1;
+  hipLaunchKernelGGL(status_poison_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), h->dstatus, grad_elem);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int32_t sefd_adam_step_guarded_dp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, float lr, float beta1,
+                                  float beta2, float eps, float grad_scale, const int32_t* skip_if_set, const float* skip_if_nan, void* stream) {
   if (n < 1 || step < 1) return -1;
   const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1), (float)std::sqrt(bc2),
-                     beta1, beta2, eps, grad_scale, skip_if_set);
+                     beta1, beta2, eps, grad_scale, skip_if_set, skip_if_nan);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 }

@@ -559,6 +559,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // forward of that layer: y [Rr][C] -> z
   auto cbn_fwd = [&](int tag, const std::string& pp, const std::string& nm, Ptr y, Ptr z, int C, int64_t Rr) -> Ptr {
     if ((C / 2) % 4 != 0) { P->error = "ComplexBatchNorm: channel pairs per layer must be a multiple of 4"; return b.none(); }
+    if (C / 2 > 1024) { P->error = "ComplexBatchNorm: at most 1024 channel pairs per layer (cbn.hip reduces a row of pairs in one workgroup)"; return b.none(); }
     CbnFwd c;
     std::memset(&c, 0, sizeof(c));
     const int h = C / 2;

@@ -346,6 +346,9 @@ class _SefdModule(nn.Module):
         else:
             rt.run(PHASE_BWD)
         if exchange is not None and exchange.active:         # DDP: sum gradients over ranks (RCCL), average inside Adam
+            # a rank whose plan gave up poisons an element of the LAST bucket: every rank's Adam then skips this step (optim.step_flat)
+            optimizer.nan_guard = self._dp_guard = self._flat_grad[0:1]
+            rt.plan.status_poison(optimizer.nan_guard, stream)
             if bucket is not None:
                 exchange.begin(self._flat_grad[:bucket[1]])
                 exchange.finish(self._flat_grad)
@@ -713,6 +716,8 @@ class FullSubNet(_SefdModule):
         else:
             plan.run(PHASE_BWD, ar, stream)
         if exchange is not None and exchange.active:
+            optimizer.nan_guard = self._dp_guard = self._flat_grad[-1:]          # in the last bucket, see _SefdModule.train_step
+            plan.status_poison(optimizer.nan_guard, stream)
             if bucket is not None:
                 for a, z in ((0, bucket[1]), (bucket[2], self._flat_grad.numel())):
                     if z > a:

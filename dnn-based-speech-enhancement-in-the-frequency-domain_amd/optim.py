@@ -61,13 +61,17 @@ class Adam(torch.optim.Optimizer):
         # timeout) set it earlier on this stream, and the update is then skipped on the device - no garbage step, no host sync here
         plan = getattr(m, "_status_plan", None)
         guard = plan.status_word() if plan is not None else None
-        rc = _lib.lib().sefd_adam_step_guarded(C.c_void_p(m._flat_param.data_ptr()), C.c_void_p(g.data_ptr()),
-                                               C.c_void_p(self._m.data_ptr()), C.c_void_p(self._v.data_ptr()),
-                                               m._flat_param.numel(), self._step, grp["lr"], grp["betas"][0], grp["betas"][1],
-                                               grp["eps"], self.grad_scale, C.c_void_p(guard) if guard else None,
-                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        # data parallel (train_step sets nan_guard to the poisoned element of the last all-reduced bucket): EVERY rank skips a step that any
+        # rank's plan gave up on - the replicas stay identical (Plan.status_poison)
+        nan_guard, self.nan_guard = getattr(self, "nan_guard", None), None
+        rc = _lib.lib().sefd_adam_step_guarded_dp(C.c_void_p(m._flat_param.data_ptr()), C.c_void_p(g.data_ptr()),
+                                                  C.c_void_p(self._m.data_ptr()), C.c_void_p(self._v.data_ptr()),
+                                                  m._flat_param.numel(), self._step, grp["lr"], grp["betas"][0], grp["betas"][1],
+                                                  grp["eps"], self.grad_scale, C.c_void_p(guard) if guard else None,
+                                                  C.c_void_p(nan_guard.data_ptr()) if nan_guard is not None else None,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"sefd_adam_step_guarded failed ({rc})")
+            raise RuntimeError(f"sefd_adam_step_guarded_dp failed ({rc})")
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -187,6 +187,12 @@ class Plan:
         """Address of the device copy of the word (sefd_adam_step_guarded's skip_if_set)."""
         return self.lib.sefd_plan_status_word(self.h)
 
+    def status_poison(self, grad_elem, stream):
+        """Data parallel: NaN into `grad_elem` (a one-element view of the LAST gradient bucket) if this plan's status word is set - the
+        all-reduce then tells every rank (sefd_adam_step_guarded_dp's skip_if_nan)."""
+        if self.lib.sefd_plan_status_poison(self.h, C.c_void_p(grad_elem.data_ptr()), C.c_void_p(stream)) != 0:
+            raise RuntimeError("sefd_plan_status_poison failed")
+
     def status(self, clear=False):
         return int(self.lib.sefd_plan_status(self.h, 1 if clear else 0))
 

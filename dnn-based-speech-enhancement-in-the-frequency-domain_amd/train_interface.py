@@ -48,12 +48,24 @@ def build_model(DEVICE):
 def save_checkpoint(path, model, optimizer, epoch):
     """train_interface.py:166-171 / 204-210.  A step whose kernels gave up (Plan.status) never reached the parameters (guarded Adam), but it
     is an error all the same: checked here, behind a device synchronisation, BEFORE anything is written."""
-    plan = getattr(model, "_status_plan", None)
-    if plan is not None:
-        torch.cuda.synchronize()
-        if plan.status() != 0:
-            raise RuntimeError("checkpoint not written" + plan._RC5)
+    check_step_status(model)
     torch.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch}, path)
+
+
+def check_step_status(model):
+    """Raises when a kernel of the model's last plan gave up (this rank), or - data parallel - when ANY rank's did: the poisoned element of
+    the all-reduced gradient (Plan.status_poison) is NaN on every rank, so all of them stop here instead of one raising and the others
+    hanging in the next collective."""
+    plan = getattr(model, "_status_plan", None)
+    if plan is None:
+        return
+    torch.cuda.synchronize()
+    if plan.status() != 0:
+        raise RuntimeError("checkpoint not written" + plan._RC5)
+    guard = getattr(model, "_dp_guard", None)
+    if guard is not None and bool(torch.isnan(guard).any()):
+        raise RuntimeError("checkpoint not written: another rank's plan gave up during the last step (its status word reached this rank "
+                           "through the gradient all-reduce); every replica skipped that update")
 
 
 def load_checkpoint(path, model, optimizer, map_location=None):
@@ -100,10 +112,16 @@ def run(train_loader, validation_loader, model=None, optimizer=None, writer=None
         mse_vali_total = np.zeros(max_epochs)
         t = time.localtime()
         tag = cfg.expr_num + '_%d.%d' % (t.tm_mon, t.tm_mday) + '_%s' % cfg.model + '_%s' % cfg.loss
+        if exchange is not None and exchange.world > 1:
+            # one directory name for the whole job: rank 0's clock decides (a midnight rollover between the ranks would split it)
+            import torch.distributed as dist
+            box = [tag]
+            dist.broadcast_object_list(box, src=0, group=exchange.pg)
+            tag = box[0]
         dir_to_save, dir_to_logs = cfg.job_dir + tag, cfg.logs_dir + tag
     fp = None
+    os.makedirs(dir_to_save, exist_ok=True)          # every rank: each one writes its own score file there (no shared file system assumed)
     if master:
-        os.makedirs(dir_to_save, exist_ok=True)
         os.makedirs(dir_to_logs, exist_ok=True)
         log_fname = str(dir_to_save + '/log.txt')
         fresh = not os.path.exists(log_fname)
@@ -124,6 +142,8 @@ def run(train_loader, validation_loader, model=None, optimizer=None, writer=None
         if hasattr(train_loader, "set_epoch"):
             train_loader.set_epoch(epoch)
         res = trainer(model, optimizer, train_loader, DEVICE, **kw)
+        if exchange is not None and exchange.world > 1 and not master:
+            check_step_status(model)                                  # every rank looks before the collectives of the validation
         if master:                                                    # replicas are identical: same start (broadcast above), same averaged gradients
             save_checkpoint(str(dir_to_save + '/' + ('chkpt_%d.pt' % epoch)), model, optimizer, epoch)
         # every rank validates AND scores its shard; losses (what picks chkpt_opt), PESQ and STOI are averaged over the ranks weighted by

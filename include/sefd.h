@@ -190,6 +190,13 @@ int32_t sefd_adam_step_guarded(float* param, const float* grad, float* exp_avg, 
  * it (after a stream synchronisation for a definite answer) and optionally clears both copies; sefd_plan_status_set sets both from the
  * host (test hook: what a kernel that gives up does). */
 const int32_t* sefd_plan_status_word(const sefd_plan* p);
+/* Data parallel: a rank whose status word is set must not hand its gradient to the others as if it were good, and the replicas must take the
+ * same decision.  sefd_plan_status_poison (enqueued behind the backward, in front of the last gradient all-reduce) overwrites *grad_elem - an
+ * element of that last bucket - with NaN when the word is set; the sum carries the NaN to every rank; sefd_adam_step_guarded_dp skips the
+ * update on every rank while *skip_if_nan is NaN (and, as before, while *skip_if_set != 0).  No extra collective. */
+int32_t sefd_plan_status_poison(const sefd_plan* p, float* grad_elem, void* stream);
+int32_t sefd_adam_step_guarded_dp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, float lr, float beta1,
+                                  float beta2, float eps, float grad_scale, const int32_t* skip_if_set, const float* skip_if_nan, void* stream);
 int32_t sefd_plan_status(const sefd_plan* p, int32_t clear);
 int32_t sefd_plan_status_set(const sefd_plan* p);
 

@@ -800,3 +800,41 @@ def test_plan_status_word_guards_adam_and_checkpoint(tmp_path):
     m.train_step(x, y, opt)
     torch.cuda.synchronize()
     assert not torch.equal(m._flat_param, before)
+
+
+def test_status_poison_reaches_every_replica_through_the_gradient(tmp_path):
+    """ADVICE r4 (guarded Adam under data parallelism): a rank whose plan gave up replaces one element of the last gradient bucket by NaN before
+    the exchange (Plan.status_poison); a sum all-reduce hands that NaN to every rank, whose Adam (skip_if_nan) then skips the SAME step, and
+    every rank's checkpoint check raises.  Emulated on one GPU: the 'other rank' is a model whose own status word is clean and whose gradient
+    received the poisoned element by addition, as the all-reduce would deliver it."""
+    from sefd_amd import train_interface
+    from sefd_amd.optim import Adam
+    bad, good = (make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR") for _ in range(2))
+    x, y = make_signals(2, 4000)
+    x, y = x.cuda(), y.cuda()
+    opts = [Adam(m.parameters(), lr=1e-3) for m in (bad, good)]
+    for m, o in zip((bad, good), opts):
+        m.train()
+        m.train_step(x, y, o)
+    stream = torch.cuda.current_stream().cuda_stream
+    good._status_plan.status_poison(good._flat_grad[0:1], stream)        # clean word: the element stays a number
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(good._flat_grad[0]))
+    bad._status_plan.status_set()
+    bad._status_plan.status_poison(bad._flat_grad[0:1], stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(bad._flat_grad[0])) and bool(torch.isfinite(bad._flat_grad[1:]).all())
+    good._flat_grad += bad._flat_grad                                    # the sum all-reduce, as the clean rank sees it
+    before, mom = good._flat_param.clone(), opts[1]._m.clone()
+    opts[1].nan_guard = good._dp_guard = good._flat_grad[0:1]
+    opts[1].step_flat()
+    torch.cuda.synchronize()
+    assert torch.equal(good._flat_param, before) and torch.equal(opts[1]._m, mom)          # skipped on the clean rank too
+    with pytest.raises(RuntimeError, match="another rank"):
+        train_interface.save_checkpoint(str(tmp_path / "c.pt"), good, opts[1], 1)
+    good._flat_grad[0] = 0.0
+    opts[1].nan_guard = good._flat_grad[0:1]
+    opts[1].step_flat()
+    torch.cuda.synchronize()
+    assert not torch.equal(good._flat_param, before)
+    bad._status_plan.status(clear=True)
