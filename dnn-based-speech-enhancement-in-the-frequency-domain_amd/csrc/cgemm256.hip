@@ -140,6 +140,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
         if (q / 2 != hf) continue;
+        if ((dbg & 64) && q != 0) continue;                    // 64: one of the four A instructions only (traffic of an LDS-resident input slab)
         const uint16_t* src = (j0 >= jlo[q] && j0 + 8 <= jhi[q] && !(dbg & 32)) ? rptr[q] + j0 : zp;
         dma16(src, A + (q * NW + wid) * 1024);
       }
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
       const char* abase = smem + c_slot * A_SLOT + aoff;
       c_slot = c_slot + 1 == NAS ? 0 : c_slot + 1;
       const char* bbase = smem + ((gk + p) & 1) * 2 * B_SLOT + boff;
-      if (has1 && !(dbg & 2)) wait_vm<NA>(); else wait_vm<0>();   // A(p), B(p) have landed (this thread's part); only A(p+1) may be in flight
+      if (has1 && !(dbg & 2)) wait_vm<(dbg & 64) ? 1 : NA>(); else wait_vm<0>();   // A(p), B(p) have landed (this thread's part); only A(p+1) may be in flight
       wg_barrier();                                        // ... everyone's part; and every wave has finished K tile p - 1: its slots may be refilled
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -451,6 +452,7 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
     case 4: SEFD_CG256_LAUNCH(4); break;
     case 8: SEFD_CG256_LAUNCH(8); break;
     case 32: SEFD_CG256_LAUNCH(32); break;
+    case 64: SEFD_CG256_LAUNCH(64); break;
     default: SEFD_CG256_LAUNCH(0); break;
   }
 #undef SEFD_CG256_LAUNCH

@@ -1131,6 +1131,7 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
 }
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (launch_slabgemm(d, ab, st)) return;                  // convolutions with an LDS-resident input slab (slabgemm.hip)
   if (launch_cgemm256(d, ab, st)) return;                  // wide-tile kernel for the N >= 128 bf16 layers (cgemm256.hip)
   if (launch_rundirect(d, ab, st)) return;                 // direct-operand kernel for the thin bf16 layers (thin.hip)
   if (d.xdt == DT_BF16) launch_rungemm_t<bf16_t>(d, ab, st);

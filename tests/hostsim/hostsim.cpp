@@ -60,7 +60,7 @@ void rungemm(const RunGemm& d, const AB& ab) {
     const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
     for (int nn = 0; nn < d.N; ++nn) {
       double acc = 0.0;
-      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, w_index(d.flags, d.ldw, d.Npad, nn, k));
+      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, w_index_g(d, nn, k));
       float v = (float)acc + (bias ? bias[nn] : 0.f);
       const bool second = d.n2 > 0 && nn >= d.n2;             // two destinations: columns >= n2 go to y2 at column n - n2
       char* y = second ? rp(ab, d.y2) : y1;
