@@ -226,7 +226,16 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   }
   if (!h->side) {
     // (a lowest-priority side stream was measured: 14.44 / 14.57 vs 14.33 / 14.42 ms per step with equal priorities - kept equal)
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return -3;
+    // SEFD_SIDE_CUS=N (tuning): the second lane's stream is confined to N of the chip's CUs, spread evenly over the XCDs
+    // (hipExtStreamCreateWithCUMask), so that the weight gradients stop time-slicing every CU with the main lane's 160 KB-LDS GEMMs.  Measured
+    // (profiles/r05_tuning_notes.md): no N beats the unmasked stream - the default stays unmasked.
+    const int side_cus = getenv("SEFD_SIDE_CUS") ? atoi(getenv("SEFD_SIDE_CUS")) : 0;
+    if (side_cus > 0 && side_cus < 256) {
+      uint32_t mask[8] = {0};
+      for (int i = 0; i < 256; ++i)
+        if ((i + 1) * side_cus / 256 > i * side_cus / 256) mask[i >> 5] |= 1u << (i & 31);
+      if (hipExtStreamCreateWithCUMask(&h->side, 8, mask) != hipSuccess) return -3;
+    } else if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return -3;
     if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) return -3;

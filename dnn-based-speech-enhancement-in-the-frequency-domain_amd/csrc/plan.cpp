@@ -388,14 +388,10 @@ static bool slab_layout(RunGemm& g, int Tout) {
   const int nfs = NF + 1 + kmax;
   int best_c = 99, best_rows = 1 << 30;
   for (int split = (S == 2 ? 1 : 0); split >= 0; --split)
-    for (int padh = 0; padh < 8; ++padh)
-      for (int padf = 0; padf < 4; ++padf)
+    for (int NPp = NP; NPp * nfs <= kSlabMaxRows; ++NPp)
+      for (int NPh = split ? (NP + 1) / 2 : 0; NPh <= (split ? NPp / 2 : 0); ++NPh)
         for (int shift = 2; shift <= 3; ++shift) {
-          if (!split && padh) continue;
-          const int NPh = split ? (NP + 1) / 2 + padh : 0;
-          const int NPp = split ? 2 * NPh + padf : NP + padf;
           const int rows = nfs * NPp;
-          if (rows > kSlabMaxRows) continue;
           const int c = slab_conflicts(Fo, S, ntap, NPp, NPh, shift);
           if (c < best_c || (c == best_c && rows < best_rows)) {
             best_c = c; best_rows = rows;
@@ -478,9 +474,11 @@ void finalize_rungemms(Builder& b, Plan* P) {
     }
   // LDS-resident input slab (slabgemm.hip, kRunSlab) for the (t, f) convolutions: every source has two runs (dt, dt + 1) of ntap frequency taps x C
   // channels, C % 32 == 0, Fo a power of two, bf16 in and out.  The packed weights go to [source][chunk][run][tap][32] order (w_index_g): like
-  // kRunWTile32 a property of the packed BUFFER, so only when every reader agrees.  SEFD_SLAB=0: off (A/B runs).  SEFD_SLAB_MINM: fewest rows.
+  // kRunWTile32 a property of the packed BUFFER, so only when every reader agrees.  SEFD_SLAB=1: on.  SEFD_SLAB_MINM: fewest rows.
   {
-    const bool on = !(getenv("SEFD_SLAB") && atoi(getenv("SEFD_SLAB")) == 0);
+    // OPT-IN (SEFD_SLAB=1): measured on MI355X (profiles/r05_tuning_notes.md) the kernel is parity-green but 3-8 % slower than rungemm / cgemm256 on the
+    // same layers - its loop trades LDS-DMA issue for fragment-address arithmetic and loses the two-workgroups-per-CU overlap of the 128-row kernel
+    const bool on = getenv("SEFD_SLAB") && atoi(getenv("SEFD_SLAB")) == 1;
     const int minm = getenv("SEFD_SLAB_MINM") ? atoi(getenv("SEFD_SLAB_MINM")) : 16384;
     std::vector<Op*> all;
     for (auto* ops : {&P->fwd, &P->bwd})
@@ -585,6 +583,9 @@ void finalize_rungemms(Builder& b, Plan* P) {
           for (int s = 0; s < 2; ++s)
             if (g.x[s].arena >= 0) fprintf(stderr, "    src%d bstride=%lld tstride=%d base=%d rowlen=%d fstride=%d Tin=%d\n", s, (long long)g.bstride[s], g.tstride[s], g.base[s], g.rowlen[s], g.fstride[s], g.Tin[s]);
           for (int s = 0; s < g.nseg; ++s) fprintf(stderr, "    seg%d src=%d dt=%d off=%d len=%d koff=%d\n", s, g.seg[s].src, g.seg[s].dt, g.seg[s].off, g.seg[s].len, g.seg[s].koff);
+          if (g.flags & kRunSlab)
+            fprintf(stderr, "    slab C=%d,%d S=%d ntap=%d p0=%d np=%d nph=%d swz=%d dtmin=%d conflicts=%d rows=%d\n", g.slab_C[0], g.slab_C[1], g.slab_S, g.slab_ntap, g.slab_p0, g.slab_np,
+                    g.slab_nph, g.slab_swz, g.slab_dtmin, slab_conflicts(g.Fo, g.slab_S, g.slab_ntap, g.slab_np, g.slab_nph, g.slab_swz), (256 / g.Fo + 2) * g.slab_np);
         }
         ++i;
       }

@@ -41,19 +41,21 @@ __device__ __forceinline__ int xcd_remap3(int bid, int nwg) {
 
 __device__ __forceinline__ void wgb() { asm volatile("s_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void wait_vm_n(int n) {           // n is wave-uniform
-  if (n <= 0) wait_vm<0>();
-  else if (n == 1) wait_vm<1>();
-  else if (n == 2) wait_vm<2>();
-  else if (n == 3) wait_vm<3>();
-  else if (n == 4) wait_vm<4>();
-  else if (n == 5) wait_vm<5>();
+__device__ __forceinline__ void wait_vm_n(int n) {           // n is wave-uniform, 0 .. 6
+  if (n < 2) { if (n < 1) wait_vm<0>(); else wait_vm<1>(); }
+  else if (n < 4) { if (n < 3) wait_vm<2>(); else wait_vm<3>(); }
+  else if (n < 5) wait_vm<4>();
+  else if (n < 6) wait_vm<5>();
   else wait_vm<6>();
 }
 
 }  // namespace
 
-template <int BN, int WM, int WN, bool BNB>
+// dbg (tuning runs only, SEFD_SLAB_DBG): 1 skip the MFMAs, 2 skip the weight DMAs, 4 skip the fragment reads, 8 skip the slab DMAs, 16 no fragment
+// address arithmetic (every tap reads the rows of tap 0)
+// NBS: weight sub-slots.  4: the weights of pair P + 1 are issued during pair P.  6: those of pair P + 2 - the barrier at the top of pair P then
+// publishes pair P + 1 as well, and the first fragments of pair P + 1 are read in front of its barrier (no read bubble behind every barrier).
+template <int BN, int WM, int WN, bool BNB, int NBS, int dbg = 0>
 __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int BM = 256, NW = 8;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
@@ -62,9 +64,11 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
   constexpr int B_BASE = 2 * SLAB;
   constexpr int NBH = BN / 16 / NW;                          // weight DMAs per thread per sub-tile (16 rows x 64 B each)
   constexpr int NQ = (kSlabMaxRows / 16 + NW - 1) / NW;      // slab DMAs per thread per chunk, at most
-  constexpr int STAT_BASE = B_BASE + 4 * B_SUB;
+  constexpr int NRING = NBS / 2, AHEAD = NRING - 1;           // pairs in the weight ring; pairs the weight stream runs ahead
+  constexpr bool PF = NBS == 6;                              // cross-barrier prefetch of a pair's first fragments
+  constexpr int STAT_BASE = B_BASE + NBS * B_SUB;
   constexpr int SMEM = STAT_BASE + (WM == 4 ? NW * WTN * 2 * 4 : 0);
-  static_assert(WM * WN == NW && NBH >= 1 && SMEM <= 160 * 1024 && (SLAB % 2048) == 0 && (!BNB || WM == 2), "geometry");
+  static_assert(WM * WN == NW && NBH >= 1 && SMEM <= 160 * 1024 && (SLAB % 2048) == 0 && (!BNB || WM == 2) && (NBS == 4 || NBS == 6), "geometry");
   __shared__ __attribute__((aligned(2048))) char smem[SMEM];
 
   const int tid = threadIdx.x;
@@ -78,20 +82,16 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
   const int ntap = d.slab_ntap, NT = 2 * ntap;               // taps per chunk; pairs per chunk = ntap
   const int S = d.slab_S, NPp = d.slab_np, NPh = d.slab_nph, swz = d.slab_swz + 6;
   const int NP = (Fo - 1) * S + ntap;                        // positions a frame's rows touch
-  int nsrc = 1;
-  int dtr[2][2] = {{0, 0}, {0, 0}};                          // frame-slot offset (dt - dtmin) of run `rank` of source s
-  {
-    int rk[2] = {0, 0};
-    for (int s = 0; s < d.nseg; ++s) {
-      const int sc = d.seg[s].src;
-      if (sc < 0) continue;
-      if (sc == 1) nsrc = 2;
-      if (rk[sc] < 2) dtr[sc][rk[sc]] = d.seg[s].dt - d.slab_dtmin;
-      ++rk[sc];
-    }
-  }
+  // planner contract (slab_geometry): runs 0, 1 belong to source 0, runs 2, 3 (if any) to source 1
+  const int nsrc = d.nseg == 4 ? 2 : 1;
+  const int dtr00 = d.seg[0].dt - d.slab_dtmin, dtr01 = d.seg[1].dt - d.slab_dtmin;   // frame-slot offset (dt - dtmin) of run `rank` of source s
+  const int dtr10 = nsrc == 2 ? d.seg[2].dt - d.slab_dtmin : 0, dtr11 = nsrc == 2 ? d.seg[3].dt - d.slab_dtmin : 0;
   const int nch0 = d.slab_C[0] >> 5, NCH = nch0 + (nsrc == 2 ? d.slab_C[1] >> 5 : 0);
-  const int nslots = 2 * (ntap - 1);                         // slab issue slots of a chunk: steps 2 and 3 of every pair but the last
+  // slab issue slots of a chunk: the four steps of every pair but the last two, steps 0-1 of the pair before the last - at the top of a chunk's last
+  // pair `vmcnt(0)` then has nothing younger than two steps to wait for, and the barrier there publishes the next chunk's slab whole
+  // (dbg 32: all four steps of every pair but the last two + steps 0-1 of the pair before the last - what the 6-sub-slot ring needs so that the
+  // barrier in front of a chunk's last pair publishes the next slab whole; measured slower than the default: steps 2-3 of every pair but the last)
+  const int nslots = (dbg & 32) ? 4 * (ntap - 2) + 2 : 2 * (ntap - 1);
 
   const uint16_t* x0 = reinterpret_cast<const uint16_t*>(rp(ab, d.x[0]));
   const uint16_t* x1 = nsrc == 2 ? reinterpret_cast<const uint16_t*>(rp(ab, d.x[1])) : x0;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
   const float bslope = BNB ? *reinterpret_cast<const float*>(rp(ab, d.bnb_slope)) : 0.f;
 
   // ---- stream state (carried across output tiles)
-  int gp = 0;                                                // pairs finished: weight sub-slots ((gp & 1) * 2 + h)
+  int gr = 0;                                                // ring position gp % NRING of the pair being multiplied: weight sub-slots gr * 2 + h
   int gch = 0;                                               // chunks finished: slab buffer gch & 1
   // slab DMA cursor: the chunk being loaded is chunk d_ch of output tile d_t (-1: none), into buffer d_buf
   int d_t = -1, d_ch = 0, d_buf = 0, d_nq = 0, d_src = 0;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
   auto issue_piece = [&](int q) {                            // piece q of the chunk under the cursor
     const int cc = d_ch - (d_src ? nch0 : 0);
     const uint16_t* src = poff[q] >= 0 ? (d_src ? x1 : x0) + poff[q] + cc * 32 : zp;
-    dma16(src, lds0 + d_buf * SLAB + (q * NW + wid) * 1024);
+    if (!(dbg & 8)) dma16(src, lds0 + d_buf * SLAB + (q * NW + wid) * 1024);
   };
   // pieces of issue slot `slot` (q mod nslots == slot); returns how many this wave issued
   auto issue_slot = [&](int slot) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
     if (d_t < 0) return 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int qs = nslots >= NQ ? q : (nslots == 4 ? (q & 3) : (q & 1));
+      const int qs = nslots >= NQ ? q : (nslots == 4 ? (q & 3) : (q & 1));   // (ntap 2: two slots)
       if (qs == slot && q < d_nq) { issue_piece(q); ++n; }
     }
     return n;
@@ -182,17 +182,18 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
     d_t = nt; d_ch = nc;
     if (nt >= 0 && (nc == 0 || nc == nch0)) setup_pieces(nt, nc >= nch0 ? 1 : 0);
   };
+  const int64_t wstep = (int64_t)d.Npad * 32;                // elements per 32-deep sub-tile
   auto b_set = [&](int t) {                                  // weight cursor to sub-tile 0 of tile t
     b_t = t; b_st = 0;
     if (t >= 0) b_ptr = w + ((int64_t)tile_n(t) * BN + wid * 16 + lb) * 32 + csb * 8;
   };
   // half h of the weights of the pair under the cursor into sub-slot (par * 2 + h); the cursor advances with the second half
-  auto issue_b = [&](int par, int h) {
+  auto issue_b = [&](int ring, int h) {
     if (b_t >= 0) {
-      const uint32_t B = lds0 + B_BASE + (par * 2 + h) * B_SUB;
-      const uint16_t* src = b_ptr + (int64_t)(b_st + h) * d.Npad * 32;
+      const uint32_t B = lds0 + B_BASE + (ring * 2 + h) * B_SUB;
 #pragma unroll
-      for (int q = 0; q < NBH; ++q) dma16(src + q * (NW * 16 * 32), B + (q * NW + wid) * 1024);
+      for (int q = 0; q < NBH; ++q) if (!(dbg & 2)) dma16(b_ptr + q * (NW * 16 * 32), B + (q * NW + wid) * 1024);
+      b_ptr += wstep;
     }
     if (h == 1 && b_t >= 0) {
       b_st += 2;
@@ -205,7 +206,11 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
     setup_pieces(t, 0);
     issue_all_pieces();
     b_set(t);
-    issue_b(gp & 1, 0); issue_b(gp & 1, 1);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) {
+      const int ring = gr + a >= NRING ? gr + a - NRING : gr + a;
+      issue_b(ring, 0); issue_b(ring, 1);
+    }
     pend = 0;
   };
 
@@ -239,49 +244,80 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int sc = ch >= nch0 ? 1 : 0;
-      const uint32_t sbuf = lds0 + (gch & 1) * SLAB;
-      advance_slab(t, ch);                                   // the chunk loaded during this one
-      for (int pc = 0; pc < ntap; ++pc) {
-        wait_vm_n(pend);                                     // this pair's weights (and, at a chunk's first pair, its slab) have landed - this thread's part
-        wgb();                                               // ... everyone's; and every wave is past the previous pair: its sub-slots / the other slab buffer may be refilled
-        pend = 0;
-        const int par = gp & 1;
+    // ---- the tile's pairs of taps, one flat loop: chunk ch, pair pc of the chunk, (rk, df) = run rank and frequency tap of the pair's first tap
+    const int NPT = NCH * ntap;
+    int ch = 0, pc = 0, rk = 0, df = 0;
+    uint32_t sbuf = lds0 + (gch & 1) * SLAB;
+    uint32_t sb0 = sbuf + dtr00 * NPp * 64, sb1 = sbuf + dtr01 * NPp * 64;      // slab row 0 of the frame slots of the chunk's two runs
+    auto tap_base = [&]() { return (rk ? sb1 : sb0) + (NPh > 0 ? (df & 1) * NPh + (df >> 1) : df) * 64; };
+    auto tap_next = [&]() { if (++df == ntap) { df = 0; rk = 1; } };
+    // fragment address of a tap, step 0 (step 1: ^ 32): unit = ((row >> swz) & 3) ^ octet, octet = 2 * step + half
+    uint32_t aA[MI], aB[MI];
+#define SLAB_ADDR(AX)                                                                                        \
+  {                                                                                                          \
+    const uint32_t tb_ = (dbg & 16) ? sbuf : tap_base();                                                     \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                         \
+      const uint32_t r_ = tb_ + Rb[i];                                                                       \
+      AX[i] = r_ + ((((r_ >> swz) & 3) ^ (uint32_t)fhalf) << 4) - lds0;                                      \
+    }                                                                                                        \
+  }
+#define SLAB_READ(AF, BF, AA, BB, X)                                                                         \
+  if (!(dbg & 4)) {                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) AF[i] = *reinterpret_cast<const uint4*>(smem + (AA[i] ^ (X))); \
+  _Pragma("unroll") for (int j = 0; j < NI; ++j) BF[j] = *reinterpret_cast<const uint4*>(smem + ((BB) ^ (X)) + j * (32 * 64)); }
+#define SLAB_MFMA(AF, BF, DMA)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                           \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) if (!(dbg & 1))                                           \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AF[i]), __builtin_bit_cast(bf16x8, BF[j]), acc[i][j], 0, 0, 0); \
+    if (i == MI / 2 - 1) { __builtin_amdgcn_sched_barrier(0); DMA; __builtin_amdgcn_sched_barrier(0); }      \
+  }
+    SLAB_ADDR(aA)
+    uint4 af0[MI], bf0[NI], af1[MI], bf1[NI];
+    if (dbg & 4) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int tau = 2 * pc + (s >> 1);
-          const int rk = tau >= ntap ? 1 : 0, df = tau - rk * ntap;
-          const int toff = ((sc ? dtr[1][rk] : dtr[0][rk]) * NPp + (NPh > 0 ? (df & 1) * NPh + (df >> 1) : df)) * 64;
-          const uint32_t bsub = (par * 2 + (s >> 1)) * B_SUB;
-          uint4 af[MI], bf[NI];
+      for (int i = 0; i < MI; ++i) af0[i] = af1[i] = make_uint4(aA[i], Rb[i], 0, 0);
 #pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            const uint32_t rowa = sbuf + Rb[i] + toff;                                     // 64-byte aligned
-            const uint32_t unit = ((rowa >> swz) & 3) ^ (uint32_t)(fhalf + 2 * (s & 1));    // octet 2 * step + half of the row
-            af[i] = *reinterpret_cast<const uint4*>(smem + (rowa - lds0) + (unit << 4));
-          }
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            bf[j] = *reinterpret_cast<const uint4*>(smem + ((boff0 ^ (32u * (s & 1))) - lds0) + bsub + j * (32 * 64));
-#pragma unroll
-          for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-            if (i == MI / 2 - 1) {                           // this step's DMAs behind the first half of its MFMAs
-              __builtin_amdgcn_sched_barrier(0);
-              if (s == 0) issue_b(par ^ 1, 0);
-              else if (s == 1) issue_b(par ^ 1, 1);
-              else if (pc + 1 < ntap) pend += issue_slot(2 * pc + (s & 1));
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
-        ++gp;
-      }
-      ++gch;
+      for (int j = 0; j < NI; ++j) bf0[j] = bf1[j] = make_uint4(boff0, lane, 0, 0);
     }
+    bool pf = false;                                         // set 0 already holds step 0 of this pair (read in front of the barrier)
+    for (int pp = 0; pp < NPT; ++pp) {
+      if (pc == 0) advance_slab(t, ch);                      // the slab cursor moves to the chunk loaded during this one
+      tap_next();
+      SLAB_ADDR(aB)
+      tap_next();
+      const uint32_t bA = boff0 - lds0 + (gr * 2) * B_SUB, bB = bA + B_SUB;
+      const int grn = gr + 1 == NRING ? 0 : gr + 1;                    // ring position of the next pair
+      const int gri = gr + AHEAD >= NRING ? gr + AHEAD - NRING : gr + AHEAD;   // ... of the pair whose weights are issued now
+      wait_vm_n(pend);                                       // the newest weights (and, in front of a chunk's last pair, its successor's slab) have landed - this thread's part
+      wgb();                                                 // ... everyone's; and every wave is past the previous pair: its sub-slots / the other slab buffer may be refilled
+      pend = 0;
+      if (!PF || !pf) { SLAB_READ(af0, bf0, aA, bA, 0u) }
+      SLAB_READ(af1, bf1, aA, bA, 32u)
+      const int slot = (dbg & 32) ? 4 * pc : 2 * pc - 2;
+      const bool more = (dbg & 32) ? pc + 2 < ntap : pc + 1 < ntap;                       // steps 2-3 carry slab pieces
+      SLAB_MFMA(af0, bf0, issue_b(gri, 0); if ((dbg & 32) && pc + 1 < ntap) issue_slot(slot))
+      SLAB_READ(af0, bf0, aB, bB, 0u)
+      SLAB_MFMA(af1, bf1, issue_b(gri, 1); if ((dbg & 32) && pc + 1 < ntap) issue_slot(slot + 1))
+      SLAB_READ(af1, bf1, aB, bB, 32u)
+      SLAB_MFMA(af0, bf0, if (more) pend += issue_slot(slot + 2))
+      // on to the next pair: its chunk's slab buffer / run bases, its first tap's addresses - and with the deep ring its first fragments
+      if (++pc == ntap) {
+        pc = 0; ++ch; ++gch; rk = 0; df = 0;
+        sbuf = lds0 + (gch & 1) * SLAB;
+        const bool s1 = ch >= nch0;
+        sb0 = sbuf + (s1 ? dtr10 : dtr00) * NPp * 64; sb1 = sbuf + (s1 ? dtr11 : dtr01) * NPp * 64;
+      }
+      pf = false;
+      if (pp + 1 < NPT) {
+        SLAB_ADDR(aA)
+        if (PF) { SLAB_READ(af0, bf0, aA, (boff0 - lds0 + (grn * 2) * B_SUB), 0u) pf = true; }
+      }
+      SLAB_MFMA(af1, bf1, if (more) pend += issue_slot(slot + 3))
+      gr = grn;
+    }
+#undef SLAB_ADDR
+#undef SLAB_READ
+#undef SLAB_MFMA
     if (BNB) wgb();                                          // the kRunBnBwd epilogue writes LDS: every wave must be past the last pair
 
     if constexpr (BNB) {
@@ -463,12 +499,30 @@ bool launch_slabgemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   const int bn = d.Npad % 256 == 0 ? 256 : 128;
   const int total = ((d.M + 255) / 256) * (d.Npad / bn);
   const dim3 grid(total < ncu ? total : ncu);
-  if (bn == 256) {
-    if (d.flags & kRunBnBwd) hipLaunchKernelGGL((slabgemm_kernel<256, 2, 4, true>), grid, dim3(512), 0, st, d, ab);
-    else hipLaunchKernelGGL((slabgemm_kernel<256, 2, 4, false>), grid, dim3(512), 0, st, d, ab);
-  } else {
-    hipLaunchKernelGGL((slabgemm_kernel<128, 4, 2, false>), grid, dim3(512), 0, st, d, ab);
+  static const int dbg = getenv("SEFD_SLAB_DBG") ? atoi(getenv("SEFD_SLAB_DBG")) : 0;
+  // 6 sub-slots + reading a pair's first fragments in front of its barrier is only correct with the early slab schedule (SEFD_SLAB_DBG=32)
+  static const int nbs = (getenv("SEFD_SLAB_NBS") && atoi(getenv("SEFD_SLAB_NBS")) == 6 && dbg == 32) ? 6 : 4;
+#define SEFD_SLAB_LAUNCH(DBG)                                                                                                \
+  do {                                                                                                                       \
+    if (bn == 256) {                                                                                                         \
+      if (d.flags & kRunBnBwd) hipLaunchKernelGGL((slabgemm_kernel<256, 2, 4, true, 4, DBG>), grid, dim3(512), 0, st, d, ab);   \
+      else hipLaunchKernelGGL((slabgemm_kernel<256, 2, 4, false, 4, DBG>), grid, dim3(512), 0, st, d, ab);                      \
+    } else {                                                                                                                 \
+      if (nbs == 4) hipLaunchKernelGGL((slabgemm_kernel<128, 4, 2, false, 4, DBG>), grid, dim3(512), 0, st, d, ab);             \
+      else hipLaunchKernelGGL((slabgemm_kernel<128, 4, 2, false, 6, DBG>), grid, dim3(512), 0, st, d, ab);                      \
+    }                                                                                                                        \
+  } while (0)
+  switch (dbg) {
+    case 1: SEFD_SLAB_LAUNCH(1); break;
+    case 2: SEFD_SLAB_LAUNCH(2); break;
+    case 4: SEFD_SLAB_LAUNCH(4); break;
+    case 8: SEFD_SLAB_LAUNCH(8); break;
+    case 10: SEFD_SLAB_LAUNCH(10); break;
+    case 16: SEFD_SLAB_LAUNCH(16); break;
+    case 32: SEFD_SLAB_LAUNCH(32); break;
+    default: SEFD_SLAB_LAUNCH(0); break;
   }
+#undef SEFD_SLAB_LAUNCH
   return true;
 }
 

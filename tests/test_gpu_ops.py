@@ -38,16 +38,15 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 3, 4001, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # L = 4001 marks the cases that send every N <= 64 conv GEMM through the direct-operand kernel (thin.hip)
                                                         ("DCCRN", 1, 2403, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("DCCRN", 1, 2401, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L odd: marks the case that lowers SEFD_CG256_MINM -> wide-tile kernel on every N % 256 == 0 layer
-                                                        ("DCCRN", 1, 2405, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L = 2405 / 2407 / 7001 mark the cases that lower SEFD_SLAB_MINM -> LDS-slab kernel (slabgemm.hip) on every conv it can take
-                                                        ("DCCRN", 3, 2407, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # ... three batch items: tiles that cross batch boundaries (zero frame slots)
-                                                        ("DCCRN", 2, 7001, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # ... T = 71: tiles inside one item, Fo = 4 layers included
+                                                        ("DCCRN", 3, 2407, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L = 2407 / 4801 mark the cases that switch the opt-in LDS-slab kernel (slabgemm.hip) on for every conv it can take; three batch items: tiles cross batch boundaries (zero frame slots)
+                                                        ("DCCRN", 1, 4801, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # ... T = 49: tiles inside one item
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM (H = 256): cluster kernels, one partial row block
-                                                        ("DCCRN", 18, 7000, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),    # the same, two row blocks, T = 71: chunked forward
+                                                        ("DCCRN", 18, 3400, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),    # the same, two row blocks, T = 35: chunked forward
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 1024, "bf16"),    # H = 512: 8 workgroups per cluster
-                                                        ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "fp32"),     # wide LSTM in fp32: per-step path
-                                                        ("DCCRN", 2, 7000, "C", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # T = 71: chunked two-lane LSTM forward
+                                                        ("DCCRN", 2, 1200, "C", (16, 32, 32, 64, 64, 64), 512, "fp32"),     # wide LSTM in fp32: per-step path
+                                                        ("DCCRN", 2, 3400, "C", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # T = 35: chunked two-lane LSTM forward
                                                         ("DCCRN_CBN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),  # DCCRN(use_cbn=True): the six ComplexBatchNorm ops (cbn.hip)
-                                                        ("DCCRN_CBN", 2, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
+                                                        ("DCCRN_CBN", 1, 2400, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("CRN", 3, 4000, "E", (16, 32, 32, 64, 64, 64), 128, "fp32"),
                                                         ("CRN", 2, 2400, "E", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("FullSubNet", 2, 13, "E", (128, 64), 0, "fp32"),
@@ -74,9 +73,11 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     os.environ.pop("SEFD_DIRECT_MINM", None)
     os.environ.pop("SEFD_BN_FUSE", None)
     os.environ.pop("SEFD_SLAB_MINM", None)
-    slab_case = L in (2405, 2407, 7001)
+    os.environ.pop("SEFD_SLAB", None)
+    slab_case = L in (2407, 4801)
     if slab_case:
         L -= L % 100
+        os.environ["SEFD_SLAB"] = "1"          # opt-in kernel
         os.environ["SEFD_SLAB_MINM"] = "1"
         os.environ["SEFD_BN_FUSE"] = "2"   # kRunBnBwd epilogue of the slab kernel
     if L in (4001, 2403):                  # the direct-operand kernel takes GEMMs with M >= 65536 by default
@@ -108,6 +109,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model.split("_")[0], use_cbn=model == "DCCRN_CBN")
     os.environ.pop("SEFD_BN_FUSE", None)
     os.environ.pop("SEFD_SLAB_MINM", None)
+    os.environ.pop("SEFD_SLAB", None)
     if slab_case:
         nslab = sum(1 for ph in (PHASE_FWD, PHASE_BWD) for i in range(plan.num_ops(ph)) if plan.op_info(ph, i)["kind"] == 1 and plan.op_info(ph, i)["flags"] & 128)
         assert nslab >= 12, nslab                  # the case runs what it is named for
