@@ -14,7 +14,8 @@ class ModelConfig(C.Structure):
                 ("n_layers", C.c_int32), ("kernel_num", C.c_int32 * 12),
                 ("rnn_layers", C.c_int32), ("rnn_units", C.c_int32), ("mask_mode", C.c_int32),
                 ("lstm_complex", C.c_int32), ("skip", C.c_int32), ("act_dtype", C.c_int32),
-                ("kernel_size", C.c_int32), ("training", C.c_int32), ("bn_world", C.c_int32), ("grad_buckets", C.c_int32), ("use_cbn", C.c_int32), ("window", C.c_int32)]
+                ("kernel_size", C.c_int32), ("training", C.c_int32), ("bn_world", C.c_int32), ("grad_buckets", C.c_int32), ("use_cbn", C.c_int32), ("window", C.c_int32),
+                ("pad_", C.c_int32), ("window_values", C.POINTER(C.c_double))]
 
 
 _lib = None

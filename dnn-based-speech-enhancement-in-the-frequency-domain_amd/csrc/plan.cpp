@@ -358,6 +358,14 @@ struct Builder {
   }
 };
 
+// ConvSTFT / ConviSTFT window sample j (tools_for_model.py:17-20)
+static double window_value(const ModelConfig& cfg, int j, int W) {
+  const double kPi_ = 3.14159265358979323846;
+  if (cfg.window == 1) return 1.0;
+  if (cfg.window == 2 && cfg.window_values) return cfg.window_values[j];
+  return 0.5 - 0.5 * std::cos(2.0 * kPi_ * j / W);
+}
+
 int32_t pe(const ParamInfo& p, int64_t idx, int sign = 1) { return (int32_t)(sign * (p.off + idx + 1)); }
 
 
@@ -808,7 +816,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // ------------------------------------------------------------------ constants: STFT bases, OLA normaliser
   // analysis basis (tools_for_model.py:16-33): K[part*NF+k][j] = w[j]*{cos,-sin}(2 pi k j / NFFT); periodic Hann
   std::vector<double> win(W);
-  for (int j = 0; j < W; ++j) win[j] = cfg.window == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);    // win_type None: np.ones (tools_for_model.py:17-18)
+  for (int j = 0; j < W; ++j) win[j] = window_value(cfg, j, W);    // win_type None: np.ones (tools_for_model.py:17-18)
   auto Kun = [&](int part, int k, int j) {
     const double ang = 2.0 * kPi * (double)(((int64_t)k * j) % NFFT) / NFFT;
     return part == 0 ? std::cos(ang) : -std::sin(ang);
@@ -2071,7 +2079,7 @@ Plan* build_crn_plan(const ModelConfig& cfg) {
   Ptr io_tgt = b.io("tgt", (int64_t)B * L);
 
   std::vector<double> win(W);
-  for (int j = 0; j < W; ++j) win[j] = cfg.window == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);    // win_type None: np.ones (tools_for_model.py:17-18)
+  for (int j = 0; j < W; ++j) win[j] = window_value(cfg, j, W);    // win_type None: np.ones (tools_for_model.py:17-18)
   auto Kun = [&](int part, int k, int j) {
     const double ang = 2.0 * kPi * (double)(((int64_t)k * j) % NFFT) / NFFT;
     return part == 0 ? std::cos(ang) : -std::sin(ang);
@@ -2554,7 +2562,7 @@ Plan* build_frontend_plan(const ModelConfig& cfg) {
   Ptr io_or = b.io("out_real", (int64_t)B * NF * T);
   Ptr io_oi = b.io("out_imag", (int64_t)B * NF * T);
   std::vector<double> win(W);
-  for (int j = 0; j < W; ++j) win[j] = cfg.window == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * kPi * j / W);    // win_type None: np.ones (tools_for_model.py:17-18)
+  for (int j = 0; j < W; ++j) win[j] = window_value(cfg, j, W);    // win_type None: np.ones (tools_for_model.py:17-18)
   Ptr spec = b.ws("spec", (int64_t)B * T * SW, DT_F32);
   if (!b.stft_fft(P->fwd, 1, io_wav, spec, B, L, T, hop, trim, NFFT, win)) {
   RunGemm g = Builder::gemm0();

@@ -24,7 +24,9 @@ struct ModelConfig {
   int32_t bn_world;         // > 1: SyncBN over that many ranks (sync points, counts scaled)
   int32_t grad_buckets;     // 2: decoder + LSTM gradients unpacked before the encoder backward (DDP overlap)
   int32_t use_cbn;          // DCCRN: ComplexBatchNorm instead of BatchNorm2d
-  int32_t window;           // 0 periodic Hann, 1 rectangular (ConvSTFT win_type None)
+  int32_t window;           // 0 periodic Hann, 1 rectangular (ConvSTFT win_type None), 2 window_values
+  int32_t pad_;
+  const double* window_values;   // window == 2: win_len values (valid during build_plan only)
 };
 
 struct ParamInfo {

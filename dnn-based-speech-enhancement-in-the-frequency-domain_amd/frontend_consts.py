@@ -11,7 +11,8 @@ def window_fn(win_type, win_len):
     if win_type in ('hanning', 'hann'):                 # scipy get_window(..., fftbins=True): periodic Hann
         n = np.arange(win_len, dtype=np.float64)
         return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_len)
-    raise NotImplementedError(f"window {win_type!r}: only the periodic Hann window is on the HIP path")
+    from scipy.signal import get_window                 # tools_for_model.py:20: any window name or (name, parameter) tuple scipy knows
+    return np.asarray(get_window(win_type, win_len, fftbins=True), dtype=np.float64)
 
 
 def stft_kernels(win_len, fft_len, win_type):

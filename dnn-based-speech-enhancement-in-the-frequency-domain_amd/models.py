@@ -178,8 +178,6 @@ class _SefdModule(nn.Module):
         ref = weakref.ref(self)
         for p in self.parameters():              # lets sefd_amd.optim.Adam(model.parameters()) find the model (optim.py)
             p._sefd_owner = ref
-        if getattr(self, "win_type", "hanning") not in ("hanning", "hann", None, "None"):
-            raise NotImplementedError(f"win_type {self.win_type!r}: the HIP path has the periodic Hann window ('hanning') and the rectangular one (None)")
 
     def flatten_parameters(self):
         pass

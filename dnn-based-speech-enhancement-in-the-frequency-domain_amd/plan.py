@@ -51,9 +51,15 @@ class Plan:
         cfg.bn_world = int(bn_world)
         cfg.grad_buckets = int(grad_buckets)
         cfg.use_cbn = 1 if use_cbn else 0
-        if win_type not in (None, "None", "hanning", "hann"):
-            raise NotImplementedError(f"window {win_type!r}: the HIP path has the periodic Hann window and the rectangular one (win_type None)")
-        cfg.window = 1 if win_type in (None, "None") else 0
+        if win_type in (None, "None"):
+            cfg.window = 1
+        elif win_type in ("hanning", "hann"):
+            cfg.window = 0
+        else:                              # any other name scipy.signal.get_window takes (tools_for_model.py:19-20): the table goes to the planner
+            from .frontend_consts import window_fn
+            self._window_values = np.ascontiguousarray(window_fn(win_type, win_len), dtype=np.float64)
+            cfg.window = 2
+            cfg.window_values = self._window_values.ctypes.data_as(C.POINTER(C.c_double))
         self.cfg = cfg
         self.model_name = model
         self.masking_mode = masking_mode

@@ -46,7 +46,10 @@ typedef struct sefd_model_config {
                              backward: a data-parallel caller starts their all-reduce there (sefd_plan_run_cb) and it rides under the
                              encoder's dgrad / wgrad kernels; the encoder range follows at the end of the phase (reverse layer order) */
   int32_t use_cbn;        /* DCCRN(use_cbn=True) (models.py:25, 76, 120): ComplexBatchNorm (tools_for_model.py:430-607) instead of nn.BatchNorm2d */
-  int32_t window;         /* ConvSTFT / ConviSTFT window (tools_for_model.py:17-20): 0 periodic Hann (cfg.window = 'hanning'), 1 rectangular (win_type None) */
+  int32_t window;         /* ConvSTFT / ConviSTFT window (tools_for_model.py:17-20): 0 periodic Hann (cfg.window = 'hanning'), 1 rectangular (win_type None),
+                             2 the table `window_values` (any other scipy.signal.get_window(name, win_len, fftbins=True): the host evaluates it) */
+  int32_t pad_;
+  const double* window_values;   /* window == 2: win_len doubles, read during sefd_plan_create only */
 } sefd_model_config;
 
 enum { SEFD_ARENA_WS = 0, SEFD_ARENA_PARAM = 1, SEFD_ARENA_GRAD = 2, SEFD_ARENA_STATE = 3, SEFD_ARENA_CONST = 4, SEFD_ARENA_IO = 5,

@@ -19,7 +19,12 @@ def periodic_hann(win_len: int) -> np.ndarray:
 
 def window_of(win_len: int, win_type="hanning") -> np.ndarray:
     """init_kernels' window (tools_for_model.py:17-20): np.ones for win_type None / 'None', else scipy's periodic window."""
-    return np.ones(win_len) if win_type in (None, "None") else periodic_hann(win_len)
+    if win_type in (None, "None"):
+        return np.ones(win_len)
+    if win_type in ("hanning", "hann"):
+        return periodic_hann(win_len)
+    from scipy.signal import get_window            # tools_for_model.py:20: any other scipy window name
+    return np.asarray(get_window(win_type, win_len, fftbins=True), dtype=np.float64)
 
 
 def analysis_kernel(win_len=400, fft_len=512, window=True, win_type="hanning") -> np.ndarray:

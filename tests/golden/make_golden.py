@@ -373,6 +373,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "large":         # BASELINE configs[4]: DCCRN-large (2x channels, rnn_units 512), short clip
         dccrn_case(cfg, models, "large_C_sisnr", (64, 128, 256, 512, 512, 512), 512, "C", "SI-SNR", False, 2, 1600, store_taps=False, gstride=997, scale=0.125)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "hamming":       # ConvSTFT(win_type='hamming'): any scipy.signal.get_window name (tools_for_model.py:19-20)
+        dccrn_case(cfg, models, "hamming_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False, 2, 4000, store_taps=False, win_type="hamming")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "rectwin":       # ConvSTFT(win_type=None): rectangular window (tools_for_model.py:17-18)
         dccrn_case(cfg, models, "rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False, 2, 4000, store_taps=False, win_type=None)
         return

@@ -91,8 +91,9 @@ def test_adam_state_dict_format_and_pending_load():
     assert opt._pending is not None and opt.state_dict()["state"][0]["exp_avg"].shape == next(m.parameters()).shape
     with pytest.raises(RuntimeError):
         opt.step()                                             # no CPU path
-    with pytest.raises(NotImplementedError):
-        models.DCCRN(rnn_units=128, win_type="hamming")        # only the periodic Hann and the rectangular (None) windows are on the HIP path
+    mh = models.DCCRN(rnn_units=128, win_type="hamming")       # any scipy.signal.get_window name (tools_for_model.py:19-20)
+    from scipy.signal import get_window
+    assert torch.allclose(mh.istft.window.reshape(-1).double(), torch.from_numpy(get_window("hamming", cfg.win_len, fftbins=True)), atol=1e-7)
     cfg.dccrn_kernel_num = [32, 64, 128, 256, 256, 256]
 
 

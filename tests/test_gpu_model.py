@@ -25,6 +25,7 @@ CASES = [
     ("noskip_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR"),       # cfg.skip_type = False (models.py:107-137, 222-223)
     ("cbn_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR"),          # DCCRN(use_cbn=True): ComplexBatchNorm (tools_for_model.py:430-607)
     ("rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR"),      # win_type=None: rectangular window (tools_for_model.py:17-18)
+    ("hamming_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR"),      # win_type='hamming': any scipy.signal.get_window name (tools_for_model.py:19-20) - the host hands the table to the planner
 ]
 
 
@@ -62,7 +63,7 @@ def test_module_step_against_reference_golden(name, kn, ru, mask, loss):
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     skip, scale, gstride = case_meta(g)
     m = make_model(kn, ru, mask, loss, lstm="real" if name.startswith("real") else "complex", skip=skip, use_cbn=name.startswith("cbn"),
-                   win_type=None if name.startswith("rectwin") else "hanning")
+                   win_type=None if name.startswith("rectwin") else "hamming" if name.startswith("hamming") else "hanning")
     m.train()
     x, y = make_signals(B, L)
     x, y = (x * scale).cuda(), (y * scale).cuda()

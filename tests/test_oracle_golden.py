@@ -96,6 +96,7 @@ CASES = [
     ("noskip_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False),       # cfg.skip_type = False
     ("cbn_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False),          # DCCRN(use_cbn=True): ComplexBatchNorm
     ("rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False),      # win_type=None: rectangular window
+    ("hamming_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False),      # win_type='hamming': a scipy.signal.get_window name (tools_for_model.py:19-20)
 ]
 
 
@@ -111,7 +112,7 @@ def test_dccrn_step_against_reference(name, kn, ru, mask, loss, perc):
     skip, scale, gstride = case_meta(g)
     cfg = DCCRNConfig(kernel_num=kn, rnn_units=ru, masking_mode=mask, lstm="real" if name.startswith("real") else "complex", skip_type=skip,
                       use_cbn=bool(int(g["g/meta/use_cbn"])) if "g/meta/use_cbn" in g else False,
-                      win_type=None if "g/meta/rect_window" in g and int(g["g/meta/rect_window"]) else "hanning")
+                      win_type="hamming" if name.startswith("hamming") else None if "g/meta/rect_window" in g and int(g["g/meta/rect_window"]) else "hanning")
     P = oracle_params(cfg)
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     x, y = make_signals(B, L)
