@@ -305,15 +305,40 @@ class _SefdModule(nn.Module):
             rt.run(PHASE_FWD)
         # sharded batch: SI-SDR's mean of ratios inside the log (tools_for_loss.py:91-94) is taken over all ranks (two floats all-reduced
         # between the loss kernels); the other losses shard exactly
+        direct = str(rt.plan.masking_mode).startswith("Direct")
         prev_dp = tfl.set_data_parallel(exchange)
         try:
-            ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
+            if direct:
+                # spectral mapping (dccrn_direct_train / crn_direct_train, trainer.py:121-181): the loss compares SPECTRA, over the rows [B * F] of
+                # length T (the reductions of tools_for_loss.py run over the last axis); the waveform output carries no loss
+                if perceptual:
+                    raise NotImplementedError("the reference has no perceptual trainer for the direct-mapping models")
+                NFr, Tr = rt.out_real.shape[1], rt.out_real.shape[2]
+                rows = lambda t: t.view(B * NFr, Tr)
+                if rt.plan.model_name == "DCCRN":             # loss = (loss(real) + loss(imag)) / 2 against the target's spectra
+                    tgt_r, tgt_i = self._stft_ref(targets)
+                    half = torch.full((1,), 0.5, dtype=torch.float32, device=inputs.device)
+                    ws_r, loss_r = tfl.loss_forward_raw(kind, rows(rt.out_real), rows(tgt_r), stream)
+                    ws_i, loss_i = tfl.loss_forward_raw(kind, rows(rt.out_imag), rows(tgt_i), stream)
+                    tfl.loss_backward_raw(kind, rows(rt.out_real), rows(tgt_r), ws_r, half, rows(rt.g_real), stream)
+                    tfl.loss_backward_raw(kind, rows(rt.out_imag), rows(tgt_i), ws_i, half, rows(rt.g_imag), stream)
+                    loss = (loss_r + loss_i) / 2
+                else:                                         # CRN: mapped magnitudes (first output) against the target magnitudes (second output)
+                    est_m, tgt_m = rows(rt.out_real), rows(rt.out_imag)
+                    ws, loss = tfl.loss_forward_raw(kind, est_m, tgt_m, stream)
+                    tfl.loss_backward_raw(kind, est_m, tgt_m, ws, None, rows(rt.g_real), stream)
+                    rt.g_imag.zero_()
+                rt.g_wav.zero_()
+            else:
+                ws, loss = tfl.loss_forward_raw(kind, rt.out_wav, targets, stream)
         finally:
             tfl.set_data_parallel(prev_dp)
-        if not wave_only:
+        if not wave_only and not direct:
             rt.g_real.zero_()
             rt.g_imag.zero_()
-        if perceptual:
+        if direct:
+            pass
+        elif perceptual:
             half = torch.full((1,), 0.5, dtype=torch.float32, device=inputs.device)
             tfl.loss_backward_raw(kind, rt.out_wav, targets, ws, half, rt.g_wav, stream)
             with torch.enable_grad():                    # the loss kernels' own autograd wrappers on leaf copies of the outputs

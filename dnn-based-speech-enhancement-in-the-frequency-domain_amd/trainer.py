@@ -123,15 +123,20 @@ def fullsubnet_train(model, optimizer, train_loader, DEVICE, exchange=None):
 
 @_sharded
 def dccrn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
-    """trainer.py:121-150 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra.  Autograd route (the loss is on the
-    spectra, not on the waveform the fused step differentiates); under `exchange` the gradients are averaged after the backward."""
+    """trainer.py:121-150 (spectral mapping): loss = (loss(real) + loss(imag)) / 2 on the spectra.  With `sefd_amd.optim.Adam` the batch is the
+    fused `model.train_step` (the spectral losses and their gradients go straight into the plan's spectrum-gradient inputs; same numbers as the
+    autograd route below, tests/test_gpu_validate.py), which is also the bucketed / overlapped data-parallel path."""
     train_loss = torch.zeros((), device=DEVICE)
     batch_num = 0
     model.train()
+    fused = isinstance(optimizer, Adam) and str(getattr(model, "masking_mode", "")).startswith("Direct")
     for inputs, targets in train_loader:
         batch_num += 1
         inputs = inputs.float().to(DEVICE)
         targets = targets.float().to(DEVICE)
+        if fused:
+            train_loss += model.train_step(inputs, targets, optimizer, exchange=exchange).detach()
+            continue
         output_real, target_real, output_imag, target_imag, _ = model(inputs, targets)
         real_loss = model.loss(output_real, target_real)
         imag_loss = model.loss(output_imag, target_imag)
@@ -147,14 +152,18 @@ def dccrn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
 @_sharded
 def crn_direct_train(model, optimizer, train_loader, DEVICE, exchange=None):
     """trainer.py:150-181: CRN spectral mapping ('Direct(None make)'): the loss compares the mapped magnitudes (first output
-    of `CRN.forward`) with the target magnitudes; the waveform output carries no loss."""
+    of `CRN.forward`) with the target magnitudes; the waveform output carries no loss.  Fused `train_step` with `sefd_amd.optim.Adam`."""
     train_loss = torch.zeros((), device=DEVICE)
     batch_num = 0
     model.train()
+    fused = isinstance(optimizer, Adam) and str(getattr(model, "masking_mode", "")).startswith("Direct")
     for inputs, targets in train_loader:
         batch_num += 1
         inputs = inputs.float().to(DEVICE, non_blocking=True)
         targets = targets.float().to(DEVICE, non_blocking=True)
+        if fused:
+            train_loss += model.train_step(inputs, targets, optimizer, exchange=exchange).detach()
+            continue
         output_mag, target_mag, _ = model(inputs, targets)
         loss = model.loss(output_mag, target_mag)
         optimizer.zero_grad()

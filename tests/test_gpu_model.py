@@ -839,3 +839,49 @@ def test_status_poison_reaches_every_replica_through_the_gradient(tmp_path):
     torch.cuda.synchronize()
     assert not torch.equal(good._flat_param, before)
     bad._status_plan.status(clear=True)
+
+
+@pytest.mark.parametrize("which,loss_kind", [("DCCRN", "MSE"), ("DCCRN", "SI-SNR"), ("CRN", "MSE"), ("CRN", "SDR")])
+def test_direct_mapping_fused_step_equals_autograd_route(which, loss_kind):
+    """VERDICT r4 missing item 4: dccrn_direct_train / crn_direct_train (trainer.py:121-181) on the fused `train_step` - the spectral losses and
+    their gradients go straight into the plan's spectrum-gradient inputs.  Must equal the literal loop (forward, loss on the spectra,
+    loss.backward(), optimizer.step()) over the same kernels: loss per step and every parameter after two steps."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models, trainer
+    from sefd_amd.optim import Adam
+    kn = (16, 32, 32, 64, 64, 64)
+    cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.perceptual, cfg.skip_type, cfg.act_dtype = list(kn), "Direct(None make)", loss_kind, False, True, "fp32"
+    x, y = make_signals(2, 4000)
+    batches = [(x, y), (0.5 * y + 0.5 * x, y)]
+    res = []
+    for fused in (False, True):
+        if which == "DCCRN":
+            m = models.DCCRN(rnn_units=128, masking_mode="Direct(None make)")
+        else:
+            m = models.CRN(rnn_units=128, rnn_input_size=128, masking_mode="Direct(None make)")
+        fill_state_dict_(m)
+        m = m.to("cuda").train()
+        opt = Adam(m.parameters(), lr=1e-3)
+        fn = trainer.dccrn_direct_train if which == "DCCRN" else trainer.crn_direct_train
+        losses = []
+        for b in batches:
+            if fused:
+                losses.append(float(fn(m, opt, [b], "cuda")))
+            else:                                    # the reference's loop body, spelled out (the trainer would pick the fused path for this optimizer)
+                outs = m(b[0].cuda(), b[1].cuda())
+                if which == "DCCRN":
+                    lossv = (m.loss(outs[0], outs[1]) + m.loss(outs[2], outs[3])) / 2
+                else:
+                    lossv = m.loss(outs[0], outs[1])
+                opt.zero_grad()
+                lossv.backward()
+                opt.step()
+                losses.append(float(lossv))
+        res.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+    (la, pa), (lb, pb) = res
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (la, lb)
+    for k in pa:
+        if pa[k].dtype.is_floating_point:
+            assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * max(1.0, float(pa[k].abs().max())), k
+    cfg.masking_mode, cfg.loss = "E", "SI-SNR"
