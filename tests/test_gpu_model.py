@@ -479,7 +479,13 @@ def test_dccrn_direct_mode_against_reference_golden():
 # that are heavily cancelling sums (a PReLU slope, an LSTM bias element) are off by up to 0.5 relative - their terms are
 # individually accurate to 2^-9, the sum is 100x smaller than its terms.  Budgets: median 8e-2, worst tensor 0.7, cosine > 0.99.
 # Measured values go to gpurun_out/r02_bf16_parity.json (copied to profiles/).
-BF16_OUT_L2, BF16_OUT_MAX, BF16_GRAD_L2, BF16_GRAD_WORST, BF16_GRAD_COS, BF16_LOSS = 2e-2, 5e-2, 8e-2, 0.7, 0.99, 2e-2
+# Round 5: the worst-tensor budget is split.  PReLU slopes (`*.2.weight`, ONE scalar per layer = a heavily cancelling sum over every
+# activation of the layer) keep a wide budget: tools/bf16_slope_analysis.py runs the same bf16 plan on the host simulator, which accumulates every
+# sum in DOUBLE and only keeps the bf16 STORAGE roundings - it is 0.83 off on encoder.1.2.weight where the MI355X kernels are 0.61 off (fp32 storage:
+# 6e-7): the error is the rounding of the stored y / dz, not the kernels' accumulation (profiles/r05_bf16_slope_analysis.json).  Every OTHER tensor
+# must stay below 0.3 (measured worst: 0.20, an LSTM bias of the ComplexBatchNorm model) - that is the guard against a broken kernel.
+BF16_OUT_L2, BF16_OUT_MAX, BF16_GRAD_L2, BF16_GRAD_WORST, BF16_GRAD_COS, BF16_LOSS = 2e-2, 5e-2, 8e-2, 0.3, 0.99, 2e-2
+BF16_SLOPE_WORST = 0.9
 _BF16_REPORT = {}
 
 
@@ -496,14 +502,14 @@ def _bf16_record(name, rec):
         except Exception:
             old = {}
     old.update(_BF16_REPORT)
-    old["_budget"] = dict(out_rel_l2=BF16_OUT_L2, out_rel_max=BF16_OUT_MAX, grad_rel_l2_median=BF16_GRAD_L2, grad_rel_l2_worst=BF16_GRAD_WORST,
+    old["_budget"] = dict(out_rel_l2=BF16_OUT_L2, out_rel_max=BF16_OUT_MAX, grad_rel_l2_median=BF16_GRAD_L2, grad_rel_l2_worst=BF16_GRAD_WORST, prelu_slope_rel_worst=BF16_SLOPE_WORST,
                           grad_cosine_min=BF16_GRAD_COS, loss_rel=BF16_LOSS,
                           note="bf16 storage / MFMA operands, fp32 accumulate, vs fp32 goldens captured from the reference")
     json.dump(old, open(path, "w"), indent=1, sort_keys=True)
 
 
 def _grad_report(grads, g, gstride):
-    worst, vals = ("", 0.0), []
+    worst, vals, slopes = ("", 0.0), [], {}
     dot = na = nb = 0.0
     pairs = [(k, grads[k], v) for k, v in sub(g, "g/grad").items()] + \
             [(k, grads[k].reshape(-1)[::gstride], v) for k, v in sub(g, "g/grad_samp").items()]
@@ -512,14 +518,17 @@ def _grad_report(grads, g, gstride):
             continue
         e = rel_l2(mine, v)
         vals.append(e)
-        if e > worst[1]:
+        if k.endswith(".2.weight"):
+            slopes[k] = e                      # PReLU slope: its own budget (BF16_SLOPE_WORST)
+        elif e > worst[1]:
             worst = (k, e)
         a, b_ = mine.detach().double().reshape(-1), torch.as_tensor(np.asarray(v)).double().reshape(-1)
         dot += float((a * b_).sum()); na += float((a * a).sum()); nb += float((b_ * b_).sum())
     gn = sub(g, "g/grad_norm")
-    nr = max(abs(float(grads[k].double().norm()) / float(v) - 1.0) for k, v in gn.items() if not noise_bias(k) and float(v) > 0)
+    nr = max(abs(float(grads[k].double().norm()) / float(v) - 1.0) for k, v in gn.items() if not noise_bias(k) and float(v) > 0 and not k.endswith(".2.weight"))
     return dict(grad_rel_l2_worst=worst[1], grad_rel_l2_worst_name=worst[0], grad_rel_l2_median=float(np.median(vals)),
-                grad_norm_ratio_worst=nr, grad_cosine=dot / max((na * nb) ** 0.5, 1e-300))
+                grad_norm_ratio_worst=nr, grad_cosine=dot / max((na * nb) ** 0.5, 1e-300), slope_rel=slopes,
+                slope_rel_worst=max(slopes.values()) if slopes else 0.0)
 
 
 @pytest.mark.parametrize("name,kn,ru,mask,loss", [("default_E_sisnr", (32, 64, 128, 256, 256, 256), 256, "E", "SI-SNR"),
@@ -546,7 +555,7 @@ def test_bf16_dccrn_step_against_reference_golden(name, kn, ru, mask, loss):
     assert rec["out_wav_rel_l2"] < BF16_OUT_L2 and rec["out_wav_rel_max"] < BF16_OUT_MAX, rec
     assert rec["out_real_rel_l2"] < BF16_OUT_L2 and rec["out_real_rel_max"] < BF16_OUT_MAX, rec
     assert rec["loss_rel"] < BF16_LOSS, rec
-    assert rec["grad_rel_l2_median"] < BF16_GRAD_L2 and rec["grad_rel_l2_worst"] < BF16_GRAD_WORST, rec
+    assert rec["grad_rel_l2_median"] < BF16_GRAD_L2 and rec["grad_rel_l2_worst"] < BF16_GRAD_WORST and rec["slope_rel_worst"] < BF16_SLOPE_WORST, rec
     assert rec["grad_cosine"] > BF16_GRAD_COS and rec["grad_norm_ratio_worst"] < BF16_GRAD_WORST, rec
 
 
@@ -590,7 +599,7 @@ def test_bf16_crn_step_against_reference_golden():
     rec["loss_rel"] = abs(rec["loss"] - rec["loss_ref"]) / max(1e-30, abs(rec["loss_ref"]))     # MSE ~ 1e-3: relative to itself
     _bf16_record("crn_default_E_mse", rec)
     assert rec["out_wav_rel_l2"] < BF16_OUT_L2 and rec["out_wav_rel_max"] < BF16_OUT_MAX and rec["est_mags_rel_l2"] < BF16_OUT_L2, rec
-    assert rec["loss_rel"] < 2 * BF16_LOSS and rec["grad_rel_l2_median"] < BF16_GRAD_L2 and rec["grad_rel_l2_worst"] < BF16_GRAD_WORST, rec
+    assert rec["loss_rel"] < 2 * BF16_LOSS and rec["grad_rel_l2_median"] < BF16_GRAD_L2 and rec["grad_rel_l2_worst"] < BF16_GRAD_WORST and rec["slope_rel_worst"] < BF16_SLOPE_WORST, rec
     assert rec["grad_cosine"] > BF16_GRAD_COS, rec
 
 
