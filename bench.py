@@ -28,9 +28,14 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI3
 PEAK_HBM_GBS = 8000.0
 K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
 F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")       # default workload; main() switches to r04_pmc_traffic_<model>.json
+F_SLAB = 128                             # ... of the opt-in LDS-slab kernel (kRunSlab, SEFD_SLAB=1)
+PMC_ROUND = "r05"
+PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_traffic.json")       # default workload; main() switches to <round>_pmc_traffic_<model>.json
 PMC_DEFAULT_BATCH = {"dccrn": 32, "dccrn_large": 64, "fullsubnet": 64}       # the batch each committed summary was collected at
 ALGO_GB_PER_UTT = 0.28                   # minimal fused activation traffic of one bf16 training step
+
+
+CPU_B32 = False
 
 
 def parse():
@@ -44,6 +49,7 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("SEFD_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--perceptual", default=None, choices=["LMS", "PMSQE"], help="DCCRN: loss = (SI-SNR + perceptual) / 2 (BASELINE configs[3] per-GPU shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-b32", action="store_true", help="also time the CPU baseline at B = 32 (1 warm-up + 5 timed steps, ~2 minutes)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the two side figures of the default run (B = 64 bf16, B = 32 fp32)")
     return ap.parse_args()
@@ -90,7 +96,7 @@ def pmc_step_total():
 def _op_class(info):
     k = info["kind"]
     if k == K_RUNGEMM:
-        return ("cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
+        return ("slabgemm" if info["flags"] & F_SLAB else "cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
     if k == K_WGRAD:
         return ("wgrad", info["dtype"])
     if k in (K_LSTM_FWD, K_LSTM_BWD):
@@ -106,7 +112,7 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
     """Two timing legs over every MFMA GEMM, LSTM recurrence and STFT launch of one step:
       in situ  (the headline `frac`): sefd_plan_run_timed - each phase in its REAL two-stream schedule with a HIP event pair around every
                op on the stream it runs on, i.e. the kernel's duration while the other lane's kernels share the chip (what a rocprofv3
-               kernel trace of the bench command shows; profiles/r04_kernel_stats_default.csv);
+               kernel trace of the bench command shows; profiles/r05_kernel_stats_default.csv);
       isolated (`frac_isolated`): the phase in program order on ONE stream, event pair per op - per-kernel rates without contention.
     achieved = algorithmic FLOPs (2*M*N*K, true unpadded N and K; sefd_plan_op_info) / measured duration."""
     from sefd_amd.plan import PHASE_BWD, PHASE_FWD
@@ -169,7 +175,7 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
             detail[label] = dict(bound="mfma", tflops=round(tf, 2), frac=round(tf / PEAK_TFLOPS[dt], 4), tflops_isolated=round(tfi, 2),
                                  frac_isolated=round(tfi / PEAK_TFLOPS[dt], 4), ms=round(v["ms_situ"], 3), ms_isolated=round(v["ms"], 3),
                                  launches=v["launches"])
-    gemm_keys = [k for k in agg if k[0] in ("rungemm", "cgemm256", "wgrad")]
+    gemm_keys = [k for k in agg if k[0] in ("rungemm", "cgemm256", "wgrad", "slabgemm")]
     key = max(gemm_keys, key=lambda k: agg[k]["ms_situ"])
     a = agg[key]
     achieved = a["flops"] / (a["ms_situ"] * 1e-3) / 1e12
@@ -177,7 +183,7 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
     peak = PEAK_TFLOPS[key[1]]
     # kernel names as tools/pmc_traffic.py stores them ("void sefd::" / "sefd::" stripped, template arguments kept)
     prefixes = {"rungemm": ["rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float"],
-                "cgemm256": ["cgemm256_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
+                "cgemm256": ["cgemm256_kernel"], "slabgemm": ["slabgemm_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
     return dict(bound="mfma", kernel=f"{key[0]}<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                 frac=round(achieved / peak, 4), frac_isolated=round(isolated / peak, 4),
                 traffic=pmc_traffic(prefixes) if pmc_ok else None, launches_per_step=a["launches"],
@@ -211,15 +217,18 @@ def cpu_baseline(L, kn, ru):
     out = dict(value=round(Bc / med, 3), unit="utt/s", cores=torch.get_num_threads(), kind="port",
                sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + {nsteps} timed steps "
                       f"(median {med:.2f} s/step, min {min(ts):.2f}), fp32")
-    # the bench batch itself (BASELINE.md section 4 asks for B = 32 beside B = 4): two timed steps, bounded by the budget of this leg
-    if med * 8 * 3 < 45:
+    # (B = 32 on the CPU takes 22 s per step - 1.43 utt/s, profiles/r04_bench_default.json; BASELINE.md section 4's median of >= 5 steps would
+    # add two minutes to the default run, so the B = 4 protocol above is the one reported; `--cpu-b32` times it with the same protocol)
+    if CPU_B32:
         x32, y32 = make_batch(32, L, 0, "cpu")
+        dccrn_train_step(P, cfgo, x32, y32, loss_kind="SI-SNR")
         t32 = []
-        for _ in range(3):
+        for _ in range(nsteps):
             t0 = time.time()
             dccrn_train_step(P, cfgo, x32, y32, loss_kind="SI-SNR")
             t32.append(time.time() - t0)
-        out["b32"] = dict(value=round(32 / min(t32[1:]), 3), unit="utt/s", sample=f"B=32, 1 warm-up + 2 timed steps (min {min(t32[1:]):.2f} s/step)")
+        m32 = sorted(t32)[len(t32) // 2]
+        out["b32"] = dict(value=round(32 / m32, 3), unit="utt/s", sample=f"B=32, 1 warm-up + {nsteps} timed steps (median {m32:.2f} s/step)")
     return out
 
 
@@ -246,6 +255,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    global CPU_B32
+    CPU_B32 = bool(args.cpu_b32)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -350,7 +361,7 @@ def main():
             # committed PMC summaries: one per model at its default batch; anything else reports traffic null
             global PMC_SUMMARY
             if args.model != "dccrn":
-                PMC_SUMMARY = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{args.model}.json")
+                PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_traffic_{args.model}.json")
             out["roofline"] = roofline(plan, arenas, pmc_ok=(B == PMC_DEFAULT_BATCH[args.model] and not args.perceptual and args.dtype == "bf16"),
                                        algo_stft_bytes=0 if args.model == "fullsubnet" else B * (4 * L + 4 * 514 * plan.T))
             info = [plan.op_info(ph, i) for ph in (0, 1) for i in range(plan.num_ops(ph))]

@@ -281,10 +281,17 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     (void)hipStreamWaitEvent(st, h->ev_join, 0);
     side_busy = false;
   };
+  // SEFD_HOLD_SKIP=K (tuning): the first K lane-1 ops in front of the first recurrence are NOT held back but issued at their program position
+  // (beside the decoder's BatchNorm / dgrad chain); the rest still waits for the recurrence.  Measured: profiles/r05_tuning_notes.md.
+  static const int hold_skip = getenv("SEFD_HOLD_SKIP") ? atoi(getenv("SEFD_HOLD_SKIP")) : 0;
+  int lane1_seen = 0;
   for (int i = first; i < last; ++i) {
     const Op& op = ops[i];
     // held: every lane-1 op in front of the first recurrence, and the ones marked kOpHold, wait for the next recurrence launch
-    if (op.lane == 1 && i < last_lstm && (!forked || op.join == kOpHold)) { held.push_back(i); continue; }
+    if (op.lane == 1 && i < last_lstm && (!forked || op.join == kOpHold)) {
+      if (!forked && lane1_seen++ < hold_skip) { side_launch(op); continue; }
+      held.push_back(i); continue;
+    }
     if (op.lane == 3) { side2_launch(op); continue; }
     if (op.lane == 1 || op.lane == 2) { side_launch(op); continue; }
     if (op.kind == OP_LSTM_BWD && (!forked || !held.empty())) {
