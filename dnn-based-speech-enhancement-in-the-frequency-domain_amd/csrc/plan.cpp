@@ -174,9 +174,11 @@ struct Builder {
     Op& op = push(ops, OP_STFT_FFT, tag);
     op.fft.src = src; op.fft.spec = spec; op.fft.tw = fft_tw; op.fft.win = cst(wf.data(), 2048);
     op.fft.B = B; op.fft.L = L; op.fft.T = T; op.fft.hop = hop; op.fft.off = off; op.fft.lp_dt = 0;
-    op.fft.corr = none(); op.fft.scale = 1.f; op.fft.lp = none();
+    op.fft.corr = none(); op.fft.scale = 1.f; op.fft.lp = none(); op.fft.pair = fft_pair();
     return true;
   }
+  // two frames per transform in the bf16 plans only (stft_fft.hip); SEFD_STFT_PAIR=0 / 1 forces one form (A/B runs)
+  int fft_pair() const { return getenv("SEFD_STFT_PAIR") ? atoi(getenv("SEFD_STFT_PAIR")) != 0 : c.act_dtype == DT_BF16; }
   Ptr fft_tw = Ptr{-1, 0, 0};
   Ptr fft_corr = Ptr{-1, 0, 0};
   // rank-2 correction of the closed-form pinv synthesis basis: cE/cO[part][k] = sum over even/odd j < W of the
@@ -218,7 +220,7 @@ struct Builder {
     Op& op = push(ops, OP_STFT_FFT, tag);
     op.fft.src = dpad; op.fft.spec = dest; op.fft.tw = fft_tw; op.fft.win = win512(win);
     op.fft.B = B; op.fft.L = Lp; op.fft.T = T; op.fft.hop = hop; op.fft.off = 0; op.fft.lp_dt = 0;
-    op.fft.corr = istft_corr((int)win.size()); op.fft.scale = 1.f / 256.f; op.fft.lp = none();
+    op.fft.corr = istft_corr((int)win.size()); op.fft.scale = 1.f / 256.f; op.fft.lp = none(); op.fft.pair = fft_pair();
     return true;
   }
 

@@ -344,7 +344,8 @@ struct StftFft {
   // the padded waveform gradient, with a rank-2 term and the 1/256:  out[part][k] = scale * ( FFT(v)[part][k]
   //   - cE[part][k] * sum_{n even} v[n] - cO[part][k] * sum_{n odd} v[n] ),  v = windowed frame.  corr = A_NONE: plain STFT.
   Ptr corr;                    // fp32 [2 (even, odd)][2 (re, im)][257]  (A_CONST)
-  float scale, pad2_;
+  float scale;
+  int32_t pair;                // 1: two real frames per complex transform (bf16 plans: half the instructions); 0: one frame per transform (fp32 plans)
 };
 // iSTFT synthesis as an inverse 512-point FFT (fft_len == 512): frames[fr][j] = win[j] / 256 * ( Re sum_{k<=256} X[k] e^{+2 pi i k j / 512}
 //   - C_parity(j) ),  C_even = sum_{part,k} X[part][k] cE[part][k], C_odd likewise with cO: the closed form of the reference's

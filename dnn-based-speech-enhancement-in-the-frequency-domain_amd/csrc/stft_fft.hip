@@ -68,6 +68,101 @@ __device__ __forceinline__ void fft512_wave(cf* x, cf* X, float2* buf, const flo
   dft8(x, X);
 }
 
+// ONE real frame per complex transform (rounds 2-4): what the fp32 plans keep (StftFft::pair == 0).  The pair transform below is as accurate in the
+// max norm (8e-8 of the largest bin against the host simulator), but a frame's small bins then carry the OTHER frame's rounding noise as well, and
+// the fp32 goldens of mask mode E - whose backward divides by |mask| - sit within 2.4e-3 instead of 1e-3 on one BatchNorm bias gradient of the
+// no-skip model with it (GPU suite, round 5).  fp32 is the parity dtype: it keeps the transform its goldens were captured against.
+constexpr int kStftFPW = 2;
+
+__global__ __launch_bounds__(256) void stft_fft_single_kernel(const StftFft d, const ArenaBases ab) {
+  constexpr int FPW = kStftFPW;
+  __shared__ float2 lds[4][kFftSlice];
+  __shared__ float2 twl[512];
+  const float* src = reinterpret_cast<const float*>(rp(ab, d.src));
+  const float* win = reinterpret_cast<const float*>(rp(ab, d.win));
+  const float2* tw = reinterpret_cast<const float2*>(rp(ab, d.tw));
+  float2* spec = reinterpret_cast<float2*>(rp(ab, d.spec));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t nfr = (int64_t)d.B * d.T;
+  const int64_t fr0 = ((int64_t)blockIdx.x * 4 + wv) * FPW;
+  float raw[FPW][8], wn[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wn[j] = win[lane + 64 * j];
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    const int64_t fr = fr0 + f;
+    const int64_t b = fr < nfr ? fr / d.T : 0;
+    const int t = fr < nfr ? (int)(fr - b * d.T) : 0;
+    const int p0 = t * d.hop - d.off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = p0 + lane + 64 * j;
+      raw[f][j] = (fr < nfr && p >= 0 && p < d.L) ? src[b * d.L + p] : 0.f;
+    }
+  }
+  for (int i = threadIdx.x; i < 512; i += 256) twl[i] = tw[i];
+  __syncthreads();
+  const int k0 = lane >> 3, ma = lane & 7;
+#pragma unroll
+  for (int f = 0; f < FPW; ++f) {
+    const int64_t fr = fr0 + f;
+    if (fr >= nfr) break;                                    // wave-uniform
+    cf x[8], X[8];
+    float vs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = raw[f][j] * wn[j]; x[j] = {v, 0.f}; vs += v; }
+    fft512_wave(x, X, lds[wv], twl, lane);
+    // Bins leave in bin order: the transform ends with lane l holding bins (l >> 3) + 8 (l & 7) + 64 mb - stored from there every store
+    // instruction touched 64 different 64-byte segments (and 64 different lines of the padded copy).  One more pass through the wave's LDS
+    // slice (conflict-free: (l >> 3) + 8 (l & 7) is a permutation of 0..63) and lane l stores bins l + 64 j: whole lines per instruction.
+    float2* buf = lds[wv];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) buf[k0 + 8 * ma + 64 * mb] = make_float2(X[mb].x, X[mb].y);
+    const cf x256 = X[4];                                    // bin 256: lane 0 (k0 = ma = 0, mb = 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float2 Y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y[j] = buf[lane + 64 * j];
+    float2* out = spec + fr * 258;
+    if (d.corr.arena >= 0) {                                 // backward of the pinv synthesis (see sefd_desc.h)
+      const float* cr = reinterpret_cast<const float*>(rp(ab, d.corr));
+      const float ge = wave_sum((lane & 1) ? 0.f : vs), go = wave_sum((lane & 1) ? vs : 0.f);   // n = lane + 64 j has the parity of lane
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        out[1 + k] = make_float2(d.scale * (Y[j].x - cr[k] * ge - cr[2 * 257 + k] * go),
+                                 d.scale * (Y[j].y - cr[257 + k] * ge - cr[3 * 257 + k] * go));
+      }
+      if (lane == 0) {
+        out[1 + 256] = make_float2(d.scale * (x256.x - cr[256] * ge - cr[2 * 257 + 256] * go),
+                                   d.scale * (x256.y - cr[257 + 256] * ge - cr[3 * 257 + 256] * go));
+        out[0] = make_float2(0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[1 + lane + 64 * j] = Y[j];
+      if (lane == 0) { out[1 + 256] = make_float2(x256.x, x256.y); out[0] = make_float2(0.f, 0.f); }
+      if (d.lp.arena >= 0) {                                 // channel-padded copy for the first encoder layer: one 16 / 32-byte slot per bin
+        char* lp = rp(ab, d.lp);
+        auto put = [&](int slot, float re, float im) {
+          const int64_t s = fr * 258 + slot;
+          if (d.lp_dt == DT_BF16) *reinterpret_cast<uint4*>(lp + s * 16) = make_uint4(pack_bf16x2(re, im), 0u, 0u, 0u);
+          else {
+            *reinterpret_cast<float4*>(lp + s * 32) = make_float4(re, im, 0.f, 0.f);
+            *reinterpret_cast<float4*>(lp + s * 32 + 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(1 + lane + 64 * j, Y[j].x, Y[j].y);
+        if (lane == 0) { put(1 + 256, x256.x, x256.y); put(0, 0.f, 0.f); }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's LDS slice is reused by its next frame
+  }
+}
+
+
 // TWO real frames per complex transform (round 5): z[n] = a[n] + i b[n] for a wave's two frames a, b; Z = DFT512(z); the frames' spectra are
 // A[k] = (Z[k] + conj Z[N - k]) / 2 and B[k] = (Z[k] - conj Z[N - k]) / (2 i).  The kernel is bound by the ~450 VALU / LDS instructions of one
 // transform per frame, not by bandwidth (profiles/r03_tuning_notes.md section 5): one transform per PAIR of frames halves them; the split costs one
@@ -227,6 +322,7 @@ __global__ __launch_bounds__(256) void istft_fft_kernel(const IstftFft d, const 
 
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st) {
   const int64_t frames = (int64_t)d.B * d.T;
+  if (!d.pair) { hipLaunchKernelGGL(stft_fft_single_kernel, dim3((unsigned)((frames + 4 * kStftFPW - 1) / (4 * kStftFPW))), dim3(256), 0, st, d, ab); return; }
   static const int ppw = getenv("SEFD_STFT_PPW") ? atoi(getenv("SEFD_STFT_PPW")) : 1;
   if (ppw == 2) hipLaunchKernelGGL(stft_fft_kernel<2>, dim3((unsigned)((frames + 15) / 16)), dim3(256), 0, st, d, ab);
   else hipLaunchKernelGGL(stft_fft_kernel<1>, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, st, d, ab);
