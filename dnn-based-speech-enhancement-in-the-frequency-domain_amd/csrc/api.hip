@@ -284,11 +284,13 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   // SEFD_HOLD_SKIP=K (tuning): the first K lane-1 ops in front of the first recurrence are NOT held back but issued at their program position
   // (beside the decoder's BatchNorm / dgrad chain); the rest still waits for the recurrence.  Measured: profiles/r05_tuning_notes.md.
   static const int hold_skip = getenv("SEFD_HOLD_SKIP") ? atoi(getenv("SEFD_HOLD_SKIP")) : 0;
+  // SEFD_NO_OPHOLD=1 (tuning): lane-1 ops marked kOpHold behind the first recurrence are issued at their program position instead of behind the next recurrence
+  static const bool no_ophold = getenv("SEFD_NO_OPHOLD") && atoi(getenv("SEFD_NO_OPHOLD")) == 1;
   int lane1_seen = 0;
   for (int i = first; i < last; ++i) {
     const Op& op = ops[i];
     // held: every lane-1 op in front of the first recurrence, and the ones marked kOpHold, wait for the next recurrence launch
-    if (op.lane == 1 && i < last_lstm && (!forked || op.join == kOpHold)) {
+    if (op.lane == 1 && i < last_lstm && (!forked || (op.join == kOpHold && !no_ophold))) {
       if (!forked && lane1_seen++ < hold_skip) { side_launch(op); continue; }
       held.push_back(i); continue;
     }

@@ -38,8 +38,7 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 3, 4001, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # L = 4001 marks the cases that send every N <= 64 conv GEMM through the direct-operand kernel (thin.hip)
                                                         ("DCCRN", 1, 2403, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("DCCRN", 1, 2401, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L odd: marks the case that lowers SEFD_CG256_MINM -> wide-tile kernel on every N % 256 == 0 layer
-                                                        ("DCCRN", 3, 2407, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L = 2407 / 3601 mark the cases that switch the opt-in LDS-slab kernel (slabgemm.hip) on for every conv it can take; three batch items: tiles cross batch boundaries (zero frame slots)
-                                                        ("DCCRN", 1, 3601, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # ... T = 37: tiles inside one item
+                                                        ("DCCRN", 3, 2407, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L = 2407 marks the case that switches the opt-in LDS-slab kernel (slabgemm.hip) on for every conv it can take; three batch items: tiles cross batch boundaries (zero frame slots)
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM (H = 256): cluster kernels, one partial row block
                                                         ("DCCRN", 18, 3400, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),    # the same, two row blocks, T = 35: chunked forward
                                                         ("DCCRN", 1, 1600, "C", (16, 32, 32, 64, 64, 64), 1024, "bf16"),    # H = 512: 8 workgroups per cluster
@@ -74,7 +73,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     os.environ.pop("SEFD_BN_FUSE", None)
     os.environ.pop("SEFD_SLAB_MINM", None)
     os.environ.pop("SEFD_SLAB", None)
-    slab_case = L in (2407, 3601)
+    slab_case = L == 2407
     if slab_case:
         L -= L % 100
         os.environ["SEFD_SLAB"] = "1"          # opt-in kernel

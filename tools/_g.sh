@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
-SEFD_STFT_PAIR=1 timeout 600 python -m pytest tests/test_gpu_model.py -q -k "test_module_step_against_reference_golden" > $O/r5n_pair1.log 2>&1; tail -4 $O/r5n_pair1.log | cut -c1-200
-timeout 600 python -m pytest tests/test_gpu_model.py -q -k "test_module_step_against_reference_golden" > $O/r5n_pair0.log 2>&1; tail -4 $O/r5n_pair0.log | cut -c1-200
+for rep in 1 2; do
+for n in 0 1; do
+echo -n "NO_OPHOLD=$n " ; SEFD_NO_OPHOLD=$n timeout 600 python bench.py --model fullsubnet --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-roofline 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*'
+done; done 2>&1 | tee $O/r5o_fsn_hold.log
