@@ -94,7 +94,9 @@ __device__ __forceinline__ void lds_barrier() {
 // each thread issues a fixed number of DMAs per stage and waits with wait_vm<N>() for all but the newest N.
 // `lds_wave_base` (wave-uniform byte address) + lane * 16 is the destination.
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "v"(gsrc)
+  // (s_nop 0: the one wait state the ISA asks for between an SALU write of M0 and the LDS-DMA that reads it - nothing pads inline asm,
+  // MI355X_MICROARCH / cdna_hip_programming.md section 5.7; five rounds of bit-reproducibility tests never caught the hazard, the slot is free)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "v"(gsrc)
                : "memory");
 }
 template <int N>
