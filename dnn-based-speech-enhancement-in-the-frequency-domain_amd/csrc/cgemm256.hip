@@ -96,6 +96,9 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   char* yb = rp(ab, d.y);
   const bool want_stats = d.stats.arena >= 0;
   const bool staged = (d.flags & kRunYAligned) && !(d.flags & kRunAccum);
+  // the output rows are one dense [M][row pitch] array (conv outputs: frames and batch items follow each other without gaps): row offset = m * y_fstride + y_off,
+  // no (b, u, fo) decode - the epilogue is VALU-bound (~1400 instructions per lane and tile, 20-25 % of a launch: profiles/r05_tuning_notes.md section 7)
+  const bool ylin = d.y_tstride == d.Fo * d.y_fstride && d.y_bstride == (int64_t)d.Tout * d.y_tstride;
   const uint16_t* ybn = BNB ? reinterpret_cast<const uint16_t*>(rp(ab, d.bnb_y)) : nullptr;   // the BatchNorm layer's forward output (bf16)
   const float bslope = BNB ? *reinterpret_cast<const float*>(rp(ab, d.bnb_slope)) : 0.f;
 
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (!BNB && staged) ? bv[j] : 0.f;       // the plain staged epilogue finds the bias already summed in
     uint4 af[MI], bf[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) af[i] = make_uint4(0, 0, 0, 0);
@@ -352,11 +355,20 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
       }
       continue;
     }
-    if (dbg & 8) continue;
+    if (dbg & 8) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));      // every accumulator element stays live: nothing upstream is dead code
+      continue;
+    }
     // ---- epilogue, wave local, no LDS: bias / ReLU / statistics on the accumulators as they sit (one column per lane), then the quad transpose
     // of dev_common.h QuadT turns every group of 4 rows x 4 lanes into 8-byte row pieces that are stored directly (a wave instruction covers 8 rows x
     // 64 contiguous bytes).  The LDS-staged version (128 ds_write_b16 + 16 ds_read_b128 per lane) took 28-34 % of the kernel (SEFD_CG256_DBG=8).
     const QuadT qt(lane);
+    const OctW ow(lane);
     float s1[NI], s2[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) s1[j] = s2[j] = 0.f;
@@ -364,14 +376,18 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
     for (int i = 0; i < MI; ++i) {
       const int row0 = mtile * BM + wm0 + i * 32;
       if (staged) {
+        const bool full = row0 + 32 <= d.M;                  // every row of this 32-row block exists (all tiles but the last)
         int64_t ro[4];                                       // output offsets of this lane's 4 rows after the transpose (-1: beyond M)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = row0 + 8 * q + 4 * (lane >> 5) + (lane & 3);
           ro[q] = -1;
           if (m < d.M) {
-            const int b = fdiv2(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv2(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
-            ro[q] = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+            if (ylin) ro[q] = (int64_t)m * d.y_fstride + d.y_off;
+            else {
+              const int b = fdiv2(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv2(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+              ro[q] = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+            }
           }
         }
 #pragma unroll
@@ -382,15 +398,32 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
           float v[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            v[e] = acc[i][j][e] + bv[j];
+            v[e] = acc[i][j][e];                             // bias included (accumulator init)
             if (d.flags & kRunRelu) v[e] = fmaxf(v[e], 0.f);
-            if (row0 + row < d.M && nok) { s1[j] += v[e]; s2[j] += v[e] * v[e]; }
           }
+          if (want_stats && nok) {
+            if (full) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint2 pk = qt.pack(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            if (ro[q] >= 0 && n0 < d.N) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yb) + ro[q] + n0) = pk;   // N % 8 == 0: 4 columns are all valid or all padding
+              for (int e = 0; e < 16; ++e) { s1[j] += v[e]; s2[j] += v[e] * v[e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row0 + row < d.M) { s1[j] += v[e]; s2[j] += v[e] * v[e]; }
+              }
+            }
+          }
+          uint2 pk[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pk[q] = qt.pack(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          // 16-byte stores: the lane pair (l, l ^ 4) splits the four row groups between them (dev_common.h OctW); N % 8 == 0: 8 columns are all valid or all padding
+          uint4 wide[2];
+          ow.widen(pk, wide);
+          const int n8 = n0 & ~7;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int64_t r = ow.hi4 ? ro[2 * h + 1] : ro[2 * h];
+            if (r >= 0 && n8 < d.N) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + r + n8) = wide[h];
           }
         }
       } else {

@@ -51,6 +51,30 @@ struct QuadT {
   }
   __device__ __forceinline__ uint2 pack(float v0, float v1, float v2, float v3) const { return pack(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)); }
 };
+// 16-byte epilogue stores (round 5): after QuadT::pack lane l holds 4 consecutive columns of one row and lane l ^ 4 the NEXT 4 columns of the same
+// row.  Stored as they are (8 bytes per lane) a tile leaves at the store-ISSUE rate of ~7 B/clk per CU (MI355X_MICROARCH.md, "attention epilogue
+// store tail": 16 x dwordx2 per lane) - measured on the N = 128 layers the epilogue was HALF the launch (profiles/r05_tuning_notes.md section 7).
+// OctW pairs the lanes: of the four row groups q the lane with bit 2 clear keeps q = 0, 2 and takes its partner's pieces of those rows, the lane with
+// bit 2 set keeps q = 1, 3: two 16-byte stores per lane instead of four 8-byte ones.  xor4: DPP row shifts by 4 inside the 16-lane row (VALU only).
+__device__ __forceinline__ uint32_t xor4(uint32_t x, bool hi4) {
+  const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, true);   // row_shl:4  lane i <- lane i + 4
+  const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);   // row_shr:4  lane i <- lane i - 4
+  return hi4 ? dn : up;
+}
+struct OctW {
+  bool hi4;          // lane & 4
+  __device__ __forceinline__ explicit OctW(int lane) : hi4((lane & 4) != 0) {}
+  // pk[q]: this lane's 8-byte piece of row group q.  Returns the two 16-byte chunks this lane stores: rows q = 0, 2 (bit 2 clear) or q = 1, 3 (set),
+  // columns (lane & 24) .. + 7 of the 32-column group.
+  __device__ __forceinline__ void widen(const uint2 (&pk)[4], uint4 (&out)[2]) const {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint2 keep = hi4 ? pk[2 * h + 1] : pk[2 * h], send = hi4 ? pk[2 * h] : pk[2 * h + 1];
+      const uint2 recv = make_uint2(xor4(send.x, hi4), xor4(send.y, hi4));
+      out[h] = hi4 ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+    }
+  }
+};
 __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 template <int DT> struct Elem;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {           // n is wave-unifor
 }  // namespace
 
 // dbg (tuning runs only, SEFD_SLAB_DBG): 1 skip the MFMAs, 2 skip the weight DMAs, 4 skip the fragment reads, 8 skip the slab DMAs, 16 no fragment
-// address arithmetic (every tap reads the rows of tap 0)
+// address arithmetic (every tap reads the rows of tap 0), 64 no epilogue
 // NBS: weight sub-slots.  4: the weights of pair P + 1 are issued during pair P.  6: those of pair P + 2 - the barrier at the top of pair P then
 // publishes pair P + 1 as well, and the first fragments of pair P + 1 are read in front of its barrier (no read bubble behind every barrier).
 template <int BN, int WM, int WN, bool BNB, int NBS, int dbg = 0>
@@ -408,6 +408,13 @@ __global__ __launch_bounds__(512) void slabgemm_kernel(const RunGemm d, const Ar
         prologue(t + gridDim.x);
       }
       continue;
+    } else if (dbg & 64) {                                   // (tuning: no epilogue at all)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));      // every accumulator element stays live: nothing upstream is dead code
     } else {
       // ---- epilogue, wave local, no LDS for the tile: bias / ReLU / statistics on the accumulators as they sit, quad transpose (dev_common.h
       // QuadT), 8-byte row-piece stores.  The next tile's first slab and weights are in flight meanwhile.
@@ -520,6 +527,8 @@ bool launch_slabgemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
     case 10: SEFD_SLAB_LAUNCH(10); break;
     case 16: SEFD_SLAB_LAUNCH(16); break;
     case 32: SEFD_SLAB_LAUNCH(32); break;
+    case 64: SEFD_SLAB_LAUNCH(64); break;
+    case 74: SEFD_SLAB_LAUNCH(74); break;
     default: SEFD_SLAB_LAUNCH(0); break;
   }
 #undef SEFD_SLAB_LAUNCH
