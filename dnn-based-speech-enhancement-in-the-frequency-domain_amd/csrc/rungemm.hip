@@ -1074,6 +1074,15 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
     cstage = cstage + 1 == S ? 0 : cstage + 1;
   }
   }
+  if (d.flags & (1 << 30)) {                        // tuning (SEFD_WG_DBG=8): no partial-sum stores; every accumulator element stays live
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < KB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(acc[a][b][r]));
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -1166,7 +1175,10 @@ static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t
   else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 4>), grid, dim3(256), 0, st, d, ab);
 }
 
-void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+void launch_wgrad(const RunGemm& d0, const ArenaBases& ab, hipStream_t st) {
+  static const int wdbg = getenv("SEFD_WG_DBG") ? atoi(getenv("SEFD_WG_DBG")) : 0;
+  RunGemm d = d0;
+  if (wdbg & 8) d.flags |= 1 << 30;
   if (d.xdt == DT_BF16 && (d.flags & kRunAligned)) {
     if (d.flags & kRunWgWide) { if (d.Npad % 256 == 0) launch_wgrad_wide(d, ab, st); else launch_wgrad_wide128(d, ab, st); return; }
     switch (wgrad_tn(d.xdt, d.N, d.Npad)) {        // sefd_desc.h: the planner sized nsplit for the same tile
