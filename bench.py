@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-b32", action="store_true", help="also time the CPU baseline at B = 32 (1 warm-up + 5 timed steps, ~2 minutes)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--from-host", action="store_true", help="side figure for DESIGN.md: every timed step first copies its batch from pinned host memory "
+                                                               "(same stream, not overlapped) - the PCIe-inclusive rate; never the reported `value`")
     ap.add_argument("--no-extra", action="store_true", help="skip the two side figures of the default run (B = 64 bf16, B = 32 fp32)")
     return ap.parse_args()
 
@@ -319,6 +321,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.from_host:
+        hx, hy = x.cpu().pin_memory(), y.cpu().pin_memory()
+        _step = model.train_step
+
+        def _from_host(xd, yd, *a, **k):
+            xd.copy_(hx, non_blocking=True)
+            yd.copy_(hy, non_blocking=True)
+            return _step(xd, yd, *a, **k)
+        model.train_step = _from_host
+        workload += " [batch copied from pinned host memory inside every step: PCIe-inclusive side figure]"
     kw = {"perceptual": args.perceptual} if args.perceptual else {}
     if args.perceptual and args.model == "fullsubnet":
         raise SystemExit("--perceptual applies to the DCCRN models")

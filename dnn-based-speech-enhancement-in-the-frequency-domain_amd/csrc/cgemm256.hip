@@ -210,7 +210,8 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = (!BNB && staged) ? bv[j] : 0.f;       // the plain staged epilogue finds the bias already summed in
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;      // (the bias is NOT summed in here: bias + sum rounds differently from sum + bias, and the kernels of
+                                                              // this library produce bit-identical outputs for the same GEMM - eval-mode batch independence test)
     uint4 af[MI], bf[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) af[i] = make_uint4(0, 0, 0, 0);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
           float v[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            v[e] = acc[i][j][e];                             // bias included (accumulator init)
+            v[e] = acc[i][j][e] + bv[j];
             if (d.flags & kRunRelu) v[e] = fmaxf(v[e], 0.f);
           }
           if (want_stats && nok) {
