@@ -208,6 +208,18 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     else launch_misc(op, ab, s);
     if (tev) (void)hipEventRecord((*tev)[2 * idx + 1], s);
   };
+  // Two stacked row-block LSTM layers (FullSubNet's sub-band model) that follow each other on the main stream become ONE launch
+  // (lstm_rows.hip lstm_fwd_rows_pair_kernel): true = ops i and i + 1 were both issued
+  auto launch_pair = [&](int i, hipStream_t s) -> bool {
+    if (i + 1 >= last || i == at) return false;
+    const Op &a = ops[i], &b = ops[i + 1];
+    if (a.kind != OP_LSTM_FWD || b.kind != OP_LSTM_FWD || a.lane != 0 || b.lane != 0 || b.join != 0) return false;
+    if (a.lstm.impl != 1 || b.lstm.impl != 1 || a.lstm.hdt != DT_BF16) return false;
+    if (tev) (void)hipEventRecord((*tev)[2 * i], s);
+    if (!launch_lstm_rows_pair(a.lstm, b.lstm, ab, s)) return false;
+    if (tev) { (void)hipEventRecord((*tev)[2 * i + 1], s); (void)hipEventRecord((*tev)[2 * i + 2], s); (void)hipEventRecord((*tev)[2 * i + 3], s); }
+    return true;
+  };
   // Two-lane execution of a whole phase: lane-1 ops (weight gradients, the folds of their row-split partial sums, the early UNPACK) in front
   // of the first LSTM backward are held back and issued on the side stream right after that kernel, so they fill the CUs the recurrence
   // leaves idle; later lane-1 ops follow at their program position, except the ones marked kOpHold, which wait for the NEXT recurrence
@@ -221,7 +233,11 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     two_lane = any2 || (any1 && lstm);
   }
   if (!two_lane) {                                       // program order on one stream is always a valid schedule
-    for (int i = first; i < last; ++i) { launch(ops[i], st); if (i == at && cb) cb(ctx); }
+    for (int i = first; i < last; ++i) {
+      if (launch_pair(i, st)) { ++i; if (i == at && cb) cb(ctx); continue; }
+      launch(ops[i], st);
+      if (i == at && cb) cb(ctx);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (!h->side) {
@@ -310,6 +326,7 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     }
     if (op.join == 1 || (op.kind == OP_UNPACK && op.join != kOpNoJoin)) join();   // UNPACK gathers gradient partials: needs the side lane's results
                                                          // (kOpNoJoin: a bucket whose partials all come from the main stream - FullSubNet's full-band model)
+    if (launch_pair(i, st)) { ++i; fork_fresh = false; if (i == at && cb) cb(ctx); continue; }
     launch(op, st);
     fork_fresh = false;
     if (i == at && cb) cb(ctx);                          // e.g. the first gradient bucket is complete: the caller starts its all-reduce

@@ -197,5 +197,6 @@ void launch_cbn(const Op& op, const ArenaBases& ab, hipStream_t st);       // Co
 void launch_lstm_bf16(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);
 void launch_lstm_cluster(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);   // H > 128 (lstm_cluster.hip)
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd);      // impl == 1 (lstm_rows.hip)
+bool launch_lstm_rows_pair(const LstmRec& d0, const LstmRec& d1, const ArenaBases& ab, hipStream_t st);   // two stacked forward layers, one launch
 
 }  // namespace sefd

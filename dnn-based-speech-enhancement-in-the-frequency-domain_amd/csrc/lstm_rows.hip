@@ -13,7 +13,9 @@
 // Same descriptor, buffers, gate-column order (unit-major) and arithmetic contract as the other LSTM kernels (LstmRec, impl == 1).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -93,16 +95,17 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&acc)[MT][4]) {
 // the other's MFMAs (measured on FullSubNet's sub-band layers, ms per launch: 4 waves 19.7 forward / 18.5 backward)
 // XF: input features whose projection is fused into the recurrence: 0 (gx holds the hoisted GEMM's pre-activations), 32 (one extra k-step,
 // A fragments of x_t in registers) or H (x_t = the layer below's h_t: a third LDS tile, H/32 more k-steps per unit block)
+// The body takes the row block as a parameter: one launch per layer runs it on block blockIdx.x (lstm_fwd_rows_kernel); the two-layer launch
+// (lstm_fwd_rows_pair_kernel below) runs the first layer's blocks and, behind a per-block flag, the second layer's on the same grid.
 template <int H, int MT, int NW, bool G16, int XF>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
+__device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const ArenaBases& ab, const int blk, uint16_t* hl /* LDS [2][RB][HS] (+ [RB][HS] for x_t when XH) */) {
   constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = (KS % 3 == 0 ? 3 : 4) * (NW == 4 ? 2 : 1), NTHR = NW * 64;
   constexpr bool XK = XF > 0, X32 = XF == 32, XH = XF == H && H != 32;
   static_assert(XF == 0 || X32 || XH, "fused input width");
-  extern __shared__ __attribute__((aligned(16))) uint16_t hl[];          // [2][RB][HS] (+ [RB][HS] for x_t when XH)
   const int T = d.T;
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const int64_t row0 = (int64_t)blk * RB;
   const char* gx = rp(ab, d.gx);
   char* gates = rp(ab, d.gates);
   float* cs = reinterpret_cast<float*>(rp(ab, d.c));
@@ -195,7 +198,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
 #pragma unroll
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[ks][q] = *reinterpret_cast<const uint4*>(wrow + ((k0 + ks) * 4 + q) * 512);
+            for (int q = 0; q < 4; ++q) {
+#ifdef SEFD_ROWS_L1DBG
+              int z = 0; asm volatile("" : "+s"(z));        // tuning: every weight load hits the same L1 lines (wrong results, latency probe)
+              bq[ks][q] = *reinterpret_cast<const uint4*>(wbase + (((k0 + ks) * z * 4 + q) * 64 + lane) * 8);
+#else
+              bq[ks][q] = *reinterpret_cast<const uint4*>(wrow + ((k0 + ks) * 4 + q) * 512);
+#endif
+            }
         };
         auto mulc = [&](const uint4 (&bq)[KC][4], int k0) {
 #pragma unroll
@@ -271,6 +281,57 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d,
       if (t + 1 < T) fill_x(t + 1);
       lds_barrier();
     }
+  }
+}
+
+template <int H, int MT, int NW, bool G16, int XF>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t hl[];
+  lstm_fwd_rows_body<H, MT, NW, G16, XF>(d, ab, (int)blockIdx.x, hl);
+}
+
+// ------------------------------------------------------------------------------------------------- two stacked layers, one launch
+// FullSubNet's sub-band model at B = 64: 16 448 rows = 343 row blocks on 256 CUs (one block per CU: LDS) - a layer's launch is two
+// dispatch rounds, the second with 87 blocks on 87 CUs, and the layer above cannot start before the last block has finished.  But block
+// j of the layer above reads only what block j of the layer below wrote (its rows' h_t, after dropout).  One launch of 2 x nblk
+// workgroups: a workgroup draws a job number (an atomic ticket: jobs are taken in the order workgroups START, whatever the dispatch order
+// is); jobs 0 .. nblk-1 are the lower layer's blocks, job nblk + j is block j of the upper layer and first waits for flag j, which the lower
+// block sets behind an agent-scope release of its stores (cdna_hip_programming.md guideline 16: drain, barrier, one lane releases and
+// stores the flag; the consumer polls one word, one lane acquires, barrier, plain loads).  Every upper job is drawn after ALL lower jobs have
+// been drawn by workgroups that are running, so the wait cannot deadlock; it is bounded all the same (a lost block must not hang the device):
+// a workgroup whose budget ran out reports through the plan's status word like the cluster kernels do (guarded Adam skips, next run returns -5).
+// The CUs the lower layer's second round leaves idle work on the upper layer: (343 t0 + 343 t1) / 256 instead of 2 t0 + 2 t1.
+// sync[0] = ticket counter, sync[1 + j] = flag of block j; zeroed by a memset node in front of every launch.
+constexpr int kPairSpinBudget = 1 << 24;         // polls of ~1 us
+
+template <int H, int MT, int NW, bool G16, int XF0>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_pair_kernel(const LstmRec d0, const LstmRec d1, const ArenaBases ab, unsigned* sync) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t hl[];
+  const int nblk = (int)(gridDim.x >> 1);
+  // the job number travels through the first word of the dynamic LDS (a static word next to 160 KB of dynamic LDS would not fit the attribute)
+  if (threadIdx.x == 0) reinterpret_cast<unsigned*>(hl)[0] = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int job = (int)reinterpret_cast<const unsigned*>(hl)[0];
+  __syncthreads();                                                     // the body starts by clearing the tiles
+  if (job < nblk) {
+    lstm_fwd_rows_body<H, MT, NW, G16, XF0>(d0, ab, job, hl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // every storing wave drains its own stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // write back this XCD's dirty lines (h / hd of the block among them)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(sync + 1 + job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    const int j = job - nblk;
+    if (threadIdx.x == 0) {
+      int budget = kPairSpinBudget;
+      while (__hip_atomic_load(sync + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && budget > 0) { --budget; __builtin_amdgcn_s_sleep(32); }
+      if (budget <= 0) set_status(ab.status, ab.dstatus);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    lstm_fwd_rows_body<H, MT, NW, G16, H>(d1, ab, j, hl);
   }
 }
 
@@ -378,7 +439,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)                       // fragment-major packing (sefd_desc.h rows_wb_index)
+            {
+#ifdef SEFD_ROWS_L1DBG
+              int z = 0; asm volatile("" : "+s"(z));
+              bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (((int64_t)(nt * KS + (k0 + ks) * z)) * 64 + lane) * 8);
+#else
               bq[ks][nt] = *reinterpret_cast<const uint4*>(wp + (((int64_t)(unit_of(nt) >> 4) * KS + k0 + ks) * 64 + lane) * 8);
+#endif
+            }
         };
         auto mulc = [&](const uint4 (&bq)[KC][NT], int k0) {
 #pragma unroll
@@ -444,12 +512,59 @@ static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
   else launch_r2<H, MT, false>(d, ab, st, fwd);
 }
 
+// ---- two stacked forward layers in one launch (lstm_fwd_rows_pair_kernel)
+static unsigned* pair_sync(hipStream_t st, size_t words) {
+  // one buffer per stream (launches on one stream are ordered); zeroed in front of every launch by the caller
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, unsigned*> map;
+  constexpr size_t kWords = 1 << 16;
+  if (words > kWords) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = map.find(st);
+  if (it != map.end()) return it->second;
+  unsigned* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), kWords * sizeof(unsigned)) != hipSuccess) return nullptr;
+  map.emplace(st, p);
+  return p;
+}
+
+template <int H, int MT, bool G16>
+static bool launch_pair2(const LstmRec& d0, const LstmRec& d1, const ArenaBases& ab, hipStream_t st) {
+  constexpr int NW = 8;
+  const unsigned nblk = (unsigned)((d0.B + 16 * MT - 1) / (16 * MT));
+  unsigned* sync = pair_sync(st, 1 + (size_t)nblk);
+  if (!sync) return false;
+  const size_t sh3 = (size_t)3 * 16 * MT * (H + 8) * 2;
+  static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_pair_kernel<H, MT, NW, G16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+  (void)once;
+  if (hipMemsetAsync(sync, 0, (1 + (size_t)nblk) * sizeof(unsigned), st) != hipSuccess) return false;
+  hipLaunchKernelGGL((lstm_fwd_rows_pair_kernel<H, MT, NW, G16, 32>), dim3(2 * nblk), dim3(NW * 64), sh3, st, d0, d1, ab, sync);
+  return true;
+}
+
+// d0, d1: consecutive OP_LSTM_FWD descriptors of one stream (impl == 1).  True when both were issued as ONE launch; false: launch them one by one.
+bool launch_lstm_rows_pair(const LstmRec& d0, const LstmRec& d1, const ArenaBases& ab, hipStream_t st) {
+  // read per call: the equivalence test flips it between two steps of one model
+  if ((getenv("SEFD_ROWS_PAIR") && atoi(getenv("SEFD_ROWS_PAIR")) == 0) || getenv("SEFD_ROWS_FWD")) return false;
+  const Ptr& below = d0.hd.arena >= 0 ? d0.hd : d0.h;               // what the upper layer reads: h after the fused dropout, or h
+  if (d0.impl != 1 || d1.impl != 1 || d0.H != d1.H || d0.B != d1.B || d0.T != d1.T || d0.gxdt != d1.gxdt || d0.hdt != DT_BF16 || d1.hdt != DT_BF16) return false;
+  if (d0.xfeat != 32 || d1.xfeat != d1.H || d1.xin.arena != below.arena || d1.xin.off != below.off) return false;
+  if (d0.t1 != 0 || d1.t1 != 0 || d0.t0 != 0 || d1.t0 != 0) return false;
+  const bool g16 = d0.gxdt == DT_BF16;
+  switch (d0.H) {
+    case 256: return g16 ? launch_pair2<256, 3, true>(d0, d1, ab, st) : launch_pair2<256, 3, false>(d0, d1, ab, st);
+    case 384: return g16 ? launch_pair2<384, 3, true>(d0, d1, ab, st) : launch_pair2<384, 3, false>(d0, d1, ab, st);
+    case 512: return g16 ? launch_pair2<512, 2, true>(d0, d1, ab, st) : launch_pair2<512, 2, false>(d0, d1, ab, st);
+    default: return false;
+  }
+}
+
 void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
   // forward, H = 384 (FullSubNet's sub-band model), ms per training step.  Row-major packed weights: 48 rows x 8 waves 110.8, 48 x 4 111.9,
   // 80 rows x 4 waves 102.7.  Fragment-major weights: 88.6 / 88.7 / 89.9 - the geometry stopped mattering (HBM-bound); 48 x 8 is launched,
   // SEFD_ROWS_FWD=54 / 34 select the others.
   static const int fv = getenv("SEFD_ROWS_FWD") ? atoi(getenv("SEFD_ROWS_FWD")) : 0;
-  if (fwd && d.H == 384 && fv == 54) { if (d.gxdt == DT_BF16) launch_r2<384, 5, true, 4>(d, ab, st, true); else launch_r2<384, 5, false, 4>(d, ab, st, true); return; }
+  if (fwd && d.H == 384 && fv == 54 && d.xfeat != 384) { if (d.gxdt == DT_BF16) launch_r2<384, 5, true, 4>(d, ab, st, true); else launch_r2<384, 5, false, 4>(d, ab, st, true); return; }
   switch (d.H) {
     case 256: launch_r<256, 3>(d, ab, st, fwd); break;
     case 384: launch_r<384, 3>(d, ab, st, fwd); break;

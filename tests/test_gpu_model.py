@@ -780,6 +780,43 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     assert torch.equal(grads[0], grads[2])
 
 
+def test_paired_subband_layers_equal_two_launches(monkeypatch):
+    """FullSubNet's two sub-band LSTM layers run as ONE launch (lstm_rows.hip lstm_fwd_rows_pair_kernel: block j of the upper layer starts behind
+    a flag of block j of the lower layer, on whatever CU is free) - a schedule, not a different computation: loss and gradients of a fused step
+    are BIT-identical to the two-launch schedule (SEFD_ROWS_PAIR=0).  B = 16: 4 112 rows = 86 blocks per layer, all 172 workgroups resident at
+    once, so every upper block really waits on its flag; the bench size (B = 64: 2 x 343 workgroups on 256 CUs) is the many-rounds case."""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.optim import Adam
+    cfg.loss, cfg.act_dtype = "MSE", "bf16"
+    try:
+        torch.manual_seed(0)
+        m = models.FullSubNet().to("cuda").train()
+    finally:
+        cfg.act_dtype = "fp32"
+    opt = Adam(m.parameters(), lr=0.0)
+    for B in (16, 64):
+        x, y = _bench_batch(B)
+        grads, losses = [], []
+        for rep, pair in enumerate((True, False, True)):
+            if pair:
+                monkeypatch.delenv("SEFD_ROWS_PAIR", raising=False)
+            else:
+                monkeypatch.setenv("SEFD_ROWS_PAIR", "0")
+            if rep > 0:                                        # same dropout masks: the step counter behind the mask hash goes back by one
+                plan, ar = next(v for k, v in m._runtimes.items() if k[0] == "fsn" and k[1] == B)
+                plan.view(ar, "io.seed").view(torch.int32)[:1].sub_(1)
+            losses.append(float(m.train_step(x, y, opt)))
+            torch.cuda.synchronize()
+            grads.append(m._flat_grad.clone())
+        monkeypatch.delenv("SEFD_ROWS_PAIR", raising=False)
+        assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
+        assert losses[0] == losses[1] == losses[2], (B, losses)
+        assert torch.equal(grads[0], grads[1]), (B, float((grads[0] - grads[1]).abs().max()))
+        assert torch.equal(grads[0], grads[2])
+        assert next(v for k, v in m._runtimes.items() if k[0] == "fsn" and k[1] == B)[0].status() == 0
+
+
 def test_plan_status_word_guards_adam_and_checkpoint(tmp_path):
     """A kernel that gives up (the cluster LSTM's bounded hand-over waits) sets its PLAN's host-mapped status word.  From then on: the
     guarded Adam leaves parameters and moments untouched (no garbage step), save_checkpoint refuses to write, the plan's next run raises -
