@@ -12,6 +12,7 @@
 //     to LDS (the GEMM's A operand) and to memory (the weight / input gradient GEMMs read it), W_hh^T fragments stream from L2.
 // Same descriptor, buffers, gate-column order (unit-major) and arithmetic contract as the other LSTM kernels (LstmRec, impl == 1).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -102,6 +103,11 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
   constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = (KS % 3 == 0 ? 3 : 4) * (NW == 4 ? 2 : 1), NTHR = NW * 64;
   constexpr bool XK = XF > 0, X32 = XF == 32, XH = XF == H && H != 32;
   static_assert(XF == 0 || X32 || XH, "fused input width");
+  // CL: the cell state of the workgroup's rows stays in LDS between frames (fp32 [RB][CS]; a lane re-reads next frame exactly the cells it
+  // wrote - same wave, same lane, no barrier) instead of being read back from the c slab in memory: only where the tiles leave room, i.e. not
+  // next to the x_t tile of a stacked layer.  CS = H + 4: the four row groups of a wave instruction (rows 4 kq + r) fall into different banks.
+  constexpr int CS = H + 4;
+  constexpr bool CL = X32 && (size_t)2 * RB * HS * 2 + (size_t)RB * CS * 4 <= 160 * 1024;
   const int T = d.T;
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,6 +126,7 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
   const uint32_t seed0 = hd ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = hd ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
   for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                  // h_{-1} = 0
   uint16_t* xl = hl + 2 * RB * HS;
+  float* cl = reinterpret_cast<float*>(hl + 2 * RB * HS);   // CL (never together with the x_t tile)
   auto fill_x = [&](int tt) {                      // x_tt of the workgroup's rows -> LDS (16-byte chunks)
     if constexpr (XH) {
       for (int i = tid; i < RB * (H / 8); i += NTHR) {
@@ -169,7 +176,12 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
         for (int r = 0; r < 4; ++r) {
           const int64_t rt = (int64_t)t * rows + rrow[mt][r];
           if constexpr (!XK) gxr[mt][r] = *reinterpret_cast<const typename GateRaw<G16>::type*>(gx + (rt * gx_ld + 4 * unit) * (G16 ? 2 : 4));
-          cpv[mt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
+#if defined(SEFD_ROWS_DBG) && (SEFD_ROWS_DBG & 4)
+          cpv[mt][r] = 0.25f;                                              // tuning: no c_{t-1} loads
+#else
+          if constexpr (CL) cpv[mt][r] = t > 0 ? cl[(16 * mt + 4 * kq + r) * CS + unit] : 0.f;
+          else cpv[mt][r] = t > 0 ? cs[(rt - rows) * H + unit] : 0.f;
+#endif
         }
       f32x4 acc[MT][4];
 #pragma unroll
@@ -199,6 +211,9 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
           for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+#if defined(SEFD_ROWS_DBG) && (SEFD_ROWS_DBG & 1)
+              if (ks > 0 || k0 > 0) { bq[ks][q] = bq[0][q]; continue; }     // tuning: one k-step's weights per unit block (wrong results)
+#endif
 #ifdef SEFD_ROWS_L1DBG
               int z = 0; asm volatile("" : "+s"(z));        // tuning: every weight load hits the same L1 lines (wrong results, latency probe)
               bq[ks][q] = *reinterpret_cast<const uint4*>(wbase + (((k0 + ks) * z * 4 + q) * 64 + lane) * 8);
@@ -213,9 +228,15 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const uint4 a = *reinterpret_cast<const uint4*>(atile + (16 * mt + ln) * HS + 32 * (k0 + ks) + 8 * kq);
+#if defined(SEFD_ROWS_DBG) && (SEFD_ROWS_DBG & 8)
+              asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));   // tuning: no MFMAs (operands stay live)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(bq[ks][q].x), "v"(bq[ks][q].y), "v"(bq[ks][q].z), "v"(bq[ks][q].w));
+#else
 #pragma unroll
               for (int q = 0; q < 4; ++q)
                 acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[ks][q]), acc[mt][q], 0, 0, 0);
+#endif
             }
         };
         // measured (sub-band layers, ms per launch): one chunk of 3 k-steps at a time 15.6; chunks of 2 double buffered 17.5 (the second
@@ -240,21 +261,35 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int rp2 = 0; rp2 < 4; rp2 += 2) {
+#if defined(SEFD_ROWS_DBG) && (SEFD_ROWS_DBG & 16)
+          const f32x2 ig = f32x2{acc[mt][0][rp2], acc[mt][0][rp2 + 1]} * 0.1f;     // tuning: no transcendentals
+          const f32x2 fg = f32x2{acc[mt][1][rp2], acc[mt][1][rp2 + 1]} * 0.1f;
+          const f32x2 gg = f32x2{acc[mt][2][rp2], acc[mt][2][rp2 + 1]} * 0.1f;
+          const f32x2 og = f32x2{acc[mt][3][rp2], acc[mt][3][rp2 + 1]} * 0.1f;
+          const f32x2 cn = fma2(fg, f32x2{cpv[mt][rp2], cpv[mt][rp2 + 1]}, ig * gg);
+          const f32x2 hv = og * cn;
+#else
           const f32x2 ig = sigmoid2(f32x2{acc[mt][0][rp2], acc[mt][0][rp2 + 1]});
           const f32x2 fg = sigmoid2(f32x2{acc[mt][1][rp2], acc[mt][1][rp2 + 1]});
           const f32x2 gg = tanh2(f32x2{acc[mt][2][rp2], acc[mt][2][rp2 + 1]});
           const f32x2 og = sigmoid2(f32x2{acc[mt][3][rp2], acc[mt][3][rp2 + 1]});
           const f32x2 cn = fma2(fg, f32x2{cpv[mt][rp2], cpv[mt][rp2 + 1]}, ig * gg);
           const f32x2 hv = og * tanh2(cn);
+#endif
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int r = rp2 + k;
             hn[(16 * mt + 4 * kq + r) * HS + unit] = f2bf(hv[k]);
+            if constexpr (CL) cl[(16 * mt + 4 * kq + r) * CS + unit] = cn[k];
+#if defined(SEFD_ROWS_DBG) && (SEFD_ROWS_DBG & 2)
+            asm volatile("" ::"v"(ig[k]), "v"(fg[k]), "v"(gg[k]), "v"(og[k]), "v"(cn[k]));     // tuning: no gate / cell-state stores
+#else
             if (rvalid[mt][r]) {
               const int64_t rt = (int64_t)t * rows + rrow[mt][r];
               st_gate4<G16>(gates, rt * gx_ld + 4 * unit, ig[k], fg[k], gg[k], og[k]);
               cs[rt * H + unit] = cn[k];
             }
+#endif
           }
         }
     }
@@ -478,6 +513,7 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
   const unsigned grid = (unsigned)((d.B + 16 * MT - 1) / (16 * MT));
   if (fwd) {
     const size_t sh = (size_t)2 * 16 * MT * (H + 8) * 2;
+    const size_t shc = sh + (size_t)16 * MT * (H + 4) * 4 <= 160 * 1024 ? sh + (size_t)16 * MT * (H + 4) * 4 : sh;   // + the cell-state tile (kernel: CL)
     if (d.xfeat == H && H != 32) {
       const size_t sh3 = (size_t)3 * 16 * MT * (H + 8) * 2;
       static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
@@ -486,7 +522,7 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
     } else if (d.xfeat == 32) {
       static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
       (void)once;
-      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, 32>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
+      hipLaunchKernelGGL((lstm_fwd_rows_kernel<H, MT, NW, G16, 32>), dim3(grid), dim3(NW * 64), shc, st, d, ab);
     } else {
       static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_kernel<H, MT, NW, G16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
       (void)once;
@@ -534,7 +570,8 @@ static bool launch_pair2(const LstmRec& d0, const LstmRec& d1, const ArenaBases&
   const unsigned nblk = (unsigned)((d0.B + 16 * MT - 1) / (16 * MT));
   unsigned* sync = pair_sync(st, 1 + (size_t)nblk);
   if (!sync) return false;
-  const size_t sh3 = (size_t)3 * 16 * MT * (H + 8) * 2;
+  const size_t sh2c = (size_t)2 * 16 * MT * (H + 8) * 2 + (size_t)16 * MT * (H + 4) * 4;      // lower layer: h tiles + cell-state tile (if it fits: CL)
+  const size_t sh3 = std::max((size_t)3 * 16 * MT * (H + 8) * 2, sh2c <= 160 * 1024 ? sh2c : (size_t)0);
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_pair_kernel<H, MT, NW, G16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
   (void)once;
   if (hipMemsetAsync(sync, 0, (1 + (size_t)nblk) * sizeof(unsigned), st) != hipSuccess) return false;

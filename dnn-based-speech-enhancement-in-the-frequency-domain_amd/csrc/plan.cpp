@@ -2984,7 +2984,11 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     auto fc_backward = [&](FcRt& fc, Ptr dy, Ptr x, int64_t rows, int H, int O, int ld, Ptr dh, int tag, const std::string& nm, bool head_fused = false) {
       RunGemm fw = fc.g;
       fw.ydt = adt; fw.flags = 0;
+      // the sub-band head's weight gradient (a 1.2 ms pass over h of the upper layer in front of the first recurrence): on the weight-gradient
+      // lane it is held back and runs in the CUs the recurrence's second dispatch round leaves idle
+      if (head_fused) b.cur_lane = wg_lane;
       b.wgrad(R, fw, dy, fc.coef, tag, &fc.bias);
+      b.cur_lane = 0;
       if (head_fused) return;                             // the row-block LSTM backward forms dh = dy . W_fc itself (O = 2: a rank-2 update)
       RunGemm g = seq_gemm(dy, adt, rows, ld, 0, O, H, DT_F32);
       const Builder::Coef cf = fc.coef;
