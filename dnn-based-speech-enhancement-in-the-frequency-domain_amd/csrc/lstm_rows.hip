@@ -99,7 +99,8 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&acc)[MT][4]) {
 // The body takes the row block as a parameter: one launch per layer runs it on block blockIdx.x (lstm_fwd_rows_kernel); the two-layer launch
 // (lstm_fwd_rows_pair_kernel below) runs the first layer's blocks and, behind a per-block flag, the second layer's on the same grid.
 template <int H, int MT, int NW, bool G16, int XF>
-__device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const ArenaBases& ab, const int blk, uint16_t* hl /* LDS [2][RB][HS] (+ [RB][HS] for x_t when XH) */) {
+__device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const ArenaBases& ab, const int blk, uint16_t* hl /* LDS [2][RB][HS] (+ [RB][HS] for x_t when XH) */,
+                                                   const int tb, const int te /* frames [tb, te); tb > 0 resumes from the stored h / c of frame tb - 1 */) {
   constexpr int KS = H / 32, NUB = H / 16, RB = 16 * MT, HS = H + 8, KC = (KS % 3 == 0 ? 3 : 4) * (NW == 4 ? 2 : 1), NTHR = NW * 64;
   constexpr bool XK = XF > 0, X32 = XF == 32, XH = XF == H && H != 32;
   static_assert(XF == 0 || X32 || XH, "fused input width");
@@ -124,9 +125,25 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
   const float* bias = XK ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   uint16_t* hd = d.hd.arena >= 0 ? reinterpret_cast<uint16_t*>(rp(ab, d.hd)) : nullptr;
   const uint32_t seed0 = hd ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = hd ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
-  for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                  // h_{-1} = 0
   uint16_t* xl = hl + 2 * RB * HS;
   float* cl = reinterpret_cast<float*>(hl + 2 * RB * HS);   // CL (never together with the x_t tile)
+  if (tb == 0) {
+    for (int i = tid; i < 2 * RB * HS; i += NTHR) hl[i] = 0;                // h_{-1} = 0
+  } else {                                         // resume: h_{tb-1} (and, CL, c_{tb-1}) of the rows from the slabs; the other h tile is written whole in frame tb
+    uint16_t* h0 = hl + (tb & 1) * RB * HS;
+    for (int i = tid; i < RB * (H / 8); i += NTHR) {
+      const int row = i / (H / 8), ch = i - row * (H / 8);
+      const int64_t b = row0 + row;
+      *reinterpret_cast<uint4*>(h0 + row * HS + 8 * ch) = *reinterpret_cast<const uint4*>(hout + ((int64_t)(tb - 1) * rows + (b < rows ? b : 0)) * H + 8 * ch);
+    }
+    if constexpr (CL) {
+      for (int i = tid; i < RB * (H / 4); i += NTHR) {
+        const int row = i / (H / 4), ch = i - row * (H / 4);
+        const int64_t b = row0 + row;
+        *reinterpret_cast<float4*>(cl + row * CS + 4 * ch) = *reinterpret_cast<const float4*>(cs + ((int64_t)(tb - 1) * rows + (b < rows ? b : 0)) * H + 4 * ch);
+      }
+    }
+  }
   auto fill_x = [&](int tt) {                      // x_tt of the workgroup's rows -> LDS (16-byte chunks)
     if constexpr (XH) {
       for (int i = tid; i < RB * (H / 8); i += NTHR) {
@@ -136,7 +153,7 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
       }
     }
   };
-  fill_x(0);
+  fill_x(tb);
   __syncthreads();
   bool rvalid[MT][4];
   int64_t rrow[MT][4];
@@ -148,7 +165,7 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
       rvalid[mt][r] = b < rows;
       rrow[mt][r] = rvalid[mt][r] ? b : 0;
     }
-  for (int t = 0; t < T; ++t) {
+  for (int t = tb; t < te; ++t) {
     const uint16_t* hc = hl + (t & 1) * RB * HS;
     uint16_t* hn = hl + ((t + 1) & 1) * RB * HS;
     uint4 xa[X32 ? MT : 1];                         // fused input projection: A fragments of x_t (one k-step of 32 features), all unit blocks
@@ -313,7 +330,7 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
       }
     }
     if constexpr (XH) {                             // every wave is past the barrier: x_t is no longer read; x_{t+1} must be visible before the next frame
-      if (t + 1 < T) fill_x(t + 1);
+      if (t + 1 < te) fill_x(t + 1);
       lds_barrier();
     }
   }
@@ -322,51 +339,63 @@ __device__ __forceinline__ void lstm_fwd_rows_body(const LstmRec& d, const Arena
 template <int H, int MT, int NW, bool G16, int XF>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t hl[];
-  lstm_fwd_rows_body<H, MT, NW, G16, XF>(d, ab, (int)blockIdx.x, hl);
+  lstm_fwd_rows_body<H, MT, NW, G16, XF>(d, ab, (int)blockIdx.x, hl, 0, d.T);
 }
 
 // ------------------------------------------------------------------------------------------------- two stacked layers, one launch
 // FullSubNet's sub-band model at B = 64: 16 448 rows = 343 row blocks on 256 CUs (one block per CU: LDS) - a layer's launch is two
 // dispatch rounds, the second with 87 blocks on 87 CUs, and the layer above cannot start before the last block has finished.  But block
-// j of the layer above reads only what block j of the layer below wrote (its rows' h_t, after dropout).  One launch of 2 x nblk
-// workgroups: a workgroup draws a job number (an atomic ticket: jobs are taken in the order workgroups START, whatever the dispatch order
-// is); jobs 0 .. nblk-1 are the lower layer's blocks, job nblk + j is block j of the upper layer and first waits for flag j, which the lower
-// block sets behind an agent-scope release of its stores (cdna_hip_programming.md guideline 16: drain, barrier, one lane releases and
-// stores the flag; the consumer polls one word, one lane acquires, barrier, plain loads).  Every upper job is drawn after ALL lower jobs have
-// been drawn by workgroups that are running, so the wait cannot deadlock; it is bounded all the same (a lost block must not hang the device):
-// a workgroup whose budget ran out reports through the plan's status word like the cluster kernels do (guarded Adam skips, next run returns -5).
-// The CUs the lower layer's second round leaves idle work on the upper layer: (343 t0 + 343 t1) / 256 instead of 2 t0 + 2 t1.
-// sync[0] = ticket counter, sync[1 + j] = flag of block j; zeroed by a memset node in front of every launch.
+// j of the layer above reads only what block j of the layer below wrote (its rows' h_t, after dropout), frame by frame.  One launch runs
+// both layers as JOBS (layer, time chunk c of C, row block j): a workgroup draws a job number (an atomic ticket: jobs are taken in the
+// order workgroups START, whatever the dispatch order is) and maps it to a job in wavefront order - L(0,.), then L(1,.) U(0,.), then
+// L(2,.) U(1,.) ... U(C-1,.) - so that everything a job waits for carries a smaller number and has been taken by a running workgroup: the
+// waits cannot deadlock.  L(c,j) resumes from the h / c that L(c-1,j) stored (flag); U(c,j) needs U(c-1,j) and L(c,j) (two flags).  A job
+// publishes behind an agent-scope release of its stores (cdna_hip_programming.md guideline 16: drain, barrier, one lane releases and stores
+// the flag; the consumer polls one word, one lane acquires, barrier, plain loads).  The waits are bounded all the same (a lost block must
+// not hang the device): a workgroup whose budget ran out reports through the plan's status word like the cluster kernels do (guarded Adam
+// skips, next run returns -5).  Time chunks make the jobs small against the launch: with whole-sequence jobs (C = 1) the 2 x 343 jobs of
+// 4.75 / 6.5 ms pack into 17.8 ms on 256 CUs, with C = 4 into ~16 (ideal: 15.1; two launches: 22.5).
+// sync[0] = ticket counter, sync[1 + (layer * C + c) * nblk + j] = flag of job (layer, c, j); zeroed by a memset node in front of every launch.
 constexpr int kPairSpinBudget = 1 << 24;         // polls of ~1 us
 
 template <int H, int MT, int NW, bool G16, int XF0>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_pair_kernel(const LstmRec d0, const LstmRec d1, const ArenaBases ab, unsigned* sync) {
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_pair_kernel(const LstmRec d0, const LstmRec d1, const ArenaBases ab, unsigned* sync, const int nblk, const int C) {
   extern __shared__ __attribute__((aligned(16))) uint16_t hl[];
-  const int nblk = (int)(gridDim.x >> 1);
   // the job number travels through the first word of the dynamic LDS (a static word next to 160 KB of dynamic LDS would not fit the attribute)
   if (threadIdx.x == 0) reinterpret_cast<unsigned*>(hl)[0] = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int job = (int)reinterpret_cast<const unsigned*>(hl)[0];
-  __syncthreads();                                                     // the body starts by clearing the tiles
-  if (job < nblk) {
-    lstm_fwd_rows_body<H, MT, NW, G16, XF0>(d0, ab, job, hl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // every storing wave drains its own stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // write back this XCD's dirty lines (h / hd of the block among them)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(sync + 1 + job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else {
-    const int j = job - nblk;
-    if (threadIdx.x == 0) {
-      int budget = kPairSpinBudget;
-      while (__hip_atomic_load(sync + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && budget > 0) { --budget; __builtin_amdgcn_s_sleep(32); }
-      if (budget <= 0) set_status(ab.status, ab.dstatus);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    lstm_fwd_rows_body<H, MT, NW, G16, H>(d1, ab, j, hl);
+  __syncthreads();                                                     // the body starts by writing the tiles
+  // wavefront order: segment 0 = L chunk 0; segments 1 + 2p, 2 + 2p = L chunk p + 1, U chunk p; last segment = U chunk C - 1
+  const int seg = job / nblk, j = job - seg * nblk;
+  int layer, c;
+  if (seg == 0) { layer = 0; c = 0; }
+  else if (seg == 2 * C - 1) { layer = 1; c = C - 1; }
+  else { layer = (seg - 1) & 1; c = (seg - 1) / 2 + (layer == 0 ? 1 : 0); }
+  const int T = d0.T, clen = (T + C - 1) / C;
+  const int tb = c * clen, te = min(T, tb + clen);
+  unsigned* flags = sync + 1;
+  if (threadIdx.x == 0) {
+    int budget = kPairSpinBudget;
+    auto wait = [&](int l2, int c2) {
+      while (__hip_atomic_load(flags + (l2 * C + c2) * nblk + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && budget > 0) { --budget; __builtin_amdgcn_s_sleep(32); }
+    };
+    if (c > 0) wait(layer, c - 1);
+    if (layer == 1) wait(0, c);
+    if (budget <= 0) set_status(ab.status, ab.dstatus);
+    if (c > 0 || layer == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (tb < te) {
+    if (layer == 0) lstm_fwd_rows_body<H, MT, NW, G16, XF0>(d0, ab, j, hl, tb, te);
+    else lstm_fwd_rows_body<H, MT, NW, G16, H>(d1, ab, j, hl, tb, te);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // every storing wave drains its own stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // write back this XCD's dirty lines (the job's h / hd / c among them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flags + (layer * C + c) * nblk + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -553,7 +582,7 @@ static unsigned* pair_sync(hipStream_t st, size_t words) {
   // one buffer per stream (launches on one stream are ordered); zeroed in front of every launch by the caller
   static std::mutex mu;
   static std::unordered_map<hipStream_t, unsigned*> map;
-  constexpr size_t kWords = 1 << 16;
+  constexpr size_t kWords = 1 << 18;
   if (words > kWords) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
   auto it = map.find(st);
@@ -568,14 +597,18 @@ template <int H, int MT, bool G16>
 static bool launch_pair2(const LstmRec& d0, const LstmRec& d1, const ArenaBases& ab, hipStream_t st) {
   constexpr int NW = 8;
   const unsigned nblk = (unsigned)((d0.B + 16 * MT - 1) / (16 * MT));
-  unsigned* sync = pair_sync(st, 1 + (size_t)nblk);
+  // time chunks per layer: SEFD_ROWS_PAIR_CHUNKS, default 4, at least 32 frames each
+  const int cenv = getenv("SEFD_ROWS_PAIR_CHUNKS") ? atoi(getenv("SEFD_ROWS_PAIR_CHUNKS")) : 4;
+  const int C = std::max(1, std::min(std::min(cenv, 16), d0.T / 32));
+  const size_t words = 1 + (size_t)2 * C * nblk;
+  unsigned* sync = pair_sync(st, words);
   if (!sync) return false;
   const size_t sh2c = (size_t)2 * 16 * MT * (H + 8) * 2 + (size_t)16 * MT * (H + 4) * 4;      // lower layer: h tiles + cell-state tile (if it fits: CL)
   const size_t sh3 = std::max((size_t)3 * 16 * MT * (H + 8) * 2, sh2c <= 160 * 1024 ? sh2c : (size_t)0);
   static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_rows_pair_kernel<H, MT, NW, G16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
   (void)once;
-  if (hipMemsetAsync(sync, 0, (1 + (size_t)nblk) * sizeof(unsigned), st) != hipSuccess) return false;
-  hipLaunchKernelGGL((lstm_fwd_rows_pair_kernel<H, MT, NW, G16, 32>), dim3(2 * nblk), dim3(NW * 64), sh3, st, d0, d1, ab, sync);
+  if (hipMemsetAsync(sync, 0, words * sizeof(unsigned), st) != hipSuccess) return false;
+  hipLaunchKernelGGL((lstm_fwd_rows_pair_kernel<H, MT, NW, G16, 32>), dim3(2 * C * nblk), dim3(NW * 64), sh3, st, d0, d1, ab, sync, (int)nblk, C);
   return true;
 }
 
