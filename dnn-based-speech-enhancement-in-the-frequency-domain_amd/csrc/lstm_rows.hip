@@ -17,6 +17,7 @@
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include "sefd_desc.h"
 #include "dev_common.h"
 
@@ -406,16 +407,18 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_pair_kernel(const LstmR
 // recurrent gradient and the cell-state carry are all live across the parts - so only HV = 1 with 48 rows is launched.
 // UP: where the upstream gradient of h_t comes from: 0 the dh array, 1 dh x the inter-layer dropout mask, 2 the 2-output head (rank-2 update).
 // A template parameter, not a run-time flag: with a branch per cell the compiler stops batching the loads of a row tile (9.8 -> 13.3 ms).
+// The body walks frames te-1 .. tb of row block blk.  te < T resumes: the recurrent gradient and the cell-state carry that frame te left (both
+// live in registers across frames) come from `carry` (fp32 [blk][2][RB][H]), where the job of the frames above stored them; tb > 0 stores them.
 template <int H, int MT, int NW, bool G16, int HV, int UP>
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
+__device__ __forceinline__ void lstm_bwd_rows_body(const LstmRec& d, const ArenaBases& ab, const int blk, uint16_t* al /* LDS: dgates_t (one half of the gate
+                                                   columns) of the workgroup's rows: [RB][AS] */, const int tb, const int te, float* carry) {
   constexpr int KS = 4 * H / 32, NT = H / 16 / NW, RB = 16 * MT, AS = 4 * H / HV + 8, KC = H >= 512 ? 4 : (HV > 1 ? 4 : 8);
   constexpr int NTH = NT / HV, KSH = KS / HV;       // unit tiles per wave and k-steps per half
   static_assert(NT % HV == 0, "unit tiles per half");
-  extern __shared__ __attribute__((aligned(16))) uint16_t al[];          // dgates_t (one half of the gate columns) of the workgroup's rows: [RB][AS]
   const int T = d.T;
   const int64_t rows = d.B;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  const int64_t row0 = (int64_t)blk * RB;
   const char* gates = rp(ab, d.gates);
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
   const float* dh = UP == 2 ? nullptr : reinterpret_cast<const float*>(rp(ab, d.dh));
@@ -433,7 +436,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dcar[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int t = T - 1; t >= 0; --t) {
+  float* cbase = carry ? carry + (int64_t)blk * 2 * RB * H : nullptr;
+  if (te < T) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (16 * mt + 4 * kq + r) * H + unit_of(nt);
+          acc[mt][nt][r] = cbase[o];
+          dcar[mt][nt][r] = cbase[RB * H + o];
+        }
+  }
+  for (int t = te - 1; t >= tb; --t) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -532,10 +548,94 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d,
       lds_barrier();
     }
   }
+  if (tb > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (16 * mt + 4 * kq + r) * H + unit_of(nt);
+          cbase[o] = acc[mt][nt][r];
+          cbase[RB * H + o] = dcar[mt][nt][r];
+        }
+  }
+}
+
+template <int H, int MT, int NW, bool G16, int HV, int UP>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_kernel(const LstmRec d, const ArenaBases ab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t al[];
+  lstm_bwd_rows_body<H, MT, NW, G16, HV, UP>(d, ab, (int)blockIdx.x, al, 0, d.T, nullptr);
+}
+
+// One layer's backward recurrence as (time chunk c of C, row block j) jobs, drawn by ticket in chunk-major order (the lstm_fwd_rows_pair_kernel
+// scheme with one layer): 343 blocks on 256 CUs are two dispatch rounds as one launch of whole-sequence workgroups, the second with 87 busy CUs;
+// as C x 343 jobs every CU stays busy until the last chunk.  Job (c, j) covers frames [T - (c + 1) clen, T - c clen) and waits for job (c - 1, j)
+// (smaller ticket: no deadlock; bounded wait, status word), which left the recurrent gradient and the cell-state carry in `carry`.
+template <int H, int MT, int NW, bool G16, int HV, int UP>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_jobs_kernel(const LstmRec d, const ArenaBases ab, unsigned* sync, float* carry, const int nblk, const int C) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t al[];
+  if (threadIdx.x == 0) reinterpret_cast<unsigned*>(al)[0] = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int job = (int)reinterpret_cast<const unsigned*>(al)[0];
+  __syncthreads();
+  const int c = job / nblk, j = job - c * nblk;
+  const int T = d.T, clen = (T + C - 1) / C;
+  const int te = T - c * clen, tb = max(0, te - clen);
+  unsigned* flags = sync + 1;
+  if (c > 0) {
+    if (threadIdx.x == 0) {
+      int budget = kPairSpinBudget;
+      while (__hip_atomic_load(flags + (c - 1) * nblk + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && budget > 0) { --budget; __builtin_amdgcn_s_sleep(32); }
+      if (budget <= 0) set_status(ab.status, ab.dstatus);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  if (tb < te) lstm_bwd_rows_body<H, MT, NW, G16, HV, UP>(d, ab, j, al, tb, te, carry);
+  if (tb > 0) {                                                        // a later job reads the carry (the dgates / dh stores need no hand-over)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(flags + c * nblk + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ launch
 bool lstm_rows_supported(int H) { return H == 256 || H == 384 || H == 512; }
+
+// ticket + flag words of the job kernels
+static unsigned* pair_sync(hipStream_t st, size_t words) {
+  // one buffer per stream (launches on one stream are ordered); zeroed in front of every launch by the caller
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, unsigned*> map;
+  constexpr size_t kWords = 1 << 18;
+  if (words > kWords) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = map.find(st);
+  if (it != map.end()) return it->second;
+  unsigned* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), kWords * sizeof(unsigned)) != hipSuccess) return nullptr;
+  map.emplace(st, p);
+  return p;
+}
+
+// carry of the chunked backward jobs (recurrent gradient + cell-state carry of every row block): one buffer per stream, grown on demand
+static float* rows_carry(hipStream_t st, size_t floats) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, std::pair<float*, size_t>> map;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& e = map[st];
+  if (e.second >= floats) return e.first;
+  if (e.first) { (void)hipStreamSynchronize(st); (void)hipFree(e.first); e = {nullptr, 0}; }
+  float* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), floats * sizeof(float)) != hipSuccess) return nullptr;
+  e = {p, floats};
+  return p;
+}
 
 template <int H, int MT, bool G16, int NW = 8, int HV = 1>
 static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bool fwd) {
@@ -560,8 +660,23 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
   } else {
     const size_t sh = (size_t)16 * MT * (4 * H / HV + 8) * 2;
     const int up = d.no == 2 ? 2 : (d.seed.arena >= 0 && d.keep < 1.f) ? 1 : 0;
+    // more blocks than CUs: (time chunk, row block) jobs (SEFD_ROWS_BWD_CHUNKS, default 5, at least 16 frames each; 1 = whole-sequence workgroups)
+    // (an explicit setting applies to any grid: the equivalence test runs it on a few blocks)
+    const int cenv = getenv("SEFD_ROWS_BWD_CHUNKS") ? atoi(getenv("SEFD_ROWS_BWD_CHUNKS")) : (grid > 256 ? 5 : 1);
+    const int C = std::max(1, std::min(std::min(cenv, 16), d.T / 16));
     auto go = [&](auto upc) {
       constexpr int UPC = decltype(upc)::value;
+      if (C > 1) {
+        const size_t words = 1 + (size_t)C * grid;
+        unsigned* sync = pair_sync(st, words);
+        float* carry = rows_carry(st, (size_t)grid * 2 * 16 * MT * H);
+        if (sync && carry && hipMemsetAsync(sync, 0, words * sizeof(unsigned), st) == hipSuccess) {
+          static bool once2 = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_jobs_kernel<H, MT, NW, G16, HV, UPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+          (void)once2;
+          hipLaunchKernelGGL((lstm_bwd_rows_jobs_kernel<H, MT, NW, G16, HV, UPC>), dim3(C * grid), dim3(NW * 64), sh, st, d, ab, sync, carry, (int)grid, C);
+          return;
+        }
+      }
       static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_rows_kernel<H, MT, NW, G16, HV, UPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
       (void)once;
       hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16, HV, UPC>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
@@ -578,28 +693,13 @@ static void launch_r(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
 }
 
 // ---- two stacked forward layers in one launch (lstm_fwd_rows_pair_kernel)
-static unsigned* pair_sync(hipStream_t st, size_t words) {
-  // one buffer per stream (launches on one stream are ordered); zeroed in front of every launch by the caller
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, unsigned*> map;
-  constexpr size_t kWords = 1 << 18;
-  if (words > kWords) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = map.find(st);
-  if (it != map.end()) return it->second;
-  unsigned* p = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&p), kWords * sizeof(unsigned)) != hipSuccess) return nullptr;
-  map.emplace(st, p);
-  return p;
-}
-
 template <int H, int MT, bool G16>
 static bool launch_pair2(const LstmRec& d0, const LstmRec& d1, const ArenaBases& ab, hipStream_t st) {
   constexpr int NW = 8;
   const unsigned nblk = (unsigned)((d0.B + 16 * MT - 1) / (16 * MT));
-  // time chunks per layer: SEFD_ROWS_PAIR_CHUNKS, default 4, at least 32 frames each
-  const int cenv = getenv("SEFD_ROWS_PAIR_CHUNKS") ? atoi(getenv("SEFD_ROWS_PAIR_CHUNKS")) : 4;
-  const int C = std::max(1, std::min(std::min(cenv, 16), d0.T / 32));
+  // time chunks per layer: SEFD_ROWS_PAIR_CHUNKS, default 5, at least 16 frames each
+  const int cenv = getenv("SEFD_ROWS_PAIR_CHUNKS") ? atoi(getenv("SEFD_ROWS_PAIR_CHUNKS")) : 5;
+  const int C = std::max(1, std::min(std::min(cenv, 16), d0.T / 16));
   const size_t words = 1 + (size_t)2 * C * nblk;
   unsigned* sync = pair_sync(st, words);
   if (!sync) return false;

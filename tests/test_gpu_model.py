@@ -781,10 +781,12 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
 
 
 def test_paired_subband_layers_equal_two_launches(monkeypatch):
-    """FullSubNet's two sub-band LSTM layers run as ONE launch (lstm_rows.hip lstm_fwd_rows_pair_kernel: block j of the upper layer starts behind
-    a flag of block j of the lower layer, on whatever CU is free) - a schedule, not a different computation: loss and gradients of a fused step
-    are BIT-identical to the two-launch schedule (SEFD_ROWS_PAIR=0).  B = 16: 4 112 rows = 86 blocks per layer, all 172 workgroups resident at
-    once, so every upper block really waits on its flag; the bench size (B = 64: 2 x 343 workgroups on 256 CUs) is the many-rounds case."""
+    """FullSubNet's two sub-band LSTM layers run as ONE launch of (layer, time chunk, row block) jobs (lstm_rows.hip lstm_fwd_rows_pair_kernel: a
+    job starts behind the flags of the jobs it reads from, on whatever CU is free), and the backward recurrences as (time chunk, row block) jobs
+    that hand the recurrent gradient and the cell-state carry through memory (lstm_bwd_rows_jobs_kernel) - schedules, not different computations:
+    loss and gradients of a fused step are BIT-identical to whole-sequence workgroups in one launch per layer (SEFD_ROWS_PAIR=0,
+    SEFD_ROWS_BWD_CHUNKS=1).  B = 16: 4 112 rows = 86 blocks per layer, every job resident at once, so the waits are real; the bench size
+    (B = 64: 343 blocks on 256 CUs) is the many-rounds case."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models
     from sefd_amd.optim import Adam
@@ -801,8 +803,13 @@ def test_paired_subband_layers_equal_two_launches(monkeypatch):
         for rep, pair in enumerate((True, False, True)):
             if pair:
                 monkeypatch.delenv("SEFD_ROWS_PAIR", raising=False)
+                if B == 16:
+                    monkeypatch.setenv("SEFD_ROWS_BWD_CHUNKS", "3")     # B = 64 (343 blocks > 256 CUs) chunks the backward by default
+                else:
+                    monkeypatch.delenv("SEFD_ROWS_BWD_CHUNKS", raising=False)
             else:
                 monkeypatch.setenv("SEFD_ROWS_PAIR", "0")
+                monkeypatch.setenv("SEFD_ROWS_BWD_CHUNKS", "1")
             if rep > 0:                                        # same dropout masks: the step counter behind the mask hash goes back by one
                 plan, ar = next(v for k, v in m._runtimes.items() if k[0] == "fsn" and k[1] == B)
                 plan.view(ar, "io.seed").view(torch.int32)[:1].sub_(1)
@@ -810,6 +817,7 @@ def test_paired_subband_layers_equal_two_launches(monkeypatch):
             torch.cuda.synchronize()
             grads.append(m._flat_grad.clone())
         monkeypatch.delenv("SEFD_ROWS_PAIR", raising=False)
+        monkeypatch.delenv("SEFD_ROWS_BWD_CHUNKS", raising=False)
         assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
         assert losses[0] == losses[1] == losses[2], (B, losses)
         assert torch.equal(grads[0], grads[1]), (B, float((grads[0] - grads[1]).abs().max()))
