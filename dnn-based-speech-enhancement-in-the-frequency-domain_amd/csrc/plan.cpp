@@ -2963,12 +2963,27 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       RunGemm fw = L.gx;
       fw.ydt = adt;
       if (gru) set_y(fw, dgates, rows, NG * H, 0);        // the GRU's gradient slab is 3H wide (the forward slab keeps a 4th block for W_hn h + b_hn)
+      Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)(um ? gate_torch_row(nn, H) : nn) * H + j, 1); };
+      // A narrow input (the sub-band model's first layer: 32 features) next to H = 384 recurrent columns: [x_t | h_{t-1} | ones] is 64 + 384 + 64 =
+      // 512 columns = exactly the two 256-wide k tiles the W_hh gradient alone occupies (its second tile half empty) - ONE weight-gradient GEMM
+      // over dgates instead of two (the 1536 x 128 launch for W_ih and the bias, 1.6 ms at B = 64, and its pass over the 9.6 GB gate gradients are gone)
+      const int xw = fw.nseg == 1 ? (int)rup(fw.seg[0].len, 64) : 0;
+      const bool cat = !gru && L.rowsk && fw.nseg == 1 && fw.seg[0].src == 0 && xw == 64 && H % 64 == 0 && rup(xw + H + 64, 256) == rup(H, 256) &&
+                       !(getenv("SEFD_FSN_WGCAT") && atoi(getenv("SEFD_FSN_WGCAT")) == 0);
+      if (cat) {
+        RunGemm fc = fw;
+        fc.x[1] = L.h; fc.bstride[1] = 0; fc.tstride[1] = (int)(rows * H); fc.base[1] = 0; fc.rowlen[1] = (int)(rows * H); fc.fstride[1] = H; fc.Tin[1] = TP;
+        fc.seg[fc.nseg++] = Seg{1, -1, 0, H, 0};           // h_{t-1}
+        const Builder::Coef cgx = L.cgx;
+        Builder::Coef cc = [=](int nn, int s, int j) -> int32_t { return s == 0 ? cgx(nn, 0, j) : chh(nn, 0, j); };
+        b.wgrad(R, fc, dgates, cc, tag, &L.bgx);
+      } else {
       b.wgrad(R, fw, dgates, L.cgx, tag, &L.bgx);
       RunGemm fh = seq_gemm(L.h, adt, rows, H, 0, H, NG * H, adt);
       fh.seg[0].dt = -1;                                   // h_{t-1}
       set_y(fh, dgh, rows, NG * H, 0);
-      Builder::Coef chh = [=](int nn, int s, int j) -> int32_t { return pe(*Whh, (int64_t)(um ? gate_torch_row(nn, H) : nn) * H + j, 1); };
       b.wgrad(R, fh, dgh, chh, tag, gru ? &L.bhh : nullptr);           // GRU: b_hh belongs to this GEMM (bias "ones" run)
+      }
       b.cur_lane = 0;
       b.cur_hold = 0;
       b.wg_rounds = 1;
