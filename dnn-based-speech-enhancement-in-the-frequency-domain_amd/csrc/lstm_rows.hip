@@ -367,14 +367,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_pair_kernel(const LstmR
   __syncthreads();
   const int job = (int)reinterpret_cast<const unsigned*>(hl)[0];
   __syncthreads();                                                     // the body starts by writing the tiles
-  // wavefront order: segment 0 = L chunk 0; segments 1 + 2p, 2 + 2p = L chunk p + 1, U chunk p; last segment = U chunk C - 1
-  const int seg = job / nblk, j = job - seg * nblk;
-  int layer, c;
-  if (seg == 0) { layer = 0; c = 0; }
-  else if (seg == 2 * C - 1) { layer = 1; c = C - 1; }
-  else { layer = (seg - 1) & 1; c = (seg - 1) / 2 + (layer == 0 ? 1 : 0); }
-  const int T = d0.T, clen = (T + C - 1) / C;
-  const int tb = c * clen, te = min(T, tb + clen);
+  const RowsJob rj = rows_pair_job(job, nblk, C, d0.T);               // wavefront order (sefd_desc.h)
+  const int layer = rj.layer, c = rj.chunk, j = rj.block, tb = rj.tb, te = rj.te;
   unsigned* flags = sync + 1;
   if (threadIdx.x == 0) {
     int budget = kPairSpinBudget;
@@ -579,9 +573,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_jobs_kernel(const LstmR
   __syncthreads();
   const int job = (int)reinterpret_cast<const unsigned*>(al)[0];
   __syncthreads();
-  const int c = job / nblk, j = job - c * nblk;
-  const int T = d.T, clen = (T + C - 1) / C;
-  const int te = T - c * clen, tb = max(0, te - clen);
+  const RowsJob rj = rows_bwd_job(job, nblk, C, d.T);                 // chunk-major order, last frames first (sefd_desc.h)
+  const int c = rj.chunk, j = rj.block, tb = rj.tb, te = rj.te;
   unsigned* flags = sync + 1;
   if (c > 0) {
     if (threadIdx.x == 0) {
@@ -593,7 +586,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_rows_jobs_kernel(const LstmR
     __syncthreads();
   }
   if (tb < te) lstm_bwd_rows_body<H, MT, NW, G16, HV, UP>(d, ab, j, al, tb, te, carry);
-  if (tb > 0) {                                                        // a later job reads the carry (the dgates / dh stores need no hand-over)
+  if (c + 1 < C) {                                                     // a later job reads the carry (the dgates / dh stores need no hand-over)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -471,6 +471,39 @@ struct Op {
   };
 };
 
+// ---- job order of the row-block recurrence launches that run as ticket-drawn jobs (lstm_rows.hip; checked on the CPU by tests/test_plan_hostsim.py)
+#ifdef __HIPCC__
+#define SEFD_HD __host__ __device__
+#else
+#define SEFD_HD
+#endif
+struct RowsJob { int layer, chunk, block, tb, te; };      // frames [tb, te) of row block `block`
+// lstm_fwd_rows_pair_kernel: two stacked layers x C time chunks x nblk row blocks, wavefront order: segment 0 = L chunk 0; segments 1 + 2p, 2 + 2p =
+// L chunk p + 1, U chunk p; last segment = U chunk C - 1.  L(c, j) reads L(c - 1, j); U(c, j) reads U(c - 1, j) and L(c, j): all in earlier segments.
+SEFD_HD static inline RowsJob rows_pair_job(int job, int nblk, int C, int T) {
+  RowsJob r;
+  const int seg = job / nblk;
+  r.block = job - seg * nblk;
+  if (seg == 0) { r.layer = 0; r.chunk = 0; }
+  else if (seg == 2 * C - 1) { r.layer = 1; r.chunk = C - 1; }
+  else { r.layer = (seg - 1) & 1; r.chunk = (seg - 1) / 2 + (r.layer == 0 ? 1 : 0); }
+  const int clen = (T + C - 1) / C;
+  r.tb = r.chunk * clen < T ? r.chunk * clen : T;
+  r.te = r.tb + clen < T ? r.tb + clen : T;
+  return r;
+}
+// lstm_bwd_rows_jobs_kernel: C time chunks x nblk row blocks, chunk-major; chunk c covers frames [T - (c + 1) clen, T - c clen) and reads the carry of (c - 1, j)
+SEFD_HD static inline RowsJob rows_bwd_job(int job, int nblk, int C, int T) {
+  RowsJob r;
+  r.layer = 0;
+  r.chunk = job / nblk;
+  r.block = job - r.chunk * nblk;
+  const int clen = (T + C - 1) / C;
+  r.te = T - r.chunk * clen > 0 ? T - r.chunk * clen : 0;
+  r.tb = r.te - clen > 0 ? r.te - clen : 0;
+  return r;
+}
+
 // Tile geometry shared by planner (padding) and kernels.
 constexpr int kBM = 128;                                   // rows per RUNGEMM block == rows per statistics block
 inline int bk_of(int dt) { return dt == DT_BF16 ? 64 : 32; }   // K-tile in elements: 128 bytes of either dtype

@@ -1172,3 +1172,8 @@ extern "C" int hostsim_run(const void* ops_, int first, int last, void* const* a
   return 0;
 }
 extern "C" int hostsim_op_size() { return (int)sizeof(Op); }
+// job order of the ticket-drawn recurrence launches (sefd_desc.h rows_pair_job / rows_bwd_job): out = {layer, chunk, block, tb, te}
+extern "C" void hostsim_rows_job(int bwd, int job, int nblk, int C, int T, int* out) {
+  const RowsJob r = bwd ? rows_bwd_job(job, nblk, C, T) : rows_pair_job(job, nblk, C, T);
+  out[0] = r.layer; out[1] = r.chunk; out[2] = r.block; out[3] = r.tb; out[4] = r.te;
+}

@@ -532,3 +532,50 @@ def test_torchstft_plan_matches_torch_stft():
     sim_run(plan, PHASE_FWD, ar)
     assert plan.T == 21
     assert rel_err(plan.io(ar, "spec", (2, 257, plan.T, 2)), torch.view_as_real(torch_stft(x))) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ job order of the ticket-drawn recurrence launches
+@pytest.mark.parametrize("nblk,C,T", [(343, 5, 190), (86, 4, 188), (11, 1, 9), (3, 11, 190), (257, 16, 301), (1, 2, 33)])
+def test_rows_job_order_is_a_deadlock_free_schedule(nblk, C, T):
+    """lstm_rows.hip draws jobs by atomic ticket, so a workgroup only ever waits for jobs with SMALLER numbers (taken by workgroups that are
+    already running).  The order functions of sefd_desc.h (shared with the kernels) must therefore: enumerate every (layer, chunk, block) once,
+    tile [0, T) with each (layer, block)'s chunks, and put everything a job reads in front of it - forward pair: L(c, j) after L(c-1, j);
+    U(c, j) after U(c-1, j) and L(c, j); backward: (c, j) after (c-1, j), chunks walking from the last frame down."""
+    import ctypes as C_
+    from simutil import sim
+    f = sim().hostsim_rows_job
+    f.restype = None
+
+    def job(bwd, n):
+        out = (C_.c_int * 5)()
+        f(bwd, n, nblk, C, T, out)
+        return tuple(out)
+    # forward pair
+    num = {}
+    for n in range(2 * C * nblk):
+        layer, c, j, tb, te = job(0, n)
+        assert (layer, c, j) not in num and 0 <= layer < 2 and 0 <= c < C and 0 <= j < nblk and 0 <= tb <= te <= T
+        num[(layer, c, j)] = (n, tb, te)
+    assert len(num) == 2 * C * nblk
+    for (layer, c, j), (n, tb, te) in num.items():
+        if c > 0:
+            assert num[(layer, c - 1, j)][0] < n and num[(layer, c - 1, j)][2] == tb      # resumes where the chunk before stopped
+        else:
+            assert tb == 0
+        if c == C - 1:
+            assert te == T
+        if layer == 1:
+            assert num[(0, c, j)][0] < n and num[(0, c, j)][1:] == (tb, te)               # the lower layer's same frames are done
+    # backward
+    num = {}
+    for n in range(C * nblk):
+        layer, c, j, tb, te = job(1, n)
+        assert (c, j) not in num and 0 <= c < C and 0 <= j < nblk and 0 <= tb <= te <= T
+        num[(c, j)] = (n, tb, te)
+    for (c, j), (n, tb, te) in num.items():
+        if c > 0:
+            assert num[(c - 1, j)][0] < n and num[(c - 1, j)][1] == te                     # the carry of the frames above
+        else:
+            assert te == T
+        if c == C - 1:
+            assert tb == 0
