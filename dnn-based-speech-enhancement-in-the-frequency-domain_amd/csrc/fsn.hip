@@ -150,11 +150,6 @@ __global__ __launch_bounds__(256) void fsn_in_kernel(const Fsn d, const ArenaBas
     __syncthreads();
   }
 }
-__device__ __forceinline__ float utt_mean(const float* sums, int b, int F, double count) {    // serial sum of F partials: deterministic
-  double s = 0.0;
-  for (int f = 0; f < F; ++f) s += sums[b * F + f];
-  return (float)(s / count);
-}
 __global__ __launch_bounds__(256) void fsn_scale_kernel(const Fsn d, const ArenaBases ab) {
   const float* mt = reinterpret_cast<const float*>(rp(ab, d.in));
   char* out = rp(ab, d.out);                                             // [TP][B][FP]
@@ -178,11 +173,17 @@ __global__ __launch_bounds__(256) void fsn_scale_kernel(const Fsn d, const Arena
   }
 }
 // means: sums [B][nper] -> aux2[B] = sum / count
-__global__ void fsn_mean_kernel(const Fsn d, const ArenaBases ab, double count, int nper) {
+// one wave per batch item: lane l adds partials l, l + 64, ... in double, then a fixed-order butterfly (one thread per item walking the 257
+// partials was a chain of 257 dependent loads: 60 us per launch, three launches per step on the critical path)
+__global__ __launch_bounds__(64) void fsn_mean_kernel(const Fsn d, const ArenaBases ab, double count, int nper) {
   const float* sums = reinterpret_cast<const float*>(rp(ab, d.sums));
   float* mu = reinterpret_cast<float*>(rp(ab, d.aux2));
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < d.B) mu[b] = utt_mean(sums, b, nper, count);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  for (int f = lane; f < nper; f += 64) s += sums[b * nper + f];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) mu[b] = (float)(s / count);
 }
 
 __device__ __forceinline__ int reflect_idx(int f, int F) { return f < 0 ? -f : (f >= F ? 2 * (F - 1) - f : f); }
@@ -464,14 +465,14 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_FSN_IN: {
       const Fsn& d = op.fsn;
       hipLaunchKernelGGL(fsn_in_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
-      hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP, d.F);
+      hipLaunchKernelGGL(fsn_mean_kernel, dim3(d.B), dim3(64), 0, st, d, ab, (double)d.F * d.TP, d.F);
       break;
     }
     case OP_FSN_SCALE: hipLaunchKernelGGL(fsn_scale_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.FP)), dim3(256), 0, st, op.fsn, ab); break;
     case OP_FSN_SBSUM: {
       const Fsn& d = op.fsn;
       hipLaunchKernelGGL(fsn_sbsum_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
-      hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
+      hipLaunchKernelGGL(fsn_mean_kernel, dim3(d.B), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
       break;
     }
     case OP_FSN_SBBUILD: hipLaunchKernelGGL(fsn_sbbuild_kernel, dim3(gridn((int64_t)op.fsn.TP * op.fsn.B * op.fsn.F * (op.fsn.NB + 1))), dim3(256), 0, st, op.fsn, ab); break;
@@ -480,7 +481,7 @@ void launch_fsn(const Op& op, const ArenaBases& ab, hipStream_t st) {
     case OP_FSN_SBBWD_SUM: {
       const Fsn& d = op.fsn;
       hipLaunchKernelGGL(fsn_sbbwd_sum_kernel, dim3(d.F, d.B), dim3(256), 0, st, d, ab);
-      hipLaunchKernelGGL(fsn_mean_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
+      hipLaunchKernelGGL(fsn_mean_kernel, dim3(d.B), dim3(64), 0, st, d, ab, (double)d.F * d.TP * (d.NB + 1), d.F);
       break;
     }
     case OP_FSN_NORMSTAT: {
