@@ -11,6 +11,10 @@
 //     it computes, so the recurrent gradient and the cell-state carry never leave its registers; dgates_t (16 MT x 4H, bf16) goes
 //     to LDS (the GEMM's A operand) and to memory (the weight / input gradient GEMMs read it), W_hh^T fragments stream from L2.
 // Same descriptor, buffers, gate-column order (unit-major) and arithmetic contract as the other LSTM kernels (LstmRec, impl == 1).
+// Launch forms (round 5, profiles/r05_tuning_notes.md section 8): one workgroup per row block for the whole sequence (lstm_fwd_rows_kernel /
+// lstm_bwd_rows_kernel), or - when a layer has more row blocks than the chip has CUs - ticket-drawn JOBS that keep every CU busy to the end:
+// lstm_fwd_rows_pair_kernel runs two stacked layers as (layer, time chunk, row block) jobs behind agent-scope flags, lstm_bwd_rows_jobs_kernel one
+// layer's backward as (time chunk, row block) jobs that hand the register-resident carry through memory.  Same arithmetic, bit-identical results.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
