@@ -2959,7 +2959,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       // input-gradient GEMM and the NEXT layer's recurrence (343 workgroups of 48 sequences on 256 CUs: its second round leaves 2/3 of the chip idle)
       b.cur_lane = wg_lane;
       b.cur_hold = wg_hold;
-      b.wg_rounds = wg_lane ? (getenv("SEFD_FSN_WG_ROUNDS") ? atoi(getenv("SEFD_FSN_WG_ROUNDS")) : 3) : 1;
+      b.wg_rounds = wg_lane ? (getenv("SEFD_FSN_WG_ROUNDS") ? atoi(getenv("SEFD_FSN_WG_ROUNDS")) : 8) : 1;   // 3 -> 8 with the job-scheduled recurrences (r05 notes): 57.1 -> 56.6 ms
       RunGemm fw = L.gx;
       fw.ydt = adt;
       if (gru) set_y(fw, dgates, rows, NG * H, 0);        // the GRU's gradient slab is 3H wide (the forward slab keeps a 4th block for W_hn h + b_hn)
