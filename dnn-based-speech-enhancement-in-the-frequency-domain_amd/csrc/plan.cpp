@@ -251,7 +251,9 @@ struct Builder {
     else if (narrow && wide_on && g.Npad == 128 && g.ldw >= 1024 && g.M >= wide_minm) { tn = 128; tk = 512; g.flags |= kRunWgWide; }
     // wg_rounds > 1 (FullSubNet): that many dispatch rounds of shorter workgroups - the launch shares the chip with a recurrence whose
     // second round leaves 2/3 of the CUs idle, and a workgroup that needs the whole kernel's duration on its CU cannot use such a hole
-    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768) * std::max(1, wg_rounds);
+    // SEFD_WG_ROUNDS / SEFD_WGW_ROUNDS (tuning): rounds of every weight-gradient GEMM / of the wide-tile ones when the model did not set its own
+    const int env_rounds = (g.flags & kRunWgWide) && getenv("SEFD_WGW_ROUNDS") ? atoi(getenv("SEFD_WGW_ROUNDS")) : getenv("SEFD_WG_ROUNDS") ? atoi(getenv("SEFD_WG_ROUNDS")) : 1;
+    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
