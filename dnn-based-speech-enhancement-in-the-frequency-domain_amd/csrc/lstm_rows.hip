@@ -403,7 +403,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_rows_pair_kernel(const LstmR
 // its share of the GEMM, barrier), so that 80 rows would fit (16 MT x 4H of bf16 is 245 KB at MT = 5) and the launch would need one
 // dispatch round instead of two.  Tried (80 rows: 4 waves x 2 parts, 8 waves x 3 parts): both spill ~350 registers - the old and the new
 // recurrent gradient and the cell-state carry are all live across the parts - so only HV = 1 with 48 rows is launched.
-// UP: where the upstream gradient of h_t comes from: 0 the dh array, 1 dh x the inter-layer dropout mask, 2 the 2-output head (rank-2 update).
+// UP: where the upstream gradient of h_t comes from: 0 the dh array, 1 dh x the inter-layer dropout mask, 2 the 2-output head (rank-2 update);
+// 3, 4: as 0, 1 with a bf16 dh slab (LstmRec::dhdt).
 // A template parameter, not a run-time flag: with a branch per cell the compiler stops batching the loads of a row tile (9.8 -> 13.3 ms).
 // The body walks frames te-1 .. tb of row block blk.  te < T resumes: the recurrent gradient and the cell-state carry that frame te left (both
 // live in registers across frames) come from `carry` (fp32 [blk][2][RB][H]), where the job of the frames above stored them; tb > 0 stores them.
@@ -419,12 +420,14 @@ __device__ __forceinline__ void lstm_bwd_rows_body(const LstmRec& d, const Arena
   const int64_t row0 = (int64_t)blk * RB;
   const char* gates = rp(ab, d.gates);
   const float* cs = reinterpret_cast<const float*>(rp(ab, d.c));
+  constexpr bool DH16 = UP >= 3, DROP = UP == 1 || UP == 4;
   const float* dh = UP == 2 ? nullptr : reinterpret_cast<const float*>(rp(ab, d.dh));
+  const uint16_t* dh16 = reinterpret_cast<const uint16_t*>(dh);
   uint16_t* dgo = reinterpret_cast<uint16_t*>(rp(ab, d.dgates));
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(rp(ab, d.wpk_b));   // [H][4H] bf16: row = unit u', column = gate column (unit-major)
   const uint16_t* dyo = UP == 2 ? reinterpret_cast<const uint16_t*>(rp(ab, d.dyo)) : nullptr;
   const float* wo = UP == 2 ? reinterpret_cast<const float*>(rp(ab, d.wo)) : nullptr;
-  const uint32_t seed0 = UP == 1 ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = UP == 1 ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
+  const uint32_t seed0 = DROP ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[0] : 0u, seed1 = DROP ? reinterpret_cast<const uint32_t*>(rp(ab, d.seed))[1] : 0u;
   const int kq = lane >> 4, ln = lane & 15;
   const int64_t gx_ld = d.gx_ld;
   // unit of (tile nt, this lane): half nt / NTH, inside the half the wave's NTH consecutive tiles
@@ -472,10 +475,10 @@ __device__ __forceinline__ void lstm_bwd_rows_body(const LstmRec& d, const Arena
             if constexpr (UP == 2) {                      // rank-2 upstream gradient from the 2-output head (bf16 pair per row)
               const uint32_t pr = reinterpret_cast<const uint32_t*>(dyo)[rt];
               dhv[n2][r] = bf2f(pr & 0xffff) * wo[unit] + bf2f(pr >> 16) * wo[H + unit];
-            } else if constexpr (UP == 1) {
-              dhv[n2][r] = dh[rt * H + unit] * drop_scale(seed0, seed1, d.drop_layer, d.keep, rt * H + unit);
             } else {
-              dhv[n2][r] = dh[rt * H + unit];
+              const float up = DH16 ? bf2f(dh16[rt * H + unit]) : dh[rt * H + unit];
+              if constexpr (DROP) dhv[n2][r] = up * drop_scale(seed0, seed1, d.drop_layer, d.keep, rt * H + unit);
+              else dhv[n2][r] = up;
             }
           }
 #pragma unroll
@@ -678,9 +681,10 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
       (void)once;
       hipLaunchKernelGGL((lstm_bwd_rows_kernel<H, MT, NW, G16, HV, UPC>), dim3(grid), dim3(NW * 64), sh, st, d, ab);
     };
+    const bool dh16 = up != 2 && d.dhdt == DT_BF16;
     if (up == 2) go(std::integral_constant<int, 2>{});
-    else if (up == 1) go(std::integral_constant<int, 1>{});
-    else go(std::integral_constant<int, 0>{});
+    else if (up == 1) { if (dh16) go(std::integral_constant<int, 4>{}); else go(std::integral_constant<int, 1>{}); }
+    else { if (dh16) go(std::integral_constant<int, 3>{}); else go(std::integral_constant<int, 0>{}); }
   }
 }
 template <int H, int MT>

@@ -2693,7 +2693,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   { Fsn f = fsn0(); f.in = mag_t; f.out = fb_in; f.sums = mu_fb; f.mode = nmode; f.stat = st_fb; b.push(Fw, OP_FSN_SCALE, 2).fsn = f; }
 
   struct LayerRt { RunGemm gx; Builder::Coef cgx; std::function<void(int, int32_t*)> bgx; Ptr gates, c, h, hd, x; int xfeat, xlen, H; int64_t rows;
-                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false, dropbwd = false, headfuse = false; Ptr dyo, wo; int sdt, xf; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
+                   const ParamInfo* Whh; RunGemm rec; std::string nm; int lid; bool cluster, rowsk, xfuse, dropfused = false, dropbwd = false, headfuse = false; Ptr dyo, wo; int sdt, xf; int dhdt = DT_F32; Ptr hd_fused; Ptr gh, hzero; std::function<void(int, int32_t*)> bhh; };
   std::vector<LayerRt> layers;
   auto lstm_forward = [&](const std::string& netname, int l, int lid, Ptr x, int xfeat, int xlen, int64_t rows, int H, int tag) -> Ptr {
     LayerRt L;
@@ -2929,6 +2929,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
           r.impl = 1; r.wpk_b = pk.w; r.wpk_f = b.none(); r.gxdt = L.sdt;
           r.xin = r.wpk_x = r.bias = r.hd = r.seed = b.none();
           if (L.dropbwd) { r.seed = io_seed; r.keep = keep; r.drop_layer = L.lid; }
+          r.dhdt = L.dhdt;
           r.dyo = r.wo = b.none();
           if (L.headfuse) { r.dyo = L.dyo; r.wo = L.wo; r.no = 2; }
         }
@@ -3032,10 +3033,15 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     Ls1.headfuse = Ls1.rowsk && !(getenv("SEFD_LSTM_HEADFUSE") && atoi(getenv("SEFD_LSTM_HEADFUSE")) == 0);
     if (Ls1.headfuse) { Ls1.dyo = d_sbo; Ls1.wo = b.pptr("sb_model.fc_output_layer.weight"); }
     fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model", Ls1.headfuse);
-    Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, DT_F32);
+    // the gradient slab between the two sub-band layers ([T x rows x H]: 4.8 GB in fp32 at B = 64, written by the input-gradient GEMM and read once by
+    // the row-block backward of the layer below): bf16 like every other activation gradient of the bf16 plans when nothing but that kernel
+    // reads it (the inter-layer dropout fused into it, or no dropout); SEFD_FSN_DH16=0: fp32
+    const bool dh16 = adt == DT_BF16 && Ls1.rowsk && Ls0.rowsk && (Ls0.dropfused || !(keep < 1.f)) && !(getenv("SEFD_FSN_DH16") && atoi(getenv("SEFD_FSN_DH16")) == 0);
+    Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, dh16 ? adt : DT_F32);
     wg_hold = !(getenv("SEFD_FSN_HOLD") && atoi(getenv("SEFD_FSN_HOLD")) == 0);
-    lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, DT_F32, 203);
+    lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, dh16 ? adt : DT_F32, 203);
     wg_hold = 0;
+    if (dh16) Ls0.dhdt = adt;
     Ptr dh2 = dropout_bwd(Ls0, dh2d, 202);
     Ptr d_sbin = b.ws("d_sbin", (int64_t)TP * rs * W, DT_F32);
     lstm_backward(Ls0, dh2, true, d_sbin, W, 0, W, DT_F32, 202);

@@ -264,7 +264,8 @@ struct LstmRec {
   // impl 1, backward, no == 2: the upstream gradient is not read from `dh` but formed from the 2-output head that follows the layer:
   // dh[t][row][u] = dyo[t][row][0] * wo[0][u] + dyo[t][row][1] * wo[1][u]   (dyo dtype gdt [T][rows][2], wo fp32 [2][H] in A_PARAM)
   Ptr dyo, wo;
-  int32_t no, pad4_;
+  int32_t no, dhdt;            // dhdt (impl 1, backward, no != 2): dtype of the `dh` slab - DT_BF16 when the input-gradient GEMM of the layer above writes bf16
+                               // (FullSubNet's sub-band layers: 4.8 GB less written and read per step at B = 64), else fp32
   int32_t gxdt, pad2_;          // impl 1 only: dtype of the gx / gates slabs (DT_BF16 halves the HBM traffic that bounds these layers; the cell
                                // update itself uses the unrounded fp32 gate values, the backward reads the stored ones)
 };

@@ -942,7 +942,7 @@ void run_op(const Op& op, const AB& ab) {
                 const float* wo = (const float*)rp(ab, d.wo);
                 dup = (float)(ld(rp(ab, d.dyo), d.gdt, row * 2) * wo[j] + ld(rp(ab, d.dyo), d.gdt, row * 2 + 1) * wo[H + j]);
               } else {
-                dup = dh[row * H + j];
+                dup = (d.impl == 1 && d.dhdt == DT_BF16) ? (double)ld(rp(ab, d.dh), DT_BF16, row * H + j) : (double)dh[row * H + j];
               }
               if (d.impl == 1 && d.seed.arena >= 0 && d.keep < 1.f) {   // fused inter-layer dropout backward: dh is the gradient of the dropped h
                 const uint32_t* seed = (const uint32_t*)rp(ab, d.seed);
