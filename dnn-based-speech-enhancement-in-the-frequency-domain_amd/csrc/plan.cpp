@@ -3027,10 +3027,10 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     // sub-band head
     Ptr d_sbo = b.ws("d_sbo", (int64_t)TP * rs * 2, adt);
     { Fsn f = fsn0(); f.in = io_gcrm; f.out = d_sbo; b.push(R, OP_FSN_OUT_BWD, 205).fsn = f; }
-    Ptr dh3 = b.ws("dh3", (int64_t)TP * rs * Hs, DT_F32);
     // sub-band head: 2 outputs.  With the row-block kernels the [T x rows x H] fp32 gradient of h (4 GB written by a K = 2 GEMM, read back
     // by the recurrence) is never materialised: the kernel computes dh = d_sbo[.., 0] W_fc[0] + d_sbo[.., 1] W_fc[1] as it needs it
     Ls1.headfuse = Ls1.rowsk && !(getenv("SEFD_LSTM_HEADFUSE") && atoi(getenv("SEFD_LSTM_HEADFUSE")) == 0);
+    Ptr dh3 = Ls1.headfuse ? b.none() : b.ws("dh3", (int64_t)TP * rs * Hs, DT_F32);       // (not even allocated then: 4.6 GB at B = 64)
     if (Ls1.headfuse) { Ls1.dyo = d_sbo; Ls1.wo = b.pptr("sb_model.fc_output_layer.weight"); }
     fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model", Ls1.headfuse);
     // the gradient slab between the two sub-band layers ([T x rows x H]: 4.8 GB in fp32 at B = 64, written by the input-gradient GEMM and read once by
