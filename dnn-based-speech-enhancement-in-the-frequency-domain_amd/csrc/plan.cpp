@@ -253,7 +253,14 @@ struct Builder {
     // second round leaves 2/3 of the CUs idle, and a workgroup that needs the whole kernel's duration on its CU cannot use such a hole
     // SEFD_WG_ROUNDS / SEFD_WGW_ROUNDS (tuning): rounds of every weight-gradient GEMM / of the wide-tile ones when the model did not set its own
     const int env_rounds = (g.flags & kRunWgWide) && getenv("SEFD_WGW_ROUNDS") ? atoi(getenv("SEFD_WGW_ROUNDS")) : getenv("SEFD_WG_ROUNDS") ? atoi(getenv("SEFD_WG_ROUNDS")) : 1;
-    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? 256 : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
+    // Wide-tile launches of SHORT workgroups (at most 10 tiles, fewer than 8192 rows per workgroup at 256 slots) fill 224 CUs, not 256: beside them the
+    // main stream's 160 KB-LDS GEMMs need whole CUs, and 220 instead of 250 workgroups leave every XCD four - DCCRN default 10.60 -> 10.50 ms per step
+    // (slots 160 / 192 / 208 / 216 / 224 / 232 / 240 / 248: 10.59 / 10.55 / 10.53 / 10.50 / 10.50 / 10.61 / 10.61 / 10.59, profiles/r05_tuning_notes.md);
+    // DCCRN-large's launches (20 / 40 tiles, or 5 tiles of 19 000-row workgroups) LOSE 0.3-0.7 ms that way and keep 256.  SEFD_WGW_SLOTS overrides.
+    const int tiles_w = std::max(1, (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk));
+    const bool short_wg = wg_rounds <= 1 && tiles_w <= 10 && (int64_t)g.M * tiles_w < (int64_t)8192 * 256;
+    const int wide_slots = getenv("SEFD_WGW_SLOTS") ? atoi(getenv("SEFD_WGW_SLOTS")) : (short_wg ? 224 : 256);
+    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
