@@ -473,7 +473,9 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int total = ((d.M + 255) / 256) * (d.Npad / 256);
-  const dim3 grid(total < ncu ? total : ncu);
+  static const int gcap = getenv("SEFD_CG256_GRID") ? atoi(getenv("SEFD_CG256_GRID")) : 0;      // tuning: fewer persistent workgroups than CUs
+  const int cap = gcap > 0 && gcap < ncu ? gcap : ncu;
+  const dim3 grid(total < cap ? total : cap);
   const bool bnb = (d.flags & kRunBnBwd) != 0;
 #define SEFD_CG256_LAUNCH(DBG)                                                                                              \
   do {                                                                                                                      \

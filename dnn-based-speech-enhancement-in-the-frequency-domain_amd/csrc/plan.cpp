@@ -260,7 +260,8 @@ struct Builder {
     const int tiles_w = std::max(1, (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk));
     const bool short_wg = wg_rounds <= 1 && tiles_w <= 10 && (int64_t)g.M * tiles_w < (int64_t)8192 * 256;
     const int wide_slots = getenv("SEFD_WGW_SLOTS") ? atoi(getenv("SEFD_WGW_SLOTS")) : (short_wg ? 224 : 256);
-    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : tn == 128 ? 512 : tn == 64 ? 768 : 1024) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
+    const int nscale = getenv("SEFD_WGN_SCALE") ? atoi(getenv("SEFD_WGN_SCALE")) : 100;      // tuning: percent of the slots of the narrow-tile launches
+    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : (tn == 128 ? 512 : tn == 64 ? 768 : 1024) * nscale / 100) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
