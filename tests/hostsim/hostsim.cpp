@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../../dnn-based-speech-enhancement-in-the-frequency-domain_amd/csrc/sefd_desc.h"
 
@@ -51,8 +55,17 @@ void rungemm(const RunGemm& d, const AB& ab) {
   const float* bgamma = bnb ? (const float*)rp(ab, d.bnb_gamma) : nullptr;
   const float* bbeta = bnb ? (const float*)rp(ab, d.bnb_beta) : nullptr;
   const float bslope = bnb ? *(const float*)rp(ab, d.bnb_slope) : 0.f;
+  // dense copy of the weights (w_index_g is an index FUNCTION: one call per MAC was most of this loop)
+  std::vector<double> wd((size_t)d.N * d.ldw);
+  for (int nn = 0; nn < d.N; ++nn)
+    for (int k = 0; k < d.ldw; ++k) wd[(size_t)nn * d.ldw + k] = ld(w, d.xdt, w_index_g(d, nn, k));
+  // 128-row blocks are independent (the statistics are per block, summed in row order inside a block): one block per thread,
+  // same summation order as the serial loop.  (kRunAccum reads y at the element it writes: rows never alias.)
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int blk = 0; blk < nblk; ++blk) {
   std::vector<double> arow(d.ldw);
-  for (int m = 0; m < d.M; ++m) {
+  const int mend = std::min(d.M, (blk + 1) * kBM);
+  for (int m = blk * kBM; m < mend; ++m) {
     const int b = m / TF, rem = m % TF, u = rem / d.Fo, fo = rem % d.Fo;
     std::fill(arow.begin(), arow.end(), 0.0);
     for (int s = 0; s < d.nseg; ++s)
@@ -60,7 +73,8 @@ void rungemm(const RunGemm& d, const AB& ab) {
     const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
     for (int nn = 0; nn < d.N; ++nn) {
       double acc = 0.0;
-      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * ld(w, d.xdt, w_index_g(d, nn, k));
+      const double* wr = &wd[(size_t)nn * d.ldw];
+      for (int k = 0; k < d.ldw; ++k) acc += arow[k] * wr[k];
       float v = (float)acc + (bias ? bias[nn] : 0.f);
       const bool second = d.n2 > 0 && nn >= d.n2;             // two destinations: columns >= n2 go to y2 at column n - n2
       char* y = second ? rp(ab, d.y2) : y1;
@@ -79,6 +93,7 @@ void rungemm(const RunGemm& d, const AB& ab) {
       } else
       if (d.stats.arena >= 0) { s1[(size_t)(m / kBM) * d.Npad + n] += v; s2[(size_t)(m / kBM) * d.Npad + n] += (double)v * v; }
     }
+  }
   }
   if (d.stats.arena >= 0) {
     float* part = (float*)rp(ab, d.stats);
@@ -129,10 +144,20 @@ void wgrad(const RunGemm& d, const AB& ab) {
   const int nsteps = per_item ? nb * spb : (d.M + kWgRows - 1) / kWgRows;
   const int per = (nsteps + d.nsplit - 1) / d.nsplit;
   std::vector<double> acc(sz);
-  std::vector<double> arow(d.ldw);
   for (int sp = 0; sp < d.nsplit; ++sp) {
     std::fill(acc.begin(), acc.end(), 0.0);
     const int st0 = sp * per, st1 = std::min(nsteps, (sp + 1) * per);
+    // every thread owns a range of output columns n and walks ALL rows of the split in order (the operand row is rebuilt per
+    // thread): per accumulator element the same sequence of additions as the serial loop
+#pragma omp parallel
+    {
+    int nth = 1, tid = 0;
+#ifdef _OPENMP
+    nth = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+    const int n0 = (int)((int64_t)d.N * tid / nth), n1 = (int)((int64_t)d.N * (tid + 1) / nth);
+    std::vector<double> arow(d.ldw);
+    if (n1 > n0)
     for (int stp = st0; stp < st1; ++stp)
     for (int r = 0; r < kWgRows; ++r) {
       int m;
@@ -149,12 +174,13 @@ void wgrad(const RunGemm& d, const AB& ab) {
       for (int s = 0; s < d.nseg; ++s)
         for (int j = 0; j < d.seg[s].len; ++j) arow[d.seg[s].koff + j] = a_elem(d, ab, d.seg[s], b, u, fo, j);
       const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
-      for (int n = 0; n < d.N; ++n) {
+      for (int n = n0; n < n1; ++n) {
         const double g = ld(dy, d.ydt, o + n);
         if (g == 0.0) continue;
         double* a = &acc[(size_t)n * d.ldw];
         for (int k = 0; k < d.ldw; ++k) a[k] += g * arow[k];
       }
+    }
     }
     for (int64_t i = 0; i < sz; ++i) part[sp * sz + i] = (float)acc[i];
   }

@@ -20,7 +20,7 @@ def ensure_built():
     desc = os.path.join(sefd_build.CSRC, "sefd_desc.h")
     if (not os.path.exists(SIM_LIB) or os.path.getmtime(SIM_LIB) < max(os.path.getmtime(SIM_SRC), os.path.getmtime(desc))):
         os.makedirs(os.path.dirname(SIM_LIB), exist_ok=True)
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SIM_LIB, SIM_SRC], check=True)
+        subprocess.run(["g++", "-O3", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-o", SIM_LIB, SIM_SRC], check=True)
 
 
 _sim = None
