@@ -1,0 +1,486 @@
+// RUNGEMM, wide tile, phase-staggered loop (round 6).  Same descriptor, same weight layout (kRunWTile32), same accumulation order and the
+// same epilogue contract as cgemm256.hip - outputs are bit-identical to it - with the K loop rebuilt after the "256 x 256 8-phase" schedule of the
+// CDNA4 GEMM playbook:
+//   * 256 x 256 output tile per 512-thread workgroup, 8 waves as 2 (M) x 4 (N), 128 x 64 accumulators each; waves w and w + 4 share a SIMD;
+//   * a 64-deep K tile is FOUR half-tiles of 16 KB: Ah0 / Ah1 = the rows of the two 64-row halves of every wave's A block (m0 / m1), Bh0 / Bh1 =
+//     the columns of the two 32-column halves of every wave's B block (n0 / n1).  A wave multiplies one C quadrant (64 x 32 x K 64 = 8 MFMA
+//     32x32x16) per PHASE: P1 (m0, n0) reads Ah0 + Bh0, P2 (m0, n1) reads Bh1, P3 (m1, n1) reads Ah1, P4 (m1, n0) reads nothing - 24 fragment
+//     reads per K tile, every LDS byte read once per wave;
+//   * a phase is { fragment reads + ONE half-tile of LDS-DMA (2 instructions per thread) | s_barrier | 8 MFMA under s_setprio 1 | s_barrier }, and the
+//     two wave groups (M halves) run ONE barrier apart: while the waves 0-3 multiply, the waves 4-7 read / issue, and vice versa - every SIMD
+//     always has one wave in its MFMA cluster;
+//   * the LDS ring is two K tiles (128 KB).  Half-tiles are restaged as they die: Ah0(g + 2) in P3 of K tile g, Bh0(g + 2) in P4, Bh1(g + 2) in P1 of
+//     g + 1, Ah1(g + 2) in P2 of g + 1 - always two or more phases after the last read of what they overwrite - and ONE counted wait per K tile
+//     (`s_waitcnt vmcnt(4)` in P4: everything but the two newest half-tiles has landed = all of K tile g + 1) orders the data for the reads of the
+//     next K tile, two barriers later.  The DMA queue is never drained inside the kernel;
+//   * the stage stream is continuous over the output tiles a workgroup walks (persistent): the next tile's first K tiles land during the epilogue.
+//     kRunBnBwd: the epilogue stages its 32-row blocks through a wave-private 4 KB scratch BEHIND the ring (no workgroup barrier, the stream goes on).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "sefd_desc.h"
+#include "dev_common.h"
+
+namespace sefd {
+
+namespace {
+
+__device__ __forceinline__ int fdiv8(int x, uint32_t m, uint32_t s) { return m ? (int)(__umulhi((uint32_t)x, m) >> s) : x; }
+
+__device__ __forceinline__ int xcd_remap8(int bid, int nwg) {
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + local;
+}
+
+__device__ __forceinline__ void bar8() { asm volatile("s_barrier" ::: "memory"); }
+
+}  // namespace
+
+// VAR (tuning builds only, -DSEFD_TUNING: the GEMM ladder of tools/probes/gemm_ladder.hip): 1 no stagger (all eight waves in the same phase),
+// 2 no s_setprio, 4 plain operand (one run, every chunk valid: no zero-page select), 8 bare epilogue (no bias / statistics), 16 no MFMAs,
+// 32 no DMAs after the prologue, 64 no fragment reads.  The product build instantiates VAR = 0 only.
+template <bool BNB, int VAR>
+__global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const ArenaBases ab) {
+  constexpr int BM = 256, BN = 256, KT = 64;
+  constexpr int HALF = 16384;                               // one half-tile
+  constexpr int KBUF = 4 * HALF;                            // one K tile: Ah0 | Ah1 | Bh0 | Bh1
+  constexpr int RING = 2 * KBUF;
+  constexpr int SMEM = RING + (BNB ? 8 * 4096 : 0);
+  constexpr int MI = 4, NI = 2;
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int nn = d.Npad / BN;
+  const int nm = (d.M + BM - 1) / BM;
+  const int total = nm * nn;
+  const int TF = d.Tout * d.Fo;
+  int nkt = 0;
+  for (int s = 0; s < d.nseg; ++s) nkt += (d.seg[s].len + KT - 1) / KT;
+
+  const uint16_t* x0 = reinterpret_cast<const uint16_t*>(rp(ab, d.x[0]));
+  const uint16_t* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const uint16_t*>(rp(ab, d.x[1])) : x0;
+  const uint16_t* w = reinterpret_cast<const uint16_t*>(rp(ab, d.w));
+  const uint16_t* zp = reinterpret_cast<const uint16_t*>(rp(ab, d.zero));
+  // ---- DMA roles.  A half-tile h: instruction q (0, 1) of wave `wid` fills the half-tile rows (q * 8 + wid) * 8 .. + 8 = tile rows
+  // q * 128 + h * 64 + wid * 8 + la (q = the wave group that reads them); lane -> (row la, 16-byte position pa); the XOR swizzle of the
+  // fragment reads is applied to the SOURCE chunk (the LDS image of an LDS-DMA is lane-linear).
+  const int la = lane >> 3, pa = lane & 7;
+  const int csa = pa ^ ((((wid & 1) * 4) + (la >> 1)) & 7);
+  // B half-tile h: two 32-deep sub-tiles (64-byte rows) of the 128 columns wc * 64 + h * 32 + c; instruction j = sub-tile j, wave `wid` fills its
+  // rows 16 * wid .. + 16 (wc = wid >> 1, c = (wid & 1) * 16 + lb); lane -> (row lb, position pb)
+  const int lb = lane >> 2, pb = lane & 3;
+  const int csb = pb ^ ((lb >> 2) & 3);
+  const int64_t wtile = (int64_t)d.Npad * 32;               // elements per 32-deep weight tile (K-tile major layout)
+  const int Tin0 = d.Tin[0], Tin1 = d.Tin[1], fs0 = d.fstride[0], fs1 = d.fstride[1], rl0 = d.rowlen[0], rl1 = d.rowlen[1];
+  const int64_t ts0 = d.tstride[0], ts1 = d.tstride[1];
+  const uint32_t lds0 = lds_addr(smem);
+  // ---- fragment roles: the wave's accumulator block is (4 x 32) x (2 x 32) at (wm0, wn0) of the output tile
+  const int wm0 = wr * 128, wn0 = wc * 64;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int ca0 = (fhalf ^ ((frow >> 1) & 7)) * 16, cb0 = (fhalf ^ ((frow >> 2) & 3)) * 16;
+  const int aoff = (wr * 64 + frow) * 128 + ca0;            // + h * HALF + i * 4096, chunk ^ (32 * s)
+  const int boff = 2 * HALF + (wc * 32 + frow) * 64 + cb0;  // + h * HALF + (s >> 1) * 8192, chunk ^ (32 * (s & 1))
+  const float* biasp = d.bias.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
+  char* yb = rp(ab, d.y);
+  const bool want_stats = d.stats.arena >= 0;
+  const bool staged = (d.flags & kRunYAligned) && !(d.flags & kRunAccum);
+  const bool ylin = d.y_tstride == d.Fo * d.y_fstride && d.y_bstride == (int64_t)d.Tout * d.y_tstride;
+  const uint16_t* ybn = BNB ? reinterpret_cast<const uint16_t*>(rp(ab, d.bnb_y)) : nullptr;
+  const float bslope = BNB ? *reinterpret_cast<const float*>(rp(ab, d.bnb_slope)) : 0.f;
+
+  // ---- stage stream: A cursor (K tile whose Ah0 / Ah1 are issued next) and B cursor, each walking the workgroup's output tiles
+  int a_t = blockIdx.x, b_t = blockIdx.x;                   // output tile index (persistent walk) of the cursors; >= total: stream exhausted
+  int a_g = 0, b_g = 0;                                     // ring parity of the cursors' K tiles
+  int a_kl = 0, b_kl = 0;                                   // K tile index inside the output tile
+  int aseg = 0, ak0 = 0, aseglen = 0;
+  int bseg = 0, bk0 = 0, bseglen = 0, bkoff = 0;
+  int a_mtile = 0;
+  const uint16_t* rptr[4];                                  // this thread's 4 operand rows (q * 2 + h) of the current run
+  uint32_t lohi[4];                                         // valid element range [lo, hi) of the run for that row, lo | hi << 16
+  const uint16_t* wb0 = w;
+  auto enter_run = [&]() {
+    const Seg sg = d.seg[aseg];
+    aseglen = sg.len;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int m = a_mtile * BM + (r4 >> 1) * 128 + (r4 & 1) * 64 + wid * 8 + la;
+      int lo = 0, hi = 0;
+      const uint16_t* ptr = x0;
+      if (VAR & 4) {
+        ptr = x0 + d.base[0] + (int64_t)min(m, d.M - 1) * fs0;
+        hi = sg.len;
+      } else if (sg.src >= 0 && m < d.M) {
+        const int b = fdiv8(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF;
+        const int u = fdiv8(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+        const int s = sg.src;
+        const int tt = u + sg.dt;
+        if (tt >= 0 && tt < (s ? Tin1 : Tin0)) {
+          const int rr = sg.off + fo * (s ? fs1 : fs0);
+          lo = rr < 0 ? -rr : 0;
+          hi = max(min(sg.len, (s ? rl1 : rl0) - rr), 0);
+          ptr = (s ? x1 : x0) + (int64_t)b * d.bstride[s] + d.base[s] + (int64_t)tt * (s ? ts1 : ts0) + rr;
+        }
+      }
+      rptr[r4] = ptr;
+      lohi[r4] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+  };
+  auto a_begin_tile = [&]() {
+    if (a_t < total) {
+      a_mtile = xcd_remap8(a_t, total) / nn;
+      aseg = 0; ak0 = 0; a_kl = 0;
+      enter_run();
+    }
+  };
+  auto b_begin_tile = [&]() {
+    if (b_t < total) {
+      const int ntile = xcd_remap8(b_t, total) % nn;
+      wb0 = w + ((int64_t)ntile * BN + (wid >> 1) * 64 + (wid & 1) * 16 + lb) * 32 + csb * 8;
+      bseg = 0; bk0 = 0; b_kl = 0; bseglen = d.seg[0].len; bkoff = d.seg[0].koff;
+    }
+  };
+  // half h of the A cursor's K tile; h == 1 is the second one issued: the cursor moves on behind it
+  auto stage_a = [&](int h, bool live) {
+    if (live) {
+      const uint32_t dst = lds0 + (a_g & 1) * KBUF + h * HALF + wid * 1024;
+      const int j0 = ak0 + csa * 8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t lh = lohi[q * 2 + h];
+        const bool ok = (VAR & 4) ? true : (a_t < total && j0 >= (int)(lh & 0xffffu) && j0 + 8 <= (int)(lh >> 16));
+        const uint16_t* src = ok ? rptr[q * 2 + h] + j0 : zp;
+        dma16(src, dst + q * 8192);
+      }
+    }
+    if (h == 1) {
+      ++a_g;
+      if (a_t < total) {
+        ak0 += KT;
+        if (++a_kl == nkt) { a_t += gridDim.x; a_begin_tile(); }
+        else if (ak0 >= aseglen) { ak0 = 0; ++aseg; enter_run(); }
+      }
+    }
+  };
+  // half h of the B cursor's K tile (both 32-deep sub-tiles); h == 1 is the second one issued
+  auto stage_b = [&](int h, bool live) {
+    if (live) {
+      const uint32_t dst = lds0 + (b_g & 1) * KBUF + (2 + h) * HALF + wid * 1024;
+      const uint16_t* src = b_t < total ? wb0 + h * (32 * 32) + (int64_t)((bkoff + bk0) >> 5) * wtile : zp;
+      const int64_t step = b_t < total ? wtile : 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(src + j * step, dst + j * 8192);
+    }
+    if (h == 1) {
+      ++b_g;
+      if (b_t < total) {
+        bk0 += KT;
+        if (++b_kl == nkt) { b_t += gridDim.x; b_begin_tile(); }
+        else if (bk0 >= bseglen) { bk0 = 0; ++bseg; bseglen = d.seg[bseg].len; bkoff = d.seg[bseg].koff; }
+      }
+    }
+  };
+
+  // ---- prologue: all of the first K tile, and the first two half-tiles of the second
+  a_begin_tile();
+  b_begin_tile();
+  stage_a(0, true); stage_b(0, true); stage_b(1, true); stage_a(1, true);
+  stage_a(0, true); stage_b(0, true);
+  wait_vm<4>();
+  bar8();
+  if (!(VAR & 1) && wr == 1) bar8();                        // the second wave group runs one barrier behind the first
+
+  constexpr bool kDma = !(VAR & 32);
+  int gk = 0;                                               // K tiles finished by this workgroup (ring parity)
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int tile = xcd_remap8(t, total);
+    const int ntile = tile % nn, mtile = tile / nn;
+    float bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = ntile * BN + wn0 + j * 32 + (lane & 31);
+      bv[j] = (biasp && n < d.N && !(VAR & 8)) ? biasp[n] : 0.f;
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (VAR & 16) {                                          // no-MFMA arm: the accumulators stay opaque, nothing downstream folds away
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
+    uint4 af[2][4], b0[4], b1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { af[0][s] = af[1][s] = b0[s] = b1[s] = make_uint4(0, 0, 0, 0); }
+
+#define SEFD8P_RDA(H)                                                                                                          \
+  if (!(VAR & 64)) {                                                                                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                            \
+        af[i][s] = *reinterpret_cast<const uint4*>(kb + (H) * HALF + i * 4096 + (aoff ^ (32 * s)));                            \
+    }                                                                                                                          \
+  }
+#define SEFD8P_RDB(H, BR)                                                                                                      \
+  if (!(VAR & 64)) {                                                                                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                              \
+      BR[s] = *reinterpret_cast<const uint4*>(kb + (H) * HALF + (s >> 1) * 8192 + (boff ^ (32 * (s & 1))));                    \
+  }
+#define SEFD8P_MMA(I0, NH, BR)                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                                           \
+  bar8();                                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                                           \
+  if (!(VAR & 16)) {                                                                                                           \
+    if (!(VAR & 2)) __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                            \
+        acc[(I0) + i][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][s]),                      \
+                                                                   __builtin_bit_cast(bf16x8, BR[s]), acc[(I0) + i][NH], 0, 0, 0); \
+    }                                                                                                                          \
+    if (!(VAR & 2)) __builtin_amdgcn_s_setprio(0);                                                                             \
+  }                                                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                                           \
+  bar8();                                                                                                                      \
+  __builtin_amdgcn_sched_barrier(0);
+
+    for (int p = 0; p < nkt; ++p) {
+      const char* kb = smem + (gk & 1) * KBUF;
+      // P1: quadrant (m0, n0)
+      SEFD8P_RDB(0, b0)
+      SEFD8P_RDA(0)
+      stage_b(1, kDma);
+      SEFD8P_MMA(0, 0, b0)
+      // P2: quadrant (m0, n1)
+      SEFD8P_RDB(1, b1)
+      stage_a(1, kDma);
+      SEFD8P_MMA(0, 1, b1)
+      // P3: quadrant (m1, n1)
+      SEFD8P_RDA(1)
+      stage_a(0, kDma);
+      SEFD8P_MMA(2, 1, b1)
+      // P4: quadrant (m1, n0); everything but the two newest half-tiles has landed = all of the next K tile
+      stage_b(0, kDma);
+      if (kDma) wait_vm<4>(); else wait_vm<0>();
+      SEFD8P_MMA(2, 0, b0)
+      ++gk;
+    }
+#undef SEFD8P_RDA
+#undef SEFD8P_RDB
+#undef SEFD8P_MMA
+
+    if constexpr (BNB) {
+      // ---- kRunBnBwd epilogue.  Per 32-row block i: the block goes to the wave's 4 KB scratch as bf16 (quad transpose, 8-byte pieces, rows of 128 bytes,
+      // 16-byte chunks XOR-swizzled by the row), then lane (chunk ch = lane & 7, rows lane >> 3 + 8 k) moves 16-byte row chunks scratch -> global and,
+      // beside each, reads the same chunk of the BatchNorm layer's forward output and accumulates the three backward sums of its 8 columns.
+      char* wt = smem + RING + wid * 4096;
+      const QuadT qt(lane);
+      const int ch = lane & 7, n0 = ntile * BN + wn0 + ch * 8;
+      const bool cok = n0 < d.N;
+      float pm[8], pis[8], pg[8], pb2[8], t0[8], t1[8], t2[8];
+      {
+        const float* mi = reinterpret_cast<const float*>(rp(ab, d.bnb_mi));
+        const float* ga = reinterpret_cast<const float*>(rp(ab, d.bnb_gamma));
+        const float* be = reinterpret_cast<const float*>(rp(ab, d.bnb_beta));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = cok ? n0 + e : 0;
+          pm[e] = mi[n]; pis[e] = mi[d.N + n]; pg[e] = ga[n]; pb2[e] = be[n];
+          t0[e] = t1[e] = t2[e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        uint4 ypre[4];
+        int64_t oo[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int m = mtile * BM + wm0 + i * 32 + (lane >> 3) + 8 * kk;
+          oo[kk] = -1;
+          ypre[kk] = make_uint4(0, 0, 0, 0);
+          if (m < d.M && cok) {
+            const int b = fdiv8(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv8(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+            oo[kk] = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+            ypre[kk] = *reinterpret_cast<const uint4*>(ybn + (int64_t)b * d.bnb_bstride + (int64_t)u * d.bnb_tstride + (int64_t)fo * d.bnb_fstride + d.bnb_off + n0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = j * 32 + (lane & 28);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 8 * q + 4 * (lane >> 5) + (lane & 3);
+            const uint2 pk = qt.pack(acc[i][j][4 * q] + bv[j], acc[i][j][4 * q + 1] + bv[j], acc[i][j][4 * q + 2] + bv[j], acc[i][j][4 * q + 3] + bv[j]);
+            *reinterpret_cast<uint2*>(wt + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = pk;
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int row = (lane >> 3) + 8 * kk;
+          const int64_t o = oo[kk];
+          const uint4 dzv = *reinterpret_cast<const uint4*>(wt + row * 128 + ((ch ^ (row & 7)) << 4));
+          if (o < 0) continue;
+          const uint4 yv = ypre[kk];
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = dzv;
+          const uint32_t dw[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dz = bf2f((uint16_t)(dw[e >> 1] >> (16 * (e & 1)))), yy = bf2f((uint16_t)(yw[e >> 1] >> (16 * (e & 1))));
+            const float xh = (yy - pm[e]) * pis[e];
+            const float bn = pg[e] * xh + pb2[e];
+            const float dbn = bn > 0.f ? dz : bslope * dz;
+            t0[e] += dbn;
+            t1[e] += dbn * xh;
+            t2[e] += bn > 0.f ? 0.f : bn * dz;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 32; o >= 8; o >>= 1) { t0[e] += __shfl_xor(t0[e], o); t1[e] += __shfl_xor(t1[e], o); t2[e] += __shfl_xor(t2[e], o); }
+      }
+      const int srow = mtile * 2 + wr;
+      if (lane < 8 && srow < (d.M + kBM - 1) / kBM) {              // this wave's 128 rows are one 128-row block of partial sums
+        float* part = reinterpret_cast<float*>(rp(ab, d.stats));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          part[((int64_t)srow * 3 + 0) * d.Npad + n0 + e] = t0[e];
+          part[((int64_t)srow * 3 + 1) * d.Npad + n0 + e] = t1[e];
+          part[((int64_t)srow * 3 + 2) * d.Npad + n0 + e] = t2[e];
+        }
+      }
+      continue;
+    }
+    // ---- epilogue, wave local, no LDS (as cgemm256.hip): bias / ReLU / statistics on the accumulators as they sit (one column per lane), quad transpose
+    // (dev_common.h QuadT), lane pairs widened to 16-byte row pieces (OctW)
+    const QuadT qt(lane);
+    const OctW ow(lane);
+    float s1[NI], s2[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row0 = mtile * BM + wm0 + i * 32;
+      if (staged) {
+        const bool full = row0 + 32 <= d.M;
+        int64_t ro[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = row0 + 8 * q + 4 * (lane >> 5) + (lane & 3);
+          ro[q] = -1;
+          if (m < d.M) {
+            if (ylin) ro[q] = (int64_t)m * d.y_fstride + d.y_off;
+            else {
+              const int b = fdiv8(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv8(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+              ro[q] = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = j * 32 + (lane & 31);
+          const bool nok = ntile * BN + wn0 + col < d.N;
+          const int n0 = ntile * BN + wn0 + j * 32 + (lane & 28);
+          float v[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            v[e] = acc[i][j][e] + bv[j];
+            if (d.flags & kRunRelu) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (want_stats && nok && !(VAR & 8)) {
+            if (full) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) { s1[j] += v[e]; s2[j] += v[e] * v[e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row0 + row < d.M) { s1[j] += v[e]; s2[j] += v[e] * v[e]; }
+              }
+            }
+          }
+          uint2 pk[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pk[q] = qt.pack(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          uint4 wide[2];
+          ow.widen(pk, wide);
+          const int n8 = n0 & ~7;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int64_t r = ow.hi4 ? ro[2 * h + 1] : ro[2 * h];
+            if (r >= 0 && n8 < d.N) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + r + n8) = wide[h];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = row0 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          if (m >= d.M) continue;
+          const int b = fdiv8(m, d.div_tf_m, d.div_tf_s), rem = m - b * TF, u = fdiv8(rem, d.div_fo_m, d.div_fo_s), fo = rem - u * d.Fo;
+          const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int n = ntile * BN + wn0 + j * 32 + (lane & 31);
+            if (n >= d.N) continue;
+            float v = acc[i][j][e] + bv[j];
+            if (d.flags & kRunAccum) v += reinterpret_cast<float*>(yb)[o + n];
+            if (d.flags & kRunRelu) v = fmaxf(v, 0.f);
+            if (d.ydt == DT_BF16) reinterpret_cast<uint16_t*>(yb)[o + n] = f2bf(v);
+            else reinterpret_cast<float*>(yb)[o + n] = v;
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+        }
+      }
+    }
+    if (want_stats && !(VAR & 8)) {                          // this wave's 128 rows are ONE 128-row statistics block of its 64 columns
+      float* part = reinterpret_cast<float*>(rp(ab, d.stats));
+      const int srow = mtile * 2 + wr;
+      const int nrows = (d.M + kBM - 1) / kBM;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float t1 = s1[j] + __shfl_xor(s1[j], 32), t2 = s2[j] + __shfl_xor(s2[j], 32);
+        const int n = ntile * BN + wn0 + j * 32 + (lane & 31);
+        if (lane < 32 && srow < nrows) {
+          part[((int64_t)srow * 2 + 0) * d.Npad + n] = t1;
+          part[((int64_t)srow * 2 + 1) * d.Npad + n] = t2;
+        }
+      }
+    }
+  }
+  if (!(VAR & 1) && wr == 0) bar8();                        // pairs with the second group's last barrier
+  wait_vm<0>();                                             // nothing may still be on its way into this workgroup's LDS when it ends
+}
+
+#ifdef SEFD_TUNING
+int g_cgemm8p_var = 0;
+#endif
+
+// The planner marks the GEMMs of this kernel (and packs their weights K-tile major) with kRunWTile32.
+bool launch_cgemm8p(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (!(d.flags & kRunWTile32)) return false;
+  static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const int total = ((d.M + 255) / 256) * (d.Npad / 256);
+  const dim3 grid(total < ncu ? total : ncu);
+  const bool bnb = (d.flags & kRunBnBwd) != 0;
+#ifdef SEFD_TUNING
+#define SEFD8P_CASE(V) case V: hipLaunchKernelGGL((cgemm8p_kernel<false, V>), grid, dim3(512), 0, st, d, ab); return true;
+  if (!bnb) switch (g_cgemm8p_var) {
+    SEFD8P_CASE(1) SEFD8P_CASE(2) SEFD8P_CASE(3) SEFD8P_CASE(4) SEFD8P_CASE(8) SEFD8P_CASE(16) SEFD8P_CASE(32) SEFD8P_CASE(64)
+    default: break;
+  }
+#undef SEFD8P_CASE
+#endif
+  if (bnb) hipLaunchKernelGGL((cgemm8p_kernel<true, 0>), grid, dim3(512), 0, st, d, ab);
+  else hipLaunchKernelGGL((cgemm8p_kernel<false, 0>), grid, dim3(512), 0, st, d, ab);
+  return true;
+}
+
+}  // namespace sefd

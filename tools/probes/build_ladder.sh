@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build tools/probes/gemm_ladder (cross-compiles here; runs on the MI355X box): the harness + the two wide-tile kernels, tuning arms compiled in.
+set -e
+cd "$(dirname "$0")/../.."
+CS=dnn-based-speech-enhancement-in-the-frequency-domain_amd/csrc
+O=tools/probes/_obj; mkdir -p $O
+F="--offload-arch=gfx950 -O3 -std=c++17 -DSEFD_TUNING -I$CS"
+/opt/rocm/bin/hipcc $F -c -o $O/cgemm256.o $CS/cgemm256.hip &
+/opt/rocm/bin/hipcc $F -c -o $O/cgemm8p.o $CS/cgemm8p.hip &
+/opt/rocm/bin/hipcc $F -c -o $O/ladder.o tools/probes/gemm_ladder.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -o tools/probes/gemm_ladder $O/ladder.o $O/cgemm256.o $O/cgemm8p.o
+ls -la tools/probes/gemm_ladder
