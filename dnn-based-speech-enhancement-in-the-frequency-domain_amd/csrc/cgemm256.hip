@@ -44,8 +44,8 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 
 }  // namespace
 
-// dbg (tuning runs only, SEFD_CG256_DBG): 1 skip the MFMAs, 2 skip the DMAs, 4 skip the fragment reads, 8 skip the epilogue,
-// 32 every A chunk from the zero page (no activation traffic)
+// dbg (tuning BUILDS only, -DSEFD_TUNING + SEFD_CG256_DBG; the product library instantiates dbg = 0 only): 1 skip the MFMAs, 2 skip the DMAs, 4 skip the fragment reads, 8 skip the epilogue,
+// 32 every A chunk from the zero page (no activation traffic), 128 / 256 the step's DMAs at a wave-dependent position between the MFMAs (2 / 4 positions)
 // BNB: the kRunBnBwd epilogue as its own instantiation - the kernel sits at the 256-register cap of two waves per SIMD, and with the
 // extra epilogue state in the one body the allocator spilled inside the K loop of EVERY launch (15x slower)
 // (dbg is a template argument; only the switch values the tuning runs use are instantiated)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
             for (int j = 0; j < NI; ++j)
               acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ii]), __builtin_bit_cast(bf16x8, bf[j]),
                                                                    acc[ii][j], 0, 0, 0);
-            if (ii == 1) {                                 // this step's two DMAs behind the first four MFMAs: the wave is held at their issue while its
+            if (ii == ((dbg & 128) ? ((wid & 1) ? 0 : 2) : ((dbg & 256) ? (wid & 3) : 1))) {   // this step's two DMAs behind the first four MFMAs: the wave is held at their issue while its
               __builtin_amdgcn_sched_barrier(0);           // own MFMAs drain (in front of / behind all eight: +0.04 ms per step, same box)
               if (s == 0) { if (has1) issue_b(p + 1, 0, kt32[1]); }
               else if (s == 1) { if (has1) issue_b(p + 1, 1, kt32[1]); }
@@ -467,30 +467,38 @@ __global__ __launch_bounds__(512) void cgemm256_kernel(const RunGemm d, const Ar
   }
 }
 
+#ifdef SEFD_TUNING
+int g_cgemm256_dbg = -1;       // tuning builds (-DSEFD_TUNING: tools/probes, A/B libraries) only: kernel variant; -1 = read SEFD_CG256_DBG once
+#endif
+
 // The planner decides which GEMMs take this kernel: it marks them (and packs their weights) with kRunWTile32.
 bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (!(d.flags & kRunWTile32)) return false;
-  static const int dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   const int total = ((d.M + 255) / 256) * (d.Npad / 256);
-  static const int gcap = getenv("SEFD_CG256_GRID") ? atoi(getenv("SEFD_CG256_GRID")) : 0;      // tuning: fewer persistent workgroups than CUs
-  const int cap = gcap > 0 && gcap < ncu ? gcap : ncu;
-  const dim3 grid(total < cap ? total : cap);
+  const dim3 grid(total < ncu ? total : ncu);
   const bool bnb = (d.flags & kRunBnBwd) != 0;
 #define SEFD_CG256_LAUNCH(DBG)                                                                                              \
   do {                                                                                                                      \
     if (bnb) hipLaunchKernelGGL((cgemm256_kernel<true, DBG>), grid, dim3(512), 0, st, d, ab);                               \
     else hipLaunchKernelGGL((cgemm256_kernel<false, DBG>), grid, dim3(512), 0, st, d, ab);                                  \
   } while (0)
-  switch (dbg) {
-    case 1: SEFD_CG256_LAUNCH(1); break;
-    case 2: SEFD_CG256_LAUNCH(2); break;
-    case 4: SEFD_CG256_LAUNCH(4); break;
-    case 8: SEFD_CG256_LAUNCH(8); break;
-    case 32: SEFD_CG256_LAUNCH(32); break;
-    case 64: SEFD_CG256_LAUNCH(64); break;
-    default: SEFD_CG256_LAUNCH(0); break;
+#ifdef SEFD_TUNING
+  // wrong-result / experimental arms exist in tuning builds only: the product library has no switch that changes what a launch computes
+  if (g_cgemm256_dbg < 0) g_cgemm256_dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
+  switch (g_cgemm256_dbg) {
+    case 1: SEFD_CG256_LAUNCH(1); return true;
+    case 2: SEFD_CG256_LAUNCH(2); return true;
+    case 4: SEFD_CG256_LAUNCH(4); return true;
+    case 8: SEFD_CG256_LAUNCH(8); return true;
+    case 32: SEFD_CG256_LAUNCH(32); return true;
+    case 64: SEFD_CG256_LAUNCH(64); return true;
+    case 128: SEFD_CG256_LAUNCH(128); return true;
+    case 256: SEFD_CG256_LAUNCH(256); return true;
+    default: break;
   }
+#endif
+  SEFD_CG256_LAUNCH(0);
 #undef SEFD_CG256_LAUNCH
   return true;
 }

@@ -23,7 +23,8 @@ def main():
         base = p.ops_ptr(ph)
         for i in range(p.num_ops(ph)):
             o = p.op_info(ph, i)
-            if o["kind"] == 1 and (o["flags"] & 16):
+            # the wide-tile GEMMs (kRunWTile32) and, for the 256 x 128 rung (tools/probes/ladder/cgemm128.hip), the LDS-DMA-able bf16 GEMMs of width 128
+            if o["kind"] == 1 and ((o["flags"] & 16) or (o["dtype"] == 1 and (o["flags"] & 1) and o["N"] == 128 and o["M"] >= 65536)):
                 raw = C.string_at(base + i * sz, sz)
                 recs.append((ph, i, raw, o))
     with open(out, "wb") as f:

@@ -14,7 +14,11 @@
 #include "sefd_desc.h"
 #include "dev_common.h"
 
-namespace sefd { extern int g_cgemm8p_var; }
+namespace sefd {
+extern int g_cgemm8p_var, g_cgemm256_dbg;
+bool launch_cgemm8p(const RunGemm& d, const ArenaBases& ab, hipStream_t st);      // tools/probes/ladder/cgemm8p.hip
+bool launch_cgemm128(const RunGemm& d, const ArenaBases& ab, hipStream_t st);     // tools/probes/ladder/cgemm128.hip
+}
 using namespace sefd;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -50,6 +54,15 @@ __global__ void checksum(const uint64_t* p, size_t n, unsigned long long* out) {
 
 struct Rec { int phase, index; Op op; std::string name; };
 
+// plain[n][ldw] <- K-tile-major tiled[(k >> 5) * Npad + n][32] (the layout kRunWTile32 names): the 128-row kernel reads the plain copy
+__global__ void untile_w(const uint16_t* tiled, uint16_t* plain, int Npad, int ldw) {
+  const size_t n = (size_t)Npad * ldw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int nn = (int)(i / ldw), k = (int)(i % ldw);
+    plain[i] = tiled[((size_t)(k >> 5) * Npad + nn) * 32 + (k & 31)];
+  }
+}
+
 static ArenaBases g_ab;
 static int64_t g_bytes[A_COUNT];
 static unsigned long long* g_sum;
@@ -65,9 +78,28 @@ static unsigned long long ws_sum() {
   return h;
 }
 
-// arm: -1 = cgemm256 (old kernel); >= 0 = cgemm8p with that VAR
+static int64_t g_spare;          // byte offset of the spare region behind the workspace proper (plain weight copies)
+// arm: -1 = the old kernel (cgemm256; for widths that are an odd multiple of 128: the 128 x 128 kernel of rungemm.hip on a plain copy of the weights);
+// >= 0 = cgemm8p with that VAR (odd multiples of 128: cgemm128, arm 0 only)
 static void launch(const RunGemm& g, int arm) {
-  if (arm < 0) { if (!launch_cgemm256(g, g_ab, 0)) { fprintf(stderr, "cgemm256 refused\n"); exit(1); } }
+  const bool w128 = g.Npad % 256 != 0;
+  if (arm < 0) {
+    if (w128) {
+      RunGemm o = g;
+      o.flags &= ~kRunWTile32;
+      o.w = Ptr{A_WS, 0, g_spare};
+      static int64_t last = -1;                              // (refill() regenerates the same weights: one plain copy per weight buffer)
+      if (last != g.w.off) {
+        hipLaunchKernelGGL(untile_w, dim3(1024), dim3(256), 0, 0, (const uint16_t*)rp(g_ab, g.w), (uint16_t*)(g_ab.p[A_WS] + g_spare), g.Npad, g.ldw);
+        last = g.w.off;
+      }
+      launch_rungemm(o, g_ab, 0);
+    } else { g_cgemm256_dbg = arm == -1 ? 0 : -arm; if (!launch_cgemm256(g, g_ab, 0)) { fprintf(stderr, "cgemm256 refused\n"); exit(1); } }
+  } else if (w128) {
+    RunGemm n = g;
+    n.flags |= kRunWTile32;                                  // the weight bytes are random: read as K-tile major here, the old arm reads their un-tiled copy
+    if (!launch_cgemm128(n, g_ab, 0)) { fprintf(stderr, "cgemm128 refused\n"); exit(1); }
+  }
   else { g_cgemm8p_var = arm; if (!launch_cgemm8p(g, g_ab, 0)) { fprintf(stderr, "cgemm8p refused\n"); exit(1); } }
 }
 
@@ -109,9 +141,11 @@ int main(int argc, char** argv) {
   }
   fclose(f);
   g_bytes[A_WS] = std::max<int64_t>(g_bytes[A_WS], (int64_t)7 << 30);
+  g_spare = (g_bytes[A_WS] + 4095) / 4096 * 4096;
   for (int a = 0; a < A_COUNT; ++a) {
-    CK(hipMalloc((void**)&g_ab.p[a], (size_t)g_bytes[a] + 4096));
-    CK(hipMemset(g_ab.p[a], 0, (size_t)g_bytes[a] + 4096));
+    const size_t extra = a == A_WS ? (size_t)(g_spare - g_bytes[a]) + (64u << 20) : 4096;
+    CK(hipMalloc((void**)&g_ab.p[a], (size_t)g_bytes[a] + extra));
+    CK(hipMemset(g_ab.p[a], 0, (size_t)g_bytes[a] + extra));
   }
   g_ab.status = nullptr; g_ab.dstatus = nullptr;
   CK(hipMalloc((void**)&g_sum, 8));
@@ -148,7 +182,9 @@ int main(int argc, char** argv) {
     const bool ok = s_old == s_new && s_old != s_none;
     if (!ok) ++bad;
     std::vector<int> arms = {-1, 0};
-    if (!bnb) { arms.push_back(1); arms.push_back(2); arms.push_back(3); arms.push_back(8); arms.push_back(16); arms.push_back(32); arms.push_back(64); if (c.plain) arms.push_back(4); }
+    if (g.Npad % 256 == 0) { arms.push_back(-128); arms.push_back(-256); }      // old kernel with its DMA issue at 2 / 4 wave-dependent positions
+    if (g.Npad % 256 != 0) { /* cgemm128 has one arm */ }
+    else if (!bnb) { arms.push_back(1); arms.push_back(2); arms.push_back(3); arms.push_back(8); arms.push_back(16); arms.push_back(32); arms.push_back(64); if (c.plain) arms.push_back(4); }
     std::vector<std::vector<float>> t(arms.size());
     for (int r = 0; r < rounds; ++r)
       for (size_t a = 0; a < arms.size(); ++a) {
@@ -166,7 +202,7 @@ int main(int argc, char** argv) {
       std::sort(t[a].begin(), t[a].end());
       const float us = t[a][t[a].size() / 2];
       char lab[16];
-      if (arms[a] < 0) snprintf(lab, sizeof lab, "old"); else snprintf(lab, sizeof lab, "8p/%d", arms[a]);
+      if (arms[a] < -1) snprintf(lab, sizeof lab, "old/%d", -arms[a]); else if (arms[a] < 0) snprintf(lab, sizeof lab, "old"); else if (g.Npad % 256 != 0) snprintf(lab, sizeof lab, "c128"); else snprintf(lab, sizeof lab, "8p/%d", arms[a]);
       printf(" %s %7.1fus %6.0fTF |", lab, us, flops / (us * 1e-6) / 1e12);
     }
     printf("\n");

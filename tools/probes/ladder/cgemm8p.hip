@@ -9,12 +9,15 @@
 //   * a phase is { fragment reads + ONE half-tile of LDS-DMA (2 instructions per thread) | s_barrier | 8 MFMA under s_setprio 1 | s_barrier }, and the
 //     two wave groups (M halves) run ONE barrier apart: while the waves 0-3 multiply, the waves 4-7 read / issue, and vice versa - every SIMD
 //     always has one wave in its MFMA cluster;
-//   * the LDS ring is two K tiles (128 KB).  Half-tiles are restaged as they die: Ah0(g + 2) in P3 of K tile g, Bh0(g + 2) in P4, Bh1(g + 2) in P1 of
-//     g + 1, Ah1(g + 2) in P2 of g + 1 - always two or more phases after the last read of what they overwrite - and ONE counted wait per K tile
-//     (`s_waitcnt vmcnt(4)` in P4: everything but the two newest half-tiles has landed = all of K tile g + 1) orders the data for the reads of the
-//     next K tile, two barriers later.  The DMA queue is never drained inside the kernel;
+//   * LDS = an A ring of THREE K tiles (96 KB) + a B ring of two (64 KB).  Every half-tile staged during K tile g belongs to K tile g + 2: Ah1(g + 2) in P1
+//     (over Ah1(g - 1), last read in P3 of g - 1), Ah0(g + 2) in P2, Bh0(g + 2) in P3 (over Bh0(g), last read in P1), Bh1(g + 2) in P4 (over Bh1(g), last
+//     read in P2) - always two or more phases after the last read of what they overwrite - and ONE counted wait per K tile (`s_waitcnt vmcnt(8)` in
+//     P4: everything but this K tile's own four stages has landed = all of K tile g + 1) orders the data for the reads of the next K tile, two
+//     barriers later: a whole K tile (~2000 cycles) of cover for the newest half-tile (the first version, a two-tile ring with vmcnt(4), had two
+//     phases and lost 15 % to the old kernel).  The DMA queue is never drained inside the kernel;
 //   * the stage stream is continuous over the output tiles a workgroup walks (persistent): the next tile's first K tiles land during the epilogue.
-//     kRunBnBwd: the epilogue stages its 32-row blocks through a wave-private 4 KB scratch BEHIND the ring (no workgroup barrier, the stream goes on).
+//     kRunBnBwd: the epilogue stages 16-row blocks through 2 KB of scratch per wave - the very bytes of the dead A half-tile that the wave itself
+//     will fill with its next two DMA instructions (program order inside the wave is the only ordering needed: no barrier, the stream goes on).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "sefd_desc.h"
@@ -44,9 +47,9 @@ template <bool BNB, int VAR>
 __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int BM = 256, BN = 256, KT = 64;
   constexpr int HALF = 16384;                               // one half-tile
-  constexpr int KBUF = 4 * HALF;                            // one K tile: Ah0 | Ah1 | Bh0 | Bh1
-  constexpr int RING = 2 * KBUF;
-  constexpr int SMEM = RING + (BNB ? 8 * 4096 : 0);
+  constexpr int ASLOT = 2 * HALF, BSLOT = 2 * HALF;         // one K tile of A: Ah0 | Ah1 ; of B: Bh0 | Bh1
+  constexpr int BBASE = 3 * ASLOT;
+  constexpr int SMEM = 3 * ASLOT + 2 * BSLOT;
   constexpr int MI = 4, NI = 2;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
   const int frow = lane & 31, fhalf = lane >> 5;
   const int ca0 = (fhalf ^ ((frow >> 1) & 7)) * 16, cb0 = (fhalf ^ ((frow >> 2) & 3)) * 16;
   const int aoff = (wr * 64 + frow) * 128 + ca0;            // + h * HALF + i * 4096, chunk ^ (32 * s)
-  const int boff = 2 * HALF + (wc * 32 + frow) * 64 + cb0;  // + h * HALF + (s >> 1) * 8192, chunk ^ (32 * (s & 1))
+  const int boff = BBASE + (wc * 32 + frow) * 64 + cb0;     // + h * HALF + (s >> 1) * 8192, chunk ^ (32 * (s & 1))
   const float* biasp = d.bias.arena >= 0 ? reinterpret_cast<const float*>(rp(ab, d.bias)) : nullptr;
   char* yb = rp(ab, d.y);
   const bool want_stats = d.stats.arena >= 0;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
 
   // ---- stage stream: A cursor (K tile whose Ah0 / Ah1 are issued next) and B cursor, each walking the workgroup's output tiles
   int a_t = blockIdx.x, b_t = blockIdx.x;                   // output tile index (persistent walk) of the cursors; >= total: stream exhausted
-  int a_g = 0, b_g = 0;                                     // ring parity of the cursors' K tiles
+  int a_g = 0, b_g = 0;                                     // ring slots of the cursors' K tiles (a_g = index mod 3, b_g = index mod 2)
   int a_kl = 0, b_kl = 0;                                   // K tile index inside the output tile
   int aseg = 0, ak0 = 0, aseglen = 0;
   int bseg = 0, bk0 = 0, bseglen = 0, bkoff = 0;
@@ -143,10 +146,10 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
       bseg = 0; bk0 = 0; b_kl = 0; bseglen = d.seg[0].len; bkoff = d.seg[0].koff;
     }
   };
-  // half h of the A cursor's K tile; h == 1 is the second one issued: the cursor moves on behind it
+  // half h of the A cursor's K tile; h == 0 is the second one issued: the cursor moves on behind it
   auto stage_a = [&](int h, bool live) {
     if (live) {
-      const uint32_t dst = lds0 + (a_g & 1) * KBUF + h * HALF + wid * 1024;
+      const uint32_t dst = lds0 + a_g * ASLOT + h * HALF + wid * 1024;
       const int j0 = ak0 + csa * 8;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -156,8 +159,8 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
         dma16(src, dst + q * 8192);
       }
     }
-    if (h == 1) {
-      ++a_g;
+    if (h == 0) {
+      a_g = a_g == 2 ? 0 : a_g + 1;
       if (a_t < total) {
         ak0 += KT;
         if (++a_kl == nkt) { a_t += gridDim.x; a_begin_tile(); }
@@ -168,14 +171,14 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
   // half h of the B cursor's K tile (both 32-deep sub-tiles); h == 1 is the second one issued
   auto stage_b = [&](int h, bool live) {
     if (live) {
-      const uint32_t dst = lds0 + (b_g & 1) * KBUF + (2 + h) * HALF + wid * 1024;
+      const uint32_t dst = lds0 + BBASE + b_g * BSLOT + h * HALF + wid * 1024;
       const uint16_t* src = b_t < total ? wb0 + h * (32 * 32) + (int64_t)((bkoff + bk0) >> 5) * wtile : zp;
       const int64_t step = b_t < total ? wtile : 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) dma16(src + j * step, dst + j * 8192);
     }
     if (h == 1) {
-      ++b_g;
+      b_g ^= 1;
       if (b_t < total) {
         bk0 += KT;
         if (++b_kl == nkt) { b_t += gridDim.x; b_begin_tile(); }
@@ -184,17 +187,17 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
     }
   };
 
-  // ---- prologue: all of the first K tile, and the first two half-tiles of the second
+  // ---- prologue: the first two K tiles
   a_begin_tile();
   b_begin_tile();
-  stage_a(0, true); stage_b(0, true); stage_b(1, true); stage_a(1, true);
-  stage_a(0, true); stage_b(0, true);
-  wait_vm<4>();
+  stage_a(1, true); stage_a(0, true); stage_b(0, true); stage_b(1, true);
+  stage_a(1, true); stage_a(0, true); stage_b(0, true); stage_b(1, true);
+  wait_vm<8>();
   bar8();
   if (!(VAR & 1) && wr == 1) bar8();                        // the second wave group runs one barrier behind the first
 
   constexpr bool kDma = !(VAR & 32);
-  int gk = 0;                                               // K tiles finished by this workgroup (ring parity)
+  int gk3 = 0, gk2 = 0;                                     // ring slots (A: mod 3, B: mod 2) of the K tile being multiplied
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int tile = xcd_remap8(t, total);
     const int ntile = tile % nn, mtile = tile / nn;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
   if (!(VAR & 64)) {                                                                                                           \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                            \
       _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                            \
-        af[i][s] = *reinterpret_cast<const uint4*>(kb + (H) * HALF + i * 4096 + (aoff ^ (32 * s)));                            \
+        af[i][s] = *reinterpret_cast<const uint4*>(ka + (H) * HALF + i * 4096 + (aoff ^ (32 * s)));                            \
     }                                                                                                                          \
   }
 #define SEFD8P_RDB(H, BR)                                                                                                      \
@@ -251,35 +254,38 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
   __builtin_amdgcn_sched_barrier(0);
 
     for (int p = 0; p < nkt; ++p) {
-      const char* kb = smem + (gk & 1) * KBUF;
+      const char* ka = smem + gk3 * ASLOT;
+      const char* kb = smem + gk2 * BSLOT;
       // P1: quadrant (m0, n0)
       SEFD8P_RDB(0, b0)
       SEFD8P_RDA(0)
-      stage_b(1, kDma);
+      stage_a(1, kDma);
       SEFD8P_MMA(0, 0, b0)
       // P2: quadrant (m0, n1)
       SEFD8P_RDB(1, b1)
-      stage_a(1, kDma);
+      stage_a(0, kDma);
       SEFD8P_MMA(0, 1, b1)
       // P3: quadrant (m1, n1)
       SEFD8P_RDA(1)
-      stage_a(0, kDma);
-      SEFD8P_MMA(2, 1, b1)
-      // P4: quadrant (m1, n0); everything but the two newest half-tiles has landed = all of the next K tile
       stage_b(0, kDma);
-      if (kDma) wait_vm<4>(); else wait_vm<0>();
+      SEFD8P_MMA(2, 1, b1)
+      // P4: quadrant (m1, n0); everything but this K tile's own four stages has landed = all of the next K tile
+      stage_b(1, kDma);
+      if (kDma) wait_vm<8>(); else wait_vm<0>();
       SEFD8P_MMA(2, 0, b0)
-      ++gk;
+      gk3 = gk3 == 2 ? 0 : gk3 + 1;
+      gk2 ^= 1;
     }
 #undef SEFD8P_RDA
 #undef SEFD8P_RDB
 #undef SEFD8P_MMA
 
     if constexpr (BNB) {
-      // ---- kRunBnBwd epilogue.  Per 32-row block i: the block goes to the wave's 4 KB scratch as bf16 (quad transpose, 8-byte pieces, rows of 128 bytes,
+      // ---- kRunBnBwd epilogue.  Per 16-row block: the block goes to the wave's 2 KB of scratch as bf16 (quad transpose, 8-byte pieces, rows of 128 bytes,
       // 16-byte chunks XOR-swizzled by the row), then lane (chunk ch = lane & 7, rows lane >> 3 + 8 k) moves 16-byte row chunks scratch -> global and,
       // beside each, reads the same chunk of the BatchNorm layer's forward output and accumulates the three backward sums of its 8 columns.
-      char* wt = smem + RING + wid * 4096;
+      // Scratch = the two 1 KB pieces of Ah1 of this tile's LAST K tile (dead since its P3) that this wave fills with its own next DMAs.
+      char* wt = smem + (gk3 == 0 ? 2 : gk3 - 1) * ASLOT + HALF + wid * 1024;      // rows 0-7 here, rows 8-15 at + 8192
       const QuadT qt(lane);
       const int ch = lane & 7, n0 = ntile * BN + wn0 + ch * 8;
       const bool cok = n0 < d.N;
@@ -297,6 +303,7 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        // the 4 forward-output chunks of a 32-row block are all in flight before the first is used
         uint4 ypre[4];
         int64_t oo[4];
 #pragma unroll
@@ -310,37 +317,45 @@ __global__ __launch_bounds__(512) void cgemm8p_kernel(const RunGemm d, const Are
             ypre[kk] = *reinterpret_cast<const uint4*>(ybn + (int64_t)b * d.bnb_bstride + (int64_t)u * d.bnb_tstride + (int64_t)fo * d.bnb_fstride + d.bnb_off + n0);
           }
         }
+        {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int col = j * 32 + (lane & 28);
+          for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 8 * q + 4 * (lane >> 5) + (lane & 3);
-            const uint2 pk = qt.pack(acc[i][j][4 * q] + bv[j], acc[i][j][4 * q + 1] + bv[j], acc[i][j][4 * q + 2] + bv[j], acc[i][j][4 * q + 3] + bv[j]);
-            *reinterpret_cast<uint2*>(wt + row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2) = pk;
-          }
-        }
+            for (int j = 0; j < NI; ++j) {
+              const int col = j * 32 + (lane & 28);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int row = (lane >> 3) + 8 * kk;
-          const int64_t o = oo[kk];
-          const uint4 dzv = *reinterpret_cast<const uint4*>(wt + row * 128 + ((ch ^ (row & 7)) << 4));
-          if (o < 0) continue;
-          const uint4 yv = ypre[kk];
-          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = dzv;
-          const uint32_t dw[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+              for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = 2 * hb + q2;
+                const int rl = 4 * (lane >> 5) + (lane & 3);              // row inside the 8-row piece q2
+                const uint2 pk = qt.pack(acc[i][j][4 * q] + bv[j], acc[i][j][4 * q + 1] + bv[j], acc[i][j][4 * q + 2] + bv[j], acc[i][j][4 * q + 3] + bv[j]);
+                *reinterpret_cast<uint2*>(wt + q2 * 8192 + rl * 128 + (((col >> 3) ^ rl) << 4) + (col & 7) * 2) = pk;
+              }
+            }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dz = bf2f((uint16_t)(dw[e >> 1] >> (16 * (e & 1)))), yy = bf2f((uint16_t)(yw[e >> 1] >> (16 * (e & 1))));
-            const float xh = (yy - pm[e]) * pis[e];
-            const float bn = pg[e] * xh + pb2[e];
-            const float dbn = bn > 0.f ? dz : bslope * dz;
-            t0[e] += dbn;
-            t1[e] += dbn * xh;
-            t2[e] += bn > 0.f ? 0.f : bn * dz;
+            for (int k2 = 0; k2 < 2; ++k2) {
+              const int kk = hb * 2 + k2;
+              const int rl = lane >> 3;
+              const uint4 dzv = *reinterpret_cast<const uint4*>(wt + k2 * 8192 + rl * 128 + ((ch ^ rl) << 4));
+              const int64_t o = oo[kk];
+              if (o < 0) continue;
+              const uint4 yv = ypre[kk];
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(yb) + o + n0) = dzv;
+              const uint32_t dw[4] = {dzv.x, dzv.y, dzv.z, dzv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float dz = bf2f((uint16_t)(dw[e >> 1] >> (16 * (e & 1)))), yy = bf2f((uint16_t)(yw[e >> 1] >> (16 * (e & 1))));
+                const float xh = (yy - pm[e]) * pis[e];
+                const float bn = pg[e] * xh + pb2[e];
+                const float dbn = bn > 0.f ? dz : bslope * dz;
+                t0[e] += dbn;
+                t1[e] += dbn * xh;
+                t2[e] += bn > 0.f ? 0.f : bn * dz;
+              }
+            }
           }
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the scratch reads are done before this wave's next DMAs land there
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
 #pragma unroll
