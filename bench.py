@@ -28,7 +28,6 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI3
 PEAK_HBM_GBS = 8000.0
 K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
 F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
-F_SLAB = 128                             # ... of the opt-in LDS-slab kernel (kRunSlab, SEFD_SLAB=1)
 PMC_ROUND = "r05"
 PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_traffic.json")       # default workload; main() switches to <round>_pmc_traffic_<model>.json
 PMC_DEFAULT_BATCH = {"dccrn": 32, "dccrn_large": 64, "fullsubnet": 64}       # the batch each committed summary was collected at
@@ -98,7 +97,7 @@ def pmc_step_total():
 def _op_class(info):
     k = info["kind"]
     if k == K_RUNGEMM:
-        return ("slabgemm" if info["flags"] & F_SLAB else "cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
+        return ("cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
     if k == K_WGRAD:
         return ("wgrad", info["dtype"])
     if k in (K_LSTM_FWD, K_LSTM_BWD):
@@ -177,7 +176,7 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
             detail[label] = dict(bound="mfma", tflops=round(tf, 2), frac=round(tf / PEAK_TFLOPS[dt], 4), tflops_isolated=round(tfi, 2),
                                  frac_isolated=round(tfi / PEAK_TFLOPS[dt], 4), ms=round(v["ms_situ"], 3), ms_isolated=round(v["ms"], 3),
                                  launches=v["launches"])
-    gemm_keys = [k for k in agg if k[0] in ("rungemm", "cgemm256", "wgrad", "slabgemm")]
+    gemm_keys = [k for k in agg if k[0] in ("rungemm", "cgemm256", "wgrad")]
     key = max(gemm_keys, key=lambda k: agg[k]["ms_situ"])
     a = agg[key]
     achieved = a["flops"] / (a["ms_situ"] * 1e-3) / 1e12
@@ -185,7 +184,7 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
     peak = PEAK_TFLOPS[key[1]]
     # kernel names as tools/pmc_traffic.py stores them ("void sefd::" / "sefd::" stripped, template arguments kept)
     prefixes = {"rungemm": ["rungemm_kernel<bf16_t" if key[1] else "rungemm_kernel<float"],
-                "cgemm256": ["cgemm256_kernel"], "slabgemm": ["slabgemm_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
+                "cgemm256": ["cgemm256_kernel"], "wgrad": ["wgrad_bf16" if key[1] else "wgrad_kernel<float"]}[key[0]]
     return dict(bound="mfma", kernel=f"{key[0]}<{'bf16' if key[1] else 'float'}>", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                 frac=round(achieved / peak, 4), frac_isolated=round(isolated / peak, 4),
                 traffic=pmc_traffic(prefixes) if pmc_ok else None, launches_per_step=a["launches"],

@@ -186,7 +186,6 @@ __device__ __forceinline__ void bnb_accum(const BnbCol& c, float slope, float dz
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
-bool launch_slabgemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);        // (t, f) convolutions with an LDS-resident input slab (slabgemm.hip)
 bool launch_rundirect(const RunGemm& d, const ArenaBases& ab, hipStream_t st);       // thin layers, N <= 64 (thin.hip)
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);

@@ -381,95 +381,6 @@ static double window_value(const ModelConfig& cfg, int j, int W) {
 int32_t pe(const ParamInfo& p, int64_t idx, int sign = 1) { return (int32_t)(sign * (p.off + idx + 1)); }
 
 
-// ---- slabgemm.hip geometry.  LDS rows of a fragment read: lane l of a 32-row A fragment (tile rows r0 .. r0 + 31, r0 % 32 == 0) reads 16 bytes
-// of the slab row of (frame slot fl + dtr, position fo * S + df); a ds_read_b128 is served in four groups of 16 lanes, conflict-free when the 16
-// lanes of a group hit 16 different 16-byte units of the 256-byte bank row.  slab_layout searches the slot order (parity split for S == 2), the
-// padding and the swizzle shift for the smallest conflict-free slab that fits kSlabMaxRows (worst case: one more frame slot per batch boundary).
-static int slab_conflicts(int Fo, int S, int ntap, int NPp, int NPh, int shift) {
-  static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-  int worst = 1;
-  for (int r0 = 0; r0 < 256; r0 += 32)
-    for (int dtr = 0; dtr < 3; ++dtr)                        // (2: a batch boundary inside the fragment shifts later frames by one more slot)
-      for (int df = 0; df < ntap; ++df)
-        for (int g = 0; g < 2; ++g) {
-          int cnt[16] = {0};
-          for (int q = 0; q < 16; ++q) {
-            const int t = r0 + grp[g][q], fl = t / Fo, fo = t % Fo, p = fo * S + df;
-            const int R = (fl + dtr) * NPp + (NPh > 0 ? (p & 1) * NPh + (p >> 1) : p);
-            const int u = (R * 4 + ((R >> shift) & 3)) & 15;
-            worst = std::max(worst, ++cnt[u]);
-          }
-        }
-  return worst;
-}
-static bool slab_layout(RunGemm& g, int Tout) {
-  const int Fo = g.Fo, S = g.slab_S, ntap = g.slab_ntap, NP = (Fo - 1) * S + ntap, NF = 256 / Fo;
-  const int kmax = (NF - 1 + Tout - 1) / Tout;               // batch boundaries a tile can cross
-  const int nfs = NF + 1 + kmax;
-  int best_c = 99, best_rows = 1 << 30;
-  for (int split = (S == 2 ? 1 : 0); split >= 0; --split)
-    for (int NPp = NP; NPp * nfs <= kSlabMaxRows; ++NPp)
-      for (int NPh = split ? (NP + 1) / 2 : 0; NPh <= (split ? NPp / 2 : 0); ++NPh)
-        for (int shift = 2; shift <= 3; ++shift) {
-          const int rows = nfs * NPp;
-          const int c = slab_conflicts(Fo, S, ntap, NPp, NPh, shift);
-          if (c < best_c || (c == best_c && rows < best_rows)) {
-            best_c = c; best_rows = rows;
-            g.slab_np = NPp; g.slab_nph = NPh; g.slab_swz = shift;
-          }
-        }
-  if (best_c > 2) return false;
-  fastdiv_make((uint32_t)g.slab_np, &g.slab_div_m, &g.slab_div_s);
-  return true;
-}
-// fills g.slab_* when the GEMM has the slab form; false otherwise (g.slab_* then meaningless)
-static bool slab_geometry(RunGemm& g) {
-  if (g.xdt != DT_BF16 || g.ydt != DT_BF16 || !(g.flags & kRunAligned) || !(g.flags & kRunYAligned) || (g.flags & (kRunAccum | kRunWTile32))) return false;
-  if (g.Npad % 128 != 0 || (g.Npad > 128 && g.Npad % 256 != 0) || g.N % 8 != 0) return false;
-  if ((g.flags & kRunBnBwd) && g.Npad % 256 != 0) return false;
-  if (g.Fo < 1 || g.Fo > 128 || (g.Fo & (g.Fo - 1)) || g.M % g.Fo != 0) return false;
-  if (g.nseg != 2 && g.nseg != 4) return false;
-  int cnt[2] = {0, 0}, dmin[2] = {1 << 20, 1 << 20}, dmax[2] = {-(1 << 20), -(1 << 20)}, off[2] = {0, 0}, len[2] = {0, 0};
-  for (int s = 0; s < g.nseg; ++s) {
-    const Seg& sg = g.seg[s];
-    if (sg.src < 0 || sg.src > 1) return false;
-    if (cnt[sg.src] == 0) { off[sg.src] = sg.off; len[sg.src] = sg.len; }
-    else if (off[sg.src] != sg.off || len[sg.src] != sg.len) return false;
-    dmin[sg.src] = std::min(dmin[sg.src], sg.dt); dmax[sg.src] = std::max(dmax[sg.src], sg.dt);
-    ++cnt[sg.src];
-  }
-  const int nsrc = cnt[1] ? 2 : 1;
-  if (cnt[0] != 2 || (nsrc == 2 && cnt[1] != 2) || g.nseg != 2 * nsrc) return false;
-  for (int s = 0; s < nsrc; ++s)
-    if (dmax[s] != dmin[s] + 1 || dmin[s] != dmin[0]) return false;
-  if (nsrc == 2 && g.seg[0].src != 0) return false;          // kernel order: all of source 0, then source 1
-  for (int s = 1; s < g.nseg; ++s)
-    if (g.seg[s].src < g.seg[s - 1].src) return false;
-  int S = 0, ntap = 0, p0 = 0;
-  for (int s = 0; s < nsrc; ++s) {
-    int Cs = 0, Ss = 0;
-    for (int cand = 1; cand <= 2 && !Cs; ++cand) {
-      if (g.fstride[s] % cand) continue;
-      const int C = g.fstride[s] / cand;
-      if (C < 32 || C % 32 || len[s] % C || off[s] % C || g.rowlen[s] % C || g.base[s] % 8 || g.tstride[s] % 8 || g.bstride[s] % 8) continue;
-      const int nt = len[s] / C;
-      if (nt != 2 && nt != 3 && nt != 5) continue;
-      Cs = C; Ss = cand;
-    }
-    if (!Cs) return false;
-    const int nt = len[s] / Cs, p = off[s] / Cs;
-    if (s == 0) { S = Ss; ntap = nt; p0 = p; }
-    else if (S != Ss || ntap != nt || p0 != p) return false;
-    g.slab_C[s] = Cs;
-  }
-  if (nsrc == 1) g.slab_C[1] = 0;
-  const int nbatch = g.M / (g.Tout * g.Fo);
-  for (int s = 0; s < nsrc; ++s)
-    if ((int64_t)nbatch * g.bstride[s] + g.base[s] >= (int64_t)1 << 31) return false;
-  g.slab_S = S; g.slab_ntap = ntap; g.slab_p0 = p0; g.slab_dtmin = dmin[0];
-  return slab_layout(g, g.Tout);
-}
-
 // Post-pass over a finished plan: give every RUNGEMM the zero page and mark the ones whose runs are whole, 16-byte aligned
 // chunks (then the kernel uses the LDS-DMA loader).  Arena buffers are 256-byte aligned, so only element offsets matter.
 void finalize_rungemms(Builder& b, Plan* P) {
@@ -492,63 +403,6 @@ void finalize_rungemms(Builder& b, Plan* P) {
         g.flags = (g.flags & ~kRunYAligned) | (ya ? kRunYAligned : 0);
       }
     }
-  // LDS-resident input slab (slabgemm.hip, kRunSlab) for the (t, f) convolutions: every source has two runs (dt, dt + 1) of ntap frequency taps x C
-  // channels, C % 32 == 0, Fo a power of two, bf16 in and out.  The packed weights go to [source][chunk][run][tap][32] order (w_index_g): like
-  // kRunWTile32 a property of the packed BUFFER, so only when every reader agrees.  SEFD_SLAB=1: on.  SEFD_SLAB_MINM: fewest rows.
-  {
-    // OPT-IN (SEFD_SLAB=1): measured on MI355X (profiles/r05_tuning_notes.md) the kernel is parity-green but 3-8 % slower than rungemm / cgemm256 on the
-    // same layers - its loop trades LDS-DMA issue for fragment-address arithmetic and loses the two-workgroups-per-CU overlap of the 128-row kernel
-    const bool on = getenv("SEFD_SLAB") && atoi(getenv("SEFD_SLAB")) == 1;
-    const int minm = getenv("SEFD_SLAB_MINM") ? atoi(getenv("SEFD_SLAB_MINM")) : 16384;
-    std::vector<Op*> all;
-    for (auto* ops : {&P->fwd, &P->bwd})
-      for (Op& op : *ops) all.push_back(&op);
-    std::map<int64_t, int> state;                            // weight buffer offset -> 1: every reader so far qualifies (same geometry), 0: no
-    std::map<int64_t, RunGemm> first;
-    auto same = [](const RunGemm& a, const RunGemm& b) {
-      if (a.nseg != b.nseg || a.Npad != b.Npad || a.ldw != b.ldw || a.slab_C[0] != b.slab_C[0] || a.slab_C[1] != b.slab_C[1] || a.slab_ntap != b.slab_ntap) return false;
-      for (int s = 0; s < a.nseg; ++s)
-        if (a.seg[s].src != b.seg[s].src || a.seg[s].len != b.seg[s].len || a.seg[s].koff != b.seg[s].koff) return false;
-      return true;
-    };
-    for (Op* op : all) {
-      if (op->kind != OP_RUNGEMM || op->g.w.arena != A_WS) continue;
-      RunGemm g = op->g;
-      const bool e = on && g.M >= minm && slab_geometry(g);
-      auto it = state.find(g.w.off);
-      if (it == state.end()) { state[g.w.off] = e ? 1 : 0; if (e) first[g.w.off] = g; }
-      else if (it->second && !(e && same(first[g.w.off], g))) it->second = 0;
-    }
-    for (auto& kv : state) {
-      if (!kv.second) continue;
-      RunGemm g0 = first[kv.first];
-      g0.flags |= kRunSlab;
-      bool done = false;
-      for (Op* po : all) {
-        if (po->kind != OP_PACK || po->pack.width != 1 || po->pack.dst.arena != A_WS || po->pack.dst.off != kv.first) continue;
-        if (po->pack.n != (int64_t)g0.Npad * g0.ldw) break;
-        int32_t* tab = reinterpret_cast<int32_t*>(P->consts.data() + po->pack.tab.off);
-        std::vector<int32_t> old(tab, tab + po->pack.n);
-        std::fill(tab, tab + po->pack.n, 0);
-        for (int n = 0; n < g0.Npad; ++n)
-          for (int s = 0; s < g0.nseg; ++s)
-            for (int j = 0; j < g0.seg[s].len; ++j) {
-              const int k = g0.seg[s].koff + j;
-              tab[w_index_g(g0, n, k)] = old[(size_t)n * g0.ldw + k];
-            }
-        done = true;
-        break;
-      }
-      if (!done) continue;
-      for (Op* op : all)
-        if (op->kind == OP_RUNGEMM && op->g.w.arena == A_WS && op->g.w.off == kv.first) {
-          RunGemm g = op->g;
-          slab_geometry(g);
-          g.flags |= kRunSlab;
-          op->g = g;
-        }
-    }
-  }
   // Wide-tile kernel (cgemm256.hip) for the bf16 layers that carry the FLOPs: N a multiple of 256, LDS-DMA-able runs, enough rows.
   // Its weights are packed K-tile major (kRunWTile32): a property of the packed BUFFER, so it is chosen only when every GEMM
   // that reads the buffer qualifies, and the PACK table of the matrix is permuted here, once.  SEFD_CG256=0: 128 x 128 kernel
@@ -567,7 +421,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
     for (Op* op : all) {
       if (op->kind != OP_RUNGEMM || op->g.w.arena != A_WS) continue;
       const RunGemm& g = op->g;
-      const bool e = wide && !(g.flags & kRunSlab) && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm && g.n2 == 0 &&
+      const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm && g.n2 == 0 &&
                      (((g.M + 255) / 256) * (int64_t)(g.Npad / 256) >= wide_mintiles || g.ldw > 1024);
       auto it = elig.find(g.w.off);
       if (it == elig.end()) elig[g.w.off] = e; else it->second = it->second && e;
@@ -603,9 +457,6 @@ void finalize_rungemms(Builder& b, Plan* P) {
           for (int s = 0; s < 2; ++s)
             if (g.x[s].arena >= 0) fprintf(stderr, "    src%d bstride=%lld tstride=%d base=%d rowlen=%d fstride=%d Tin=%d\n", s, (long long)g.bstride[s], g.tstride[s], g.base[s], g.rowlen[s], g.fstride[s], g.Tin[s]);
           for (int s = 0; s < g.nseg; ++s) fprintf(stderr, "    seg%d src=%d dt=%d off=%d len=%d koff=%d\n", s, g.seg[s].src, g.seg[s].dt, g.seg[s].off, g.seg[s].len, g.seg[s].koff);
-          if (g.flags & kRunSlab)
-            fprintf(stderr, "    slab C=%d,%d S=%d ntap=%d p0=%d np=%d nph=%d swz=%d dtmin=%d conflicts=%d rows=%d\n", g.slab_C[0], g.slab_C[1], g.slab_S, g.slab_ntap, g.slab_p0, g.slab_np,
-                    g.slab_nph, g.slab_swz, g.slab_dtmin, slab_conflicts(g.Fo, g.slab_S, g.slab_ntap, g.slab_np, g.slab_nph, g.slab_swz), (256 / g.Fo + 2) * g.slab_np);
         }
         ++i;
       }

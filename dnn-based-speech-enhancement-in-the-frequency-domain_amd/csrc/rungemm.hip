@@ -1140,7 +1140,6 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
 }
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
-  if (launch_slabgemm(d, ab, st)) return;                  // convolutions with an LDS-resident input slab (slabgemm.hip)
   if (launch_cgemm256(d, ab, st)) return;                  // wide-tile kernel for the N >= 128 bf16 layers (cgemm256.hip)
   if (launch_rundirect(d, ab, st)) return;                 // direct-operand kernel for the thin bf16 layers (thin.hip)
   if (d.xdt == DT_BF16) launch_rungemm_t<bf16_t>(d, ab, st);
@@ -1176,9 +1175,12 @@ static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t
 }
 
 void launch_wgrad(const RunGemm& d0, const ArenaBases& ab, hipStream_t st) {
-  static const int wdbg = getenv("SEFD_WG_DBG") ? atoi(getenv("SEFD_WG_DBG")) : 0;
   RunGemm d = d0;
+#ifdef SEFD_TUNING
+  // wrong-result arm (no partial-sum stores), tuning builds only (-DSEFD_TUNING): the product library has no switch that changes what a launch computes
+  static const int wdbg = getenv("SEFD_WG_DBG") ? atoi(getenv("SEFD_WG_DBG")) : 0;
   if (wdbg & 8) d.flags |= 1 << 30;
+#endif
   if (d.xdt == DT_BF16 && (d.flags & kRunAligned)) {
     if (d.flags & kRunWgWide) { if (d.Npad % 256 == 0) launch_wgrad_wide(d, ab, st); else launch_wgrad_wide128(d, ab, st); return; }
     switch (wgrad_tn(d.xdt, d.N, d.Npad)) {        // sefd_desc.h: the planner sized nsplit for the same tile

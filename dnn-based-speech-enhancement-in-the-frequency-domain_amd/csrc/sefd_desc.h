@@ -81,18 +81,6 @@ struct RunGemm {
   // upstream gradient produces the input gradients of BOTH sources of a decoder layer: previous layer's output and the skip connection)
   int32_t n2;
   Ptr y2;
-  // kRunSlab (slabgemm.hip): the GEMM is a (t, f) convolution over channels-last tensors - every run is `slab_ntap` frequency taps x slab_C[src]
-  // channels of one frame, a row's runs start at position  slab_p0 + fo * slab_S  (positions = groups of slab_C[src] elements), the two time taps
-  // of a source are its two runs.  Instead of streaming the tap-expanded operand (each input element 2 * ntap / S times per tile), a 256-row tile
-  // keeps the input positions it touches ONCE in LDS, 32 channels at a time (the slab: frame slots x position slots x 64 bytes), and reads its
-  // MFMA A fragments from there for every tap.  K order of the packed weights (slab_w_index): [source][32-channel chunk][run][tap][32].
-  //   position slot of position p (relative to slab_p0): slab_nph > 0: (p & 1) * slab_nph + (p >> 1) (stride-2 layers: a tap then reads consecutive
-  //   slots), else p;  slab_np = slots per frame (padded by the planner so that the fragment reads are free of LDS bank conflicts);
-  //   16-byte unit u of LDS row R holds channels 8 * (u ^ ((R >> slab_swz) & 3)) .. + 8 of the chunk.
-  int32_t slab_C[2];
-  int32_t slab_S, slab_ntap, slab_p0, slab_np, slab_nph, slab_swz;
-  int32_t slab_dtmin;          // smallest dt of the runs; every source has exactly the runs dt = slab_dtmin and slab_dtmin + 1
-  uint32_t slab_div_m, slab_div_s;   // fastdiv_make(slab_np)
 };
 static inline void fastdiv_make(uint32_t d, uint32_t* m, uint32_t* s) {
   if (d <= 1) { *m = 0; *s = 0; return; }
@@ -108,31 +96,14 @@ constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chu
 constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw / 32][Npad][32]: the B operand of one 32-deep K tile is ONE
                                  // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
 constexpr int kRunBnBwd = 64;    // epilogue accumulates BatchNorm-backward partial sums against the layer's forward output (fields bnb_*); `stats` rows are [3][Npad]
-constexpr int kRunSlab = 128;    // slabgemm.hip: LDS-resident input slab, weights in slab_w_index order (fields slab_*)
-constexpr int kSlabMaxRows = 736;   // 64-byte rows per slab buffer (two buffers + four 32-deep weight sub-tiles of 256 columns = 156 KB of LDS)
 constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`
 static inline int64_t w_index(int flags, int ldw, int Npad, int n, int k) {
   return (flags & kRunWTile32) ? ((int64_t)(k >> 5) * Npad + n) * 32 + (k & 31) : (int64_t)n * ldw + k;
 }
 
-// element index of W[n][k] for any RUNGEMM descriptor.  kRunSlab: k in run r of source s -> tap df = (k - koff) / C, channel c; sub-tile
-// st = (chunks of the sources before s) * NT + (c / 32) * NT + rank(r) * ntap + df with NT = 2 * ntap taps per chunk, rank = position of the run among
-// its source's runs; element (st * Npad + n) * 32 + c % 32.  Padding columns (no run covers k) map to element 0: their operand is zero.
-static inline int64_t w_index_g(const RunGemm& g, int n, int k) {
-  if (!(g.flags & kRunSlab)) return w_index(g.flags, g.ldw, g.Npad, n, k);
-  const int NT = 2 * g.slab_ntap;
-  for (int r = 0; r < g.nseg; ++r) {
-    const Seg& sg = g.seg[r];
-    if (sg.src < 0 || k < sg.koff || k >= sg.koff + sg.len) continue;
-    const int C = g.slab_C[sg.src], j = k - sg.koff, df = j / C, c = j % C;
-    int rank = 0;
-    for (int q = 0; q < r; ++q) rank += g.seg[q].src == sg.src;
-    const int st = (sg.src ? (g.slab_C[0] / 32) * NT : 0) + (c / 32) * NT + rank * g.slab_ntap + df;
-    return ((int64_t)st * g.Npad + n) * 32 + (c & 31);
-  }
-  return 0;
-}
+// element index of W[n][k] for any RUNGEMM descriptor
+static inline int64_t w_index_g(const RunGemm& g, int n, int k) { return w_index(g.flags, g.ldw, g.Npad, n, k); }
 
 // PACK: dst[i] = sum_{e < width} sign(tab[i*width+e]) * src[|tab[i*width+e]|-1]   (entry 0 -> nothing).  Table int32 in A_CONST.
 // width 1: packed conv / LSTM weights ; width 2: combined biases (b_r - b_i | b_r + b_i), (b_ih + b_hh).

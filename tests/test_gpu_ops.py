@@ -38,7 +38,6 @@ def _typed(t_u8, dt):
                                                         ("DCCRN", 3, 4001, "R", (16, 32, 32, 64, 64, 64), 128, "bf16"),     # L = 4001 marks the cases that send every N <= 64 conv GEMM through the direct-operand kernel (thin.hip)
                                                         ("DCCRN", 1, 2403, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),
                                                         ("DCCRN", 1, 2401, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L odd: marks the case that lowers SEFD_CG256_MINM -> wide-tile kernel on every N % 256 == 0 layer
-                                                        ("DCCRN", 2, 2407, "C", (32, 64, 128, 256, 256, 256), 256, "bf16"),  # L = 2407 marks the case that switches the opt-in LDS-slab kernel (slabgemm.hip) on for every conv it can take; two batch items: tiles cross the batch boundary (zero frame slots)
                                                         ("DCCRN", 2, 1600, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),     # wide LSTM (H = 256): cluster kernels, one partial row block
                                                         ("DCCRN", 18, 2000, "C", (16, 32, 32, 64, 64, 64), 512, "bf16"),    # the same, two row blocks (18 sequences > 16)
                                                         ("DCCRN", 1, 1600, "C", (16, 32, 32, 64, 64, 64), 1024, "bf16"),    # H = 512: 8 workgroups per cluster
@@ -71,14 +70,6 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
         os.environ.pop("SEFD_WG256_MINM", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
     os.environ.pop("SEFD_BN_FUSE", None)
-    os.environ.pop("SEFD_SLAB_MINM", None)
-    os.environ.pop("SEFD_SLAB", None)
-    slab_case = L == 2407
-    if slab_case:
-        L -= L % 100
-        os.environ["SEFD_SLAB"] = "1"          # opt-in kernel
-        os.environ["SEFD_SLAB_MINM"] = "1"
-        os.environ["SEFD_BN_FUSE"] = "2"   # kRunBnBwd epilogue of the slab kernel
     if L in (4001, 2403):                  # the direct-operand kernel takes GEMMs with M >= 65536 by default
         L -= 1 if L == 4001 else 3
         os.environ["SEFD_DIRECT_MINM"] = "0"
@@ -107,11 +98,6 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     if model != "FullSubNet":
         plan = Plan(B, L, masking_mode=mode, kernel_num=kn, rnn_units=ru, act_dtype=dtype, model=model.split("_")[0], use_cbn=model == "DCCRN_CBN")
     os.environ.pop("SEFD_BN_FUSE", None)
-    os.environ.pop("SEFD_SLAB_MINM", None)
-    os.environ.pop("SEFD_SLAB", None)
-    if slab_case:
-        nslab = sum(1 for ph in (PHASE_FWD, PHASE_BWD) for i in range(plan.num_ops(ph)) if plan.op_info(ph, i)["kind"] == 1 and plan.op_info(ph, i)["flags"] & 128)
-        assert nslab >= 12, nslab                  # the case runs what it is named for
     os.environ.pop("SEFD_CG256_MINM", None)        # the plan is built: later tests get the default thresholds again
     os.environ.pop("SEFD_WG256_MINM", None)
     os.environ.pop("SEFD_LSTM_ROWS_MIN", None)
@@ -200,7 +186,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     os.environ.pop("SEFD_LSTM_MT", None)
     os.environ.pop("SEFD_LSTM_RPW", None)
     os.environ.pop("SEFD_DIRECT_MINM", None)
-    with open(_report_path(f"ops_report_{model}_B{B}_{mode.replace('/', '-')}_{dtype}_{L}{'_slab' if slab_case else ''}.txt"), "w") as f:
+    with open(_report_path(f"ops_report_{model}_B{B}_{mode.replace('/', '-')}_{dtype}_{L}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert not bad, "\n".join(bad[:20])
 
