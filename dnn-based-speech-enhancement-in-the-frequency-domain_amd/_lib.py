@@ -81,6 +81,9 @@ def lib():
         "sefd_plan_status_word": (vp, [vp]),
         "sefd_plan_status": (i32, [vp, i32]),
         "sefd_plan_status_set": (i32, [vp]),
+        "sefd_tuning_set": (None, [C.c_char_p, C.c_char_p]),
+        "sefd_tuning_get": (C.c_char_p, [C.c_char_p]),
+        "sefd_tuning_clear": (None, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
@@ -97,4 +100,5 @@ EXPORTED = ["sefd_plan_create", "sefd_plan_destroy", "sefd_plan_error", "sefd_pl
             "sefd_plan_const_data", "sefd_plan_num_ops", "sefd_plan_ops", "sefd_op_size", "sefd_plan_op_info", "sefd_plan_run",
             "sefd_plan_grad_bucket", "sefd_plan_grad_bucket_range", "sefd_plan_run_cb", "sefd_plan_run_flags", "sefd_plan_run_timed",
             "sefd_loss_ws_floats", "sefd_loss_forward", "sefd_loss_backward", "sefd_loss_rows_ws_floats", "sefd_loss_rows_forward", "sefd_loss_rows_backward", "sefd_loss_dp_offset", "sefd_loss_dp_finish", "sefd_lms_forward", "sefd_lms_backward", "sefd_fsn_targets", "sefd_mix_snr", "sefd_pmsqe_table_floats", "sefd_pmsqe_ws_floats", "sefd_pmsqe_forward", "sefd_pmsqe_backward",
-            "sefd_adam_step", "sefd_adam_step_guarded", "sefd_adam_step_guarded_dp", "sefd_plan_status_poison", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set"]
+            "sefd_adam_step", "sefd_adam_step_guarded", "sefd_adam_step_guarded_dp", "sefd_plan_status_poison", "sefd_plan_status_word", "sefd_plan_status", "sefd_plan_status_set",
+            "sefd_tuning_set", "sefd_tuning_get", "sefd_tuning_clear"]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsefd_hip.so")
-SOURCES = ["api.hip", "kernels.hip", "rungemm.hip", "cgemm256.hip", "lstm_bf16.hip", "lstm_cluster.hip", "lstm_rows.hip", "bn.hip", "cbn.hip", "lms.hip", "pmsqe.hip", "mix.hip", "fsn.hip", "stft_fft.hip", "thin.hip", "plan.cpp"]
+SOURCES = ["api.hip", "kernels.hip", "rungemm.hip", "cgemm256.hip", "lstm_bf16.hip", "lstm_cluster.hip", "lstm_rows.hip", "bn.hip", "cbn.hip", "lms.hip", "pmsqe.hip", "mix.hip", "fsn.hip", "stft_fft.hip", "thin.hip", "plan.cpp", "tuning.cpp"]
 
 
 def _headers():
@@ -26,8 +26,40 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_digest(paths, extra="") -> str:
+    """sha256 over the CONTENTS of `paths` (sorted by name) + `extra` (compiler flags).  "Is the built library current?" is decided by this
+    digest, stored beside the library as <lib>.stamp, not by modification times: a snapshot of the tree on another machine (gpurun, the
+    driver's GPU box) has arbitrary mtimes, and a library that merely LOOKS older than its sources was rebuilt there for 90 seconds."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def stamp_current(lib, digest) -> bool:
+    try:
+        return os.path.exists(lib) and open(lib + ".stamp").read().strip() == digest
+    except OSError:
+        return False
+
+
+def write_stamp(lib, digest):
+    with open(lib + ".stamp", "w") as f:
+        f.write(digest + "\n")
+
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _digest():
+    return source_digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), " ".join(FLAGS + SOURCES))
+
+
 def needs_build() -> bool:
-    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _headers())
+    return not stamp_current(LIB, _digest())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -40,7 +72,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
         if force or _stale(obj, [src] + heads):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", obj, src])
+            jobs.append([hipcc] + FLAGS + ["-c", "-o", obj, src])
 
     def run(cmd):
         if verbose:
@@ -50,6 +82,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=int(os.environ.get("SEFD_BUILD_JOBS", "6"))) as ex:
         list(ex.map(run, jobs))
     run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [os.path.join(OBJ, s + ".o") for s in SOURCES])
+    write_stamp(LIB, _digest())
     return LIB
 
 

@@ -6,6 +6,7 @@
 #include "../../include/sefd.h"
 #include "dev_common.h"
 #include "plan.h"
+#include "tuning.h"
 
 using namespace sefd;
 
@@ -14,7 +15,8 @@ struct sefd_plan {
   std::vector<std::string> names;
   // second stream + events for the off-critical-path lane (created on first use, owned by the plan)
   mutable hipStream_t side = nullptr, side2 = nullptr;   // side2: lane 3 (the layer-1 input GEMMs between the chunks of the forward recurrences)
-  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side2 = nullptr;
+  mutable hipStream_t mainq = nullptr;                    // CU-partition experiment (SEFD_MAIN_CUS): a library-owned, CU-masked stream that carries the main lane
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side2 = nullptr, ev_main = nullptr;
   // host-mapped status word of THIS plan (created on first use: plans are also built on hosts without a GPU).  0 = fine; sticky once set
   // by a kernel that gave up (cluster LSTM hand-over timeout) until sefd_plan_status(clear = 1)
   mutable int* status = nullptr;
@@ -49,6 +51,8 @@ void sefd_plan_destroy(sefd_plan* h) {
   if (!h) return;
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->side2) { (void)hipStreamSynchronize(h->side2); (void)hipStreamDestroy(h->side2); }
+  if (h->mainq) { (void)hipStreamSynchronize(h->mainq); (void)hipStreamDestroy(h->mainq); }
+  if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   if (h->ev_side2) (void)hipEventDestroy(h->ev_side2);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -225,7 +229,7 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   // leaves idle; later lane-1 ops follow at their program position, except the ones marked kOpHold, which wait for the NEXT recurrence
   // launch (FullSubNet).  The main stream waits for the lane at the ops that carry `join` and at every main-stream UNPACK.
   // Partial runs (tests, per-op timing) and SEFD_NO_OVERLAP=1 execute everything in program order on `stream`.
-  const bool no_overlap = getenv("SEFD_NO_OVERLAP") != nullptr;      // read per call: the schedule-equivalence test flips it between two steps
+  const bool no_overlap = tune_str("NO_OVERLAP") != nullptr;      // read per call: the schedule-equivalence test flips it between two steps
   bool two_lane = !no_overlap && first == 0 && last == (int)ops.size();
   if (two_lane) {
     bool any1 = false, any2 = false, lstm = false;
@@ -245,18 +249,42 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     // SEFD_SIDE_CUS=N (tuning): the second lane's stream is confined to N of the chip's CUs, spread evenly over the XCDs
     // (hipExtStreamCreateWithCUMask), so that the weight gradients stop time-slicing every CU with the main lane's 160 KB-LDS GEMMs.  Measured
     // (profiles/r05_tuning_notes.md): no N beats the unmasked stream - the default stays unmasked.
-    const int side_cus = getenv("SEFD_SIDE_CUS") ? atoi(getenv("SEFD_SIDE_CUS")) : 0;
+    // Round 6: BOTH lanes on library-created masked queues.  SEFD_MAIN_CUS=M puts the main lane of a whole-phase run on a second
+    // masked stream with the M CUs the side lane's mask leaves out first (M + N > 256: the two masks overlap on the remaining CUs), forked from / joined
+    // to the caller's stream by events.  Measured: profiles/r06_tuning_notes.md.
+    const int side_cus = tune_str("SIDE_CUS") ? atoi(tune_str("SIDE_CUS")) : 0;
+    const int main_cus = tune_str("MAIN_CUS") ? atoi(tune_str("MAIN_CUS")) : 0;
+    uint32_t smask[8] = {0};
     if (side_cus > 0 && side_cus < 256) {
-      uint32_t mask[8] = {0};
       for (int i = 0; i < 256; ++i)
-        if ((i + 1) * side_cus / 256 > i * side_cus / 256) mask[i >> 5] |= 1u << (i & 31);
-      if (hipExtStreamCreateWithCUMask(&h->side, 8, mask) != hipSuccess) return -3;
+        if ((i + 1) * side_cus / 256 > i * side_cus / 256) smask[i >> 5] |= 1u << (i & 31);
+      if (hipExtStreamCreateWithCUMask(&h->side, 8, smask) != hipSuccess) return -3;
     } else if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return -3;
+    if (main_cus > 0 && main_cus <= 256) {
+      uint32_t mmask[8] = {0};
+      int n = 0;
+      for (int i = 0; i < 256 && n < main_cus; ++i) if (!(smask[i >> 5] >> (i & 31) & 1)) { mmask[i >> 5] |= 1u << (i & 31); ++n; }   // the side lane's complement first
+      for (int i = 0; i < 256 && n < main_cus; ++i) if (!(mmask[i >> 5] >> (i & 31) & 1)) { mmask[i >> 5] |= 1u << (i & 31); ++n; }
+      if (hipExtStreamCreateWithCUMask(&h->mainq, 8, mmask) != hipSuccess) return -3;
+      if (hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess) return -3;
+    }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return -3;
     if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) return -3;
     if (hipEventCreateWithFlags(&h->ev_side2, hipEventDisableTiming) != hipSuccess) return -3;
   }
+  hipStream_t caller = st;
+  const bool use_mainq = h->mainq && phase == 1;          // the backward phase only: the forward's lanes are its LSTM chunks, the main lane needs every CU there
+  if (use_mainq) {                                        // the main lane moves to the masked queue: ordered behind the caller's stream here, joined back below
+    (void)hipEventRecord(h->ev_main, caller);
+    (void)hipStreamWaitEvent(h->mainq, h->ev_main, 0);
+    st = h->mainq;
+  }
+  auto to_caller = [&]() {                                // everything the main lane has been given so far is ordered in front of the caller's next work
+    if (!use_mainq) return;
+    (void)hipEventRecord(h->ev_main, st);
+    (void)hipStreamWaitEvent(caller, h->ev_main, 0);
+  };
   std::vector<int> held;
   bool has_lstm_bwd = false;
   for (const Op& op : ops) has_lstm_bwd |= op.kind == OP_LSTM_BWD;
@@ -299,9 +327,9 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
   };
   // SEFD_HOLD_SKIP=K (tuning): the first K lane-1 ops in front of the first recurrence are NOT held back but issued at their program position
   // (beside the decoder's BatchNorm / dgrad chain); the rest still waits for the recurrence.  Measured: profiles/r05_tuning_notes.md.
-  static const int hold_skip = getenv("SEFD_HOLD_SKIP") ? atoi(getenv("SEFD_HOLD_SKIP")) : 0;
+  static const int hold_skip = tune_str("HOLD_SKIP") ? atoi(tune_str("HOLD_SKIP")) : 0;
   // SEFD_NO_OPHOLD=1 (tuning): lane-1 ops marked kOpHold behind the first recurrence are issued at their program position instead of behind the next recurrence
-  static const bool no_ophold = getenv("SEFD_NO_OPHOLD") && atoi(getenv("SEFD_NO_OPHOLD")) == 1;
+  static const bool no_ophold = tune_str("NO_OPHOLD") && atoi(tune_str("NO_OPHOLD")) == 1;
   int lane1_seen = 0;
   for (int i = first; i < last; ++i) {
     const Op& op = ops[i];
@@ -326,12 +354,13 @@ static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void
     }
     if (op.join == 1 || (op.kind == OP_UNPACK && op.join != kOpNoJoin)) join();   // UNPACK gathers gradient partials: needs the side lane's results
                                                          // (kOpNoJoin: a bucket whose partials all come from the main stream - FullSubNet's full-band model)
-    if (launch_pair(i, st)) { ++i; fork_fresh = false; if (i == at && cb) cb(ctx); continue; }
+    if (launch_pair(i, st)) { ++i; fork_fresh = false; if (i == at && cb) { to_caller(); cb(ctx); } continue; }
     launch(op, st);
     fork_fresh = false;
-    if (i == at && cb) cb(ctx);                          // e.g. the first gradient bucket is complete: the caller starts its all-reduce
+    if (i == at && cb) { to_caller(); cb(ctx); }         // e.g. the first gradient bucket is complete: the caller starts its all-reduce
   }
   join();
+  to_caller();
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -643,4 +672,8 @@ int32_t sefd_adam_step_guarded_dp(float* param, const float* grad, float* exp_av
                      beta1, beta2, eps, grad_scale, skip_if_set, skip_if_nan);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
-}
+}void sefd_tuning_set(const char* knob, const char* value) { if (knob) sefd::tune_set(knob, value); }
+const char* sefd_tuning_get(const char* knob) { return knob ? sefd::tune_str(knob) : nullptr; }
+void sefd_tuning_clear(void) { sefd::tune_clear(); }
+
+

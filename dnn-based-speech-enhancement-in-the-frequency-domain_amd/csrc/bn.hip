@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 namespace sefd {
@@ -265,7 +266,7 @@ static inline int gridcap(int64_t n, int cap = 16384) {
 }
 
 void launch_bn(const Op& op, const ArenaBases& ab, hipStream_t st) {
-  static const int rev = getenv("SEFD_BN_REV") ? atoi(getenv("SEFD_BN_REV")) : 1;   // measured: bn_bwd_reduce 97 -> 80 us, bn_bwd_apply 96 -> 86 us per launch (average)
+  static const int rev = tune_str("BN_REV") ? atoi(tune_str("BN_REV")) : 1;   // measured: bn_bwd_reduce 97 -> 80 us, bn_bwd_apply 96 -> 86 us per launch (average)
   if (op.kind == OP_BN_APPLY) {
     const BnApply& d = op.bna;
     if (d.dt == DT_BF16) hipLaunchKernelGGL((bn_apply_kernel_v<bf16_t>), dim3(gridcap(d.R * d.C / 8)), dim3(256), 0, st, d, ab, rev);

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 namespace sefd {
@@ -485,7 +486,7 @@ bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   } while (0)
 #ifdef SEFD_TUNING
   // wrong-result / experimental arms exist in tuning builds only: the product library has no switch that changes what a launch computes
-  if (g_cgemm256_dbg < 0) g_cgemm256_dbg = getenv("SEFD_CG256_DBG") ? atoi(getenv("SEFD_CG256_DBG")) : 0;
+  if (g_cgemm256_dbg < 0) g_cgemm256_dbg = tune_str("CG256_DBG") ? atoi(tune_str("CG256_DBG")) : 0;
   switch (g_cgemm256_dbg) {
     case 1: SEFD_CG256_LAUNCH(1); return true;
     case 2: SEFD_CG256_LAUNCH(2); return true;

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <unordered_map>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 namespace sefd {
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(const BnBwdApply 
 }
 
 static bool fin_two_level(int nblk, int C, hipStream_t st, FinScratch* fs, dim3* grid) {
-  static const bool on = !(getenv("SEFD_BN_FIN2") && atoi(getenv("SEFD_BN_FIN2")) == 0);
+  static const bool on = !(tune_str("BN_FIN2") && atoi(tune_str("BN_FIN2")) == 0);
   if (!on || nblk < 64 || C > kFinMaxC) return false;
   *fs = fin_scratch(st);
   if (!fs->sums) return false;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 // No implicit mul+add contraction in this file: with it the compiler fused the cell update `f*c + i*g` differently for the two
@@ -335,8 +336,8 @@ static void launch_t(const LstmRec& d, const ArenaBases& ab, hipStream_t st, boo
   dim3 block(64 * (d.H / 16));
   // SEFD_LSTM_RPW = 4 / 16 forces a variant for both directions, SEFD_LSTM_RPW_BWD for the backward alone (read per launch: the per-op test
   // runs both variants in one process)
-  const char* ev = getenv("SEFD_LSTM_RPW");
-  const char* evb = getenv("SEFD_LSTM_RPW_BWD");
+  const char* ev = tune_str("LSTM_RPW");
+  const char* evb = tune_str("LSTM_RPW_BWD");
   const int rpw_env = !fwd && evb ? atoi(evb) : ev ? atoi(ev) : 0;
   const bool spread = rpw_env ? rpw_env == 4 : (int64_t)((d.B + 3) / 4) * d.G <= 1024;      // one cell per lane while the chip has CUs to spare
   if (fwd && spread) hipLaunchKernelGGL((lstm_fwd_bf16_kernel<HMAX, 4>), dim3((d.B + 3) / 4, d.G), block, 2 * 16 * (d.H + 8) * sizeof(uint16_t), st, d, ab);

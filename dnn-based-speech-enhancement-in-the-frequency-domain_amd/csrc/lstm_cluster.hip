@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 #pragma clang fp contract(off)
@@ -468,7 +469,7 @@ __global__ void lstm_mark_kernel(uint4* h, int64_t rows, int T, int H8, int t0, 
 static int pick_mt(const LstmRec& d, int nc) {
   static int ncu = 0;
   if (!ncu) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&p, dev); ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
-  if (const char* e = getenv("SEFD_LSTM_MT")) { const int v = atoi(e); if (v >= 1 && v <= kMaxMT) return v; }   // tuning / test override
+  if (const char* e = tune_str("LSTM_MT")) { const int v = atoi(e); if (v >= 1 && v <= kMaxMT) return v; }   // tuning / test override
   const int64_t nb16 = (d.B + 15) / 16;
   if (nb16 * nc * d.G <= ncu) return 1;
   // measured on FullSubNet's sub-band model (16448 rows, H = 384; ms per training step): MT 1: 187, 2: 156, 3: 158, 8: 183 - two

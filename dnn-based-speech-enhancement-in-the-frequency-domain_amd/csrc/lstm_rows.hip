@@ -23,6 +23,7 @@
 #include <unordered_map>
 #include <utility>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 #pragma clang fp contract(off)
@@ -662,7 +663,7 @@ static void launch_r2(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
     const int up = d.no == 2 ? 2 : (d.seed.arena >= 0 && d.keep < 1.f) ? 1 : 0;
     // more blocks than CUs: (time chunk, row block) jobs (SEFD_ROWS_BWD_CHUNKS, default 5, at least 16 frames each; 1 = whole-sequence workgroups)
     // (an explicit setting applies to any grid: the equivalence test runs it on a few blocks)
-    const int cenv = getenv("SEFD_ROWS_BWD_CHUNKS") ? atoi(getenv("SEFD_ROWS_BWD_CHUNKS")) : (grid > 256 ? 5 : 1);
+    const int cenv = tune_str("ROWS_BWD_CHUNKS") ? atoi(tune_str("ROWS_BWD_CHUNKS")) : (grid > 256 ? 5 : 1);
     const int C = std::max(1, std::min(std::min(cenv, 16), d.T / 16));
     auto go = [&](auto upc) {
       constexpr int UPC = decltype(upc)::value;
@@ -699,7 +700,7 @@ static bool launch_pair2(const LstmRec& d0, const LstmRec& d1, const ArenaBases&
   constexpr int NW = 8;
   const unsigned nblk = (unsigned)((d0.B + 16 * MT - 1) / (16 * MT));
   // time chunks per layer: SEFD_ROWS_PAIR_CHUNKS, default 5, at least 16 frames each
-  const int cenv = getenv("SEFD_ROWS_PAIR_CHUNKS") ? atoi(getenv("SEFD_ROWS_PAIR_CHUNKS")) : 5;
+  const int cenv = tune_str("ROWS_PAIR_CHUNKS") ? atoi(tune_str("ROWS_PAIR_CHUNKS")) : 5;
   const int C = std::max(1, std::min(std::min(cenv, 16), d0.T / 16));
   const size_t words = 1 + (size_t)2 * C * nblk;
   unsigned* sync = pair_sync(st, words);
@@ -716,7 +717,7 @@ static bool launch_pair2(const LstmRec& d0, const LstmRec& d1, const ArenaBases&
 // d0, d1: consecutive OP_LSTM_FWD descriptors of one stream (impl == 1).  True when both were issued as ONE launch; false: launch them one by one.
 bool launch_lstm_rows_pair(const LstmRec& d0, const LstmRec& d1, const ArenaBases& ab, hipStream_t st) {
   // read per call: the equivalence test flips it between two steps of one model
-  if ((getenv("SEFD_ROWS_PAIR") && atoi(getenv("SEFD_ROWS_PAIR")) == 0) || getenv("SEFD_ROWS_FWD")) return false;
+  if ((tune_str("ROWS_PAIR") && atoi(tune_str("ROWS_PAIR")) == 0) || tune_str("ROWS_FWD")) return false;
   const Ptr& below = d0.hd.arena >= 0 ? d0.hd : d0.h;               // what the upper layer reads: h after the fused dropout, or h
   if (d0.impl != 1 || d1.impl != 1 || d0.H != d1.H || d0.B != d1.B || d0.T != d1.T || d0.gxdt != d1.gxdt || d0.hdt != DT_BF16 || d1.hdt != DT_BF16) return false;
   if (d0.xfeat != 32 || d1.xfeat != d1.H || d1.xin.arena != below.arena || d1.xin.off != below.off) return false;
@@ -734,7 +735,7 @@ void launch_lstm_rows(const LstmRec& d, const ArenaBases& ab, hipStream_t st, bo
   // forward, H = 384 (FullSubNet's sub-band model), ms per training step.  Row-major packed weights: 48 rows x 8 waves 110.8, 48 x 4 111.9,
   // 80 rows x 4 waves 102.7.  Fragment-major weights: 88.6 / 88.7 / 89.9 - the geometry stopped mattering (HBM-bound); 48 x 8 is launched,
   // SEFD_ROWS_FWD=54 / 34 select the others.
-  static const int fv = getenv("SEFD_ROWS_FWD") ? atoi(getenv("SEFD_ROWS_FWD")) : 0;
+  static const int fv = tune_str("ROWS_FWD") ? atoi(tune_str("ROWS_FWD")) : 0;
   if (fwd && d.H == 384 && fv == 54 && d.xfeat != 384) { if (d.gxdt == DT_BF16) launch_r2<384, 5, true, 4>(d, ab, st, true); else launch_r2<384, 5, false, 4>(d, ab, st, true); return; }
   switch (d.H) {
     case 256: launch_r<256, 3>(d, ab, st, fwd); break;

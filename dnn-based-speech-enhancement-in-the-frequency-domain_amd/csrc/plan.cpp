@@ -9,6 +9,7 @@
 //     run descriptors: the skip connection is a second source pointer, the LSTM feature order c*D+d is a weight permutation;
 //   * decoder buffers keep the extra frame that `out[..., 1:]` drops, because BatchNorm statistics include it.
 #include "plan.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <array>
@@ -163,7 +164,7 @@ struct Builder {
   // (caller plans the framing GEMM instead) for other transform sizes.
   bool stft_fft(std::vector<Op>& ops, int tag, Ptr src, Ptr spec, int B, int L, int T, int hop, int off, int NFFT,
                 const std::vector<double>& win) {
-    if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM")) return false;
+    if (NFFT != 512 || (int)win.size() > 512 || tune_str("STFT_GEMM")) return false;
     if (fft_tw.arena < 0) {
       std::vector<float> tw(1024);
       for (int k = 0; k < 512; ++k) { tw[2 * k] = (float)std::cos(2.0 * kPi * k / 512.0); tw[2 * k + 1] = (float)std::sin(2.0 * kPi * k / 512.0); }
@@ -178,7 +179,7 @@ struct Builder {
     return true;
   }
   // two frames per transform in the bf16 plans only (stft_fft.hip); SEFD_STFT_PAIR=0 / 1 forces one form (A/B runs)
-  int fft_pair() const { return getenv("SEFD_STFT_PAIR") ? atoi(getenv("SEFD_STFT_PAIR")) != 0 : c.act_dtype == DT_BF16; }
+  int fft_pair() const { return tune_str("STFT_PAIR") ? atoi(tune_str("STFT_PAIR")) != 0 : c.act_dtype == DT_BF16; }
   Ptr fft_tw = Ptr{-1, 0, 0};
   Ptr fft_corr = Ptr{-1, 0, 0};
   // rank-2 correction of the closed-form pinv synthesis basis: cE/cO[part][k] = sum over even/odd j < W of the
@@ -207,7 +208,7 @@ struct Builder {
   }
   // iSTFT synthesis est -> frames as an inverse FFT (istft_fft_kernel); false: plan the synthesis GEMM instead
   bool istft_fft(std::vector<Op>& ops, int tag, Ptr est, Ptr frames, int64_t nframes, int NFFT, const std::vector<double>& win) {
-    if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM")) return false;
+    if (NFFT != 512 || (int)win.size() > 512 || tune_str("STFT_GEMM")) return false;
     if (fft_tw.arena < 0) return false;                      // the STFT helper creates the twiddle table first
     Op& op = push(ops, OP_ISTFT_FFT, tag);
     op.ifft.est = est; op.ifft.frames = frames; op.ifft.tw = fft_tw; op.ifft.win = win512(win); op.ifft.corr = istft_corr((int)win.size());
@@ -216,7 +217,7 @@ struct Builder {
   }
   // its backward: d est = Kinv . (frames of the padded waveform gradient) = the analysis transform with the same correction
   bool istft_bwd_fft(std::vector<Op>& ops, int tag, Ptr dpad, Ptr dest, int B, int Lp, int T, int hop, int NFFT, const std::vector<double>& win) {
-    if (NFFT != 512 || (int)win.size() > 512 || getenv("SEFD_STFT_GEMM") || fft_tw.arena < 0) return false;
+    if (NFFT != 512 || (int)win.size() > 512 || tune_str("STFT_GEMM") || fft_tw.arena < 0) return false;
     Op& op = push(ops, OP_STFT_FFT, tag);
     op.fft.src = dpad; op.fft.spec = dest; op.fft.tw = fft_tw; op.fft.win = win512(win);
     op.fft.B = B; op.fft.L = Lp; op.fft.T = T; op.fft.hop = hop; op.fft.off = 0; op.fft.lp_dt = 0;
@@ -244,23 +245,23 @@ struct Builder {
     int tn = narrow ? wgrad_tn(g.xdt, g.N, g.Npad) : (g.xdt == DT_BF16 && g.Npad >= 128) ? 128 : kWgTN;
     // the layers that carry the FLOPs: 256 x 256 tile of the 8-wave kernel.  SEFD_WG256=0 keeps the 128 x 128 tile; SEFD_WG256_MINM
     // lowers the row threshold (tests run the wide kernel on small cases)
-    const bool wide_on = !(getenv("SEFD_WG256") && atoi(getenv("SEFD_WG256")) == 0);
-    const int64_t wide_minm = getenv("SEFD_WG256_MINM") ? atoll(getenv("SEFD_WG256_MINM")) : 32768;
+    const bool wide_on = !(tune_str("WG256") && atoi(tune_str("WG256")) == 0);
+    const int64_t wide_minm = tune_str("WG256_MINM") ? atoll(tune_str("WG256_MINM")) : 32768;
     int tk = kWgTK;
     if (narrow && wide_on && g.Npad % 256 == 0 && g.ldw >= 384 && g.M >= wide_minm) { tn = 256; tk = 256; g.flags |= kRunWgWide; }
     else if (narrow && wide_on && g.Npad == 128 && g.ldw >= 1024 && g.M >= wide_minm) { tn = 128; tk = 512; g.flags |= kRunWgWide; }
     // wg_rounds > 1 (FullSubNet): that many dispatch rounds of shorter workgroups - the launch shares the chip with a recurrence whose
     // second round leaves 2/3 of the CUs idle, and a workgroup that needs the whole kernel's duration on its CU cannot use such a hole
     // SEFD_WG_ROUNDS / SEFD_WGW_ROUNDS (tuning): rounds of every weight-gradient GEMM / of the wide-tile ones when the model did not set its own
-    const int env_rounds = (g.flags & kRunWgWide) && getenv("SEFD_WGW_ROUNDS") ? atoi(getenv("SEFD_WGW_ROUNDS")) : getenv("SEFD_WG_ROUNDS") ? atoi(getenv("SEFD_WG_ROUNDS")) : 1;
+    const int env_rounds = (g.flags & kRunWgWide) && tune_str("WGW_ROUNDS") ? atoi(tune_str("WGW_ROUNDS")) : tune_str("WG_ROUNDS") ? atoi(tune_str("WG_ROUNDS")) : 1;
     // Wide-tile launches of SHORT workgroups (at most 10 tiles, fewer than 8192 rows per workgroup at 256 slots) fill 224 CUs, not 256: beside them the
     // main stream's 160 KB-LDS GEMMs need whole CUs, and 220 instead of 250 workgroups leave every XCD four - DCCRN default 10.60 -> 10.50 ms per step
     // (slots 160 / 192 / 208 / 216 / 224 / 232 / 240 / 248: 10.59 / 10.55 / 10.53 / 10.50 / 10.50 / 10.61 / 10.61 / 10.59, profiles/r05_tuning_notes.md);
     // DCCRN-large's launches (20 / 40 tiles, or 5 tiles of 19 000-row workgroups) LOSE 0.3-0.7 ms that way and keep 256.  SEFD_WGW_SLOTS overrides.
     const int tiles_w = std::max(1, (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk));
     const bool short_wg = wg_rounds <= 1 && tiles_w <= 10 && (int64_t)g.M * tiles_w < (int64_t)8192 * 256;
-    const int wide_slots = getenv("SEFD_WGW_SLOTS") ? atoi(getenv("SEFD_WGW_SLOTS")) : (short_wg ? 224 : 256);
-    const int nscale = getenv("SEFD_WGN_SCALE") ? atoi(getenv("SEFD_WGN_SCALE")) : 100;      // tuning: percent of the slots of the narrow-tile launches
+    const int wide_slots = tune_str("WGW_SLOTS") ? atoi(tune_str("WGW_SLOTS")) : (short_wg ? 224 : 256);
+    const int nscale = tune_str("WGN_SCALE") ? atoi(tune_str("WGN_SCALE")) : 100;      // tuning: percent of the slots of the narrow-tile launches
     const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : (tn == 128 ? 512 : tn == 64 ? 768 : 1024) * nscale / 100) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
@@ -302,7 +303,7 @@ struct Builder {
   struct SumSeg { int64_t rel, n, ns; };
   std::vector<SumSeg> pending_sums;
   void split_sum(std::vector<Op>& ops, int64_t rel, int64_t n, int64_t ns, int tag) {
-    const bool multi = !(getenv("SEFD_SPLITSUM_MULTI") && atoi(getenv("SEFD_SPLITSUM_MULTI")) == 0);
+    const bool multi = !(tune_str("SPLITSUM_MULTI") && atoi(tune_str("SPLITSUM_MULTI")) == 0);
     if (multi) { pending_sums.push_back(SumSeg{rel, n, ns}); return; }
     Op& os = push(ops, OP_SPLITSUM, tag);
     os.unpack.n = n;
@@ -408,12 +409,12 @@ void finalize_rungemms(Builder& b, Plan* P) {
   // that reads the buffer qualifies, and the PACK table of the matrix is permuted here, once.  SEFD_CG256=0: 128 x 128 kernel
   // everywhere (A/B runs).
   {
-    const bool wide = !(getenv("SEFD_CG256") && atoi(getenv("SEFD_CG256")) == 0);
-    const int wide_minm = getenv("SEFD_CG256_MINM") ? atoi(getenv("SEFD_CG256_MINM")) : 4096;
+    const bool wide = !(tune_str("CG256") && atoi(tune_str("CG256")) == 0);
+    const int wide_minm = tune_str("CG256_MINM") ? atoi(tune_str("CG256_MINM")) : 4096;
     // ... and enough 256 x 256 tiles to occupy the chip: the projection's input gradient (M = B*T = 15 456, N = 256: 61 tiles on 256 CUs) ran
     // 65 us on the wide kernel; as 242 workgroups of the 128-row kernel it fills the chip: 33 us.  Only up to K = 1024: DCCRN-large's few-tile
     // GEMMs have K = 2048 and lost 0.75 ms per step on the 128-row kernel.  (Tests that lower MINM run small cases on purpose.)
-    const int wide_mintiles = getenv("SEFD_CG256_MINTILES") ? atoi(getenv("SEFD_CG256_MINTILES")) : (getenv("SEFD_CG256_MINM") ? 0 : 100);
+    const int wide_mintiles = tune_str("CG256_MINTILES") ? atoi(tune_str("CG256_MINTILES")) : (tune_str("CG256_MINM") ? 0 : 100);
     std::map<int64_t, bool> elig;                            // weight buffer offset -> every reader (either phase) qualifies
     std::vector<Op*> all;
     for (auto* ops : {&P->fwd, &P->bwd})
@@ -445,7 +446,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
         for (Op* op : all) if (op->kind == OP_RUNGEMM && op->g.w.arena == A_WS && op->g.w.off == kv.first) op->g.flags |= kRunWTile32;
     }
   }
-  if (getenv("SEFD_DUMP_GEMMS")) {                          // planner debugging: every GEMM descriptor of the plan on stderr
+  if (tune_str("DUMP_GEMMS")) {                          // planner debugging: every GEMM descriptor of the plan on stderr
     int ph = 0;
     for (auto* ops : {&P->fwd, &P->bwd}) {
       int i = 0;
@@ -484,7 +485,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
   // pass sat in the serial loss section, the forward's in front of the STFT).  The forward packs are issued first and joined by the first
   // op that reads a packed matrix; the backward packs are issued right after that op (one launch of both slowed the STFT / spectrum
   // kernels next to it and delayed the first GEMM by 55 us).  SEFD_PACK_EARLY=0 keeps one launch per phase at its head.
-  if (!(getenv("SEFD_PACK_EARLY") && atoi(getenv("SEFD_PACK_EARLY")) == 0) && !P->fwd.empty() && !P->bwd.empty() &&
+  if (!(tune_str("PACK_EARLY") && atoi(tune_str("PACK_EARLY")) == 0) && !P->fwd.empty() && !P->bwd.empty() &&
       P->fwd[0].kind == OP_PACKMULTI && P->bwd[0].kind == OP_PACKMULTI) {
     P->fwd[0].lane = 2;
     size_t first = 0;
@@ -571,10 +572,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // bf16 mode runs the cluster kernels of lstm_cluster.hip (W_hh spread over H/64 CUs, h handed over in memory every step);
   // fp32 mode and odd sizes fall back to one GEMM + one cell launch per time step on the same buffers.
   const bool cluster_ok = adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0;
-  const bool stepped = (H > 128 && !cluster_ok) || getenv("SEFD_LSTM_STEPPED") != nullptr;
+  const bool stepped = (H > 128 && !cluster_ok) || tune_str("LSTM_STEPPED") != nullptr;
   // all weight gradients ride the second stream (after the fork they run next to the encoder's dgrad / BatchNorm chain and
   // fill the tails of its kernels: 14.42 -> 14.30 ms/step); SEFD_LANE_ALL=0 keeps only the decoder's there
-  const bool lane_all = !(getenv("SEFD_LANE_ALL") != nullptr && atoi(getenv("SEFD_LANE_ALL")) == 0);
+  const bool lane_all = !(tune_str("LANE_ALL") != nullptr && atoi(tune_str("LANE_ALL")) == 0);
   if (H % 16 != 0 || (adt == DT_BF16 && H % 32 != 0)) { P->error = "rnn_units/2 must be a multiple of 16 (32 for bf16)"; return P; }
   if (adt == DT_BF16 && H % 32 != 0) { P->error = "bf16: rnn_units/2 must be a multiple of 32"; return P; }
   if (Fe[n] < 1 || (Fe[0] % (1 << n)) != 0) { P->error = "fft_len/2 must be divisible by 2^n_layers"; return P; }
@@ -738,7 +739,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   const int CP = 8;
   {
     spec_lp = b.ws("xin", (int64_t)B * T * NS * CP, adt);
-    const bool fuse_pad = !(getenv("SEFD_SPECPAD_FUSE") && atoi(getenv("SEFD_SPECPAD_FUSE")) == 0);
+    const bool fuse_pad = !(tune_str("SPECPAD_FUSE") && atoi(tune_str("SPECPAD_FUSE")) == 0);
     if (spec_fft && fuse_pad && NS == 258) {      // the FFT kernel writes the padded copy beside the spectrogram (no SPECPAD pass: 48 us at B = 32)
       F.back().fft.lp = spec_lp; F.back().fft.lp_dt = adt;
     } else {
@@ -900,7 +901,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   // GEMM + recurrence of a chunk, second HIP stream) runs while layer 0 already works on the next chunk - the two 483-step
   // recurrences (8 workgroups each, latency-bound) overlap instead of running back to back.  SEFD_LSTM_CHUNKS=1 disables.
   // Measured (B = 32, T = 483): 1 chunk 14.08 ms/step, 2-6 chunks 13.84-13.94, 8: 13.94, 16: 14.50 -> 4.
-  int nchunk = getenv("SEFD_LSTM_CHUNKS") ? atoi(getenv("SEFD_LSTM_CHUNKS")) : 4;
+  int nchunk = tune_str("LSTM_CHUNKS") ? atoi(tune_str("LSTM_CHUNKS")) : 4;
   if (!(cx && !stepped && adt == DT_BF16 && NL == 2) || nchunk < 2 || T < 8 * nchunk) nchunk = 1;
   const bool pipe = nchunk > 1;
   LstmRec pipe_rec[2];
@@ -923,7 +924,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       o[0] = pe(*bih[set], gq, 1); o[1] = pe(*bhh[set], gq, 1);
     };
     ls[l].bgx = bias;
-    const bool gx_merge = !(getenv("SEFD_GX_MERGE") && atoi(getenv("SEFD_GX_MERGE")) == 0) && BT * 8 * H < (1LL << 31);
+    const bool gx_merge = !(tune_str("GX_MERGE") && atoi(tune_str("GX_MERGE")) == 0) && BT * 8 * H < (1LL << 31);
     for (int p = 0; p < 2; ++p) {
       RunGemm g = Builder::gemm0();
       g.x[0] = lin; g.xdt = adt; g.ydt = DT_F32;
@@ -1027,7 +1028,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       }
       // lane 3 (third stream): the input GEMM of layer 1 for this chunk reads layer 0's chunk only, so it runs BESIDE layer 1's recurrence
       // over the previous chunk instead of queueing behind it on the second stream (round 4 timeline: 657 -> ~520 us for the LSTM block)
-      static const bool lane3 = !(getenv("SEFD_LSTM_LANE3") && atoi(getenv("SEFD_LSTM_LANE3")) == 0);
+      static const bool lane3 = !(tune_str("LSTM_LANE3") && atoi(tune_str("LSTM_LANE3")) == 0);
       b.cur_lane = lane3 ? 3 : 2;
       {
         Op& op = b.push(F, OP_COMBINE_FWD, 200);
@@ -1151,8 +1152,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // contiguous in the channels-last buffer), zero weights where the odd phase has no tap.  These layers are bound by streaming the
     // tap-expanded activation operand through L2 -> LDS, not by MFMAs: 20 % more MACs, the operand streamed once instead of twice.
     // The backward reads only the per-phase coefficient functions.
-    const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 64;
-    const bool merge = Cob <= merge_maxn && !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
+    const int merge_maxn = tune_str("PHASE_MERGE_MAXN") ? atoi(tune_str("PHASE_MERGE_MAXN")) : 64;
+    const bool merge = Cob <= merge_maxn && !(tune_str("WG_SWAP") && atoi(tune_str("WG_SWAP")) == 0);
     for (int par = 0; par < 2; ++par) {
       RunGemm g = Builder::gemm0();
       g.xdt = adt; g.ydt = adt;
@@ -1302,8 +1303,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       if (cfg.skip) d_skip[i] = b.ws("enc" + std::to_string(i) + ".dskip", e, adt);
     }
     constexpr int kCsRows = 2048;                // workgroups of MASK_BWD when it also leaves the mask layer's bias-gradient shares
-    const bool mask_colsum = !(getenv("SEFD_MASK_COLSUM") && atoi(getenv("SEFD_MASK_COLSUM")) == 0) && CP >= 2 && CP <= 8 &&
-                             !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
+    const bool mask_colsum = !(tune_str("MASK_COLSUM") && atoi(tune_str("MASK_COLSUM")) == 0) && CP >= 2 && CP <= 8 &&
+                             !(tune_str("WG_SWAP") && atoi(tune_str("WG_SWAP")) == 0);
     int mask_colsum_op = -1;
     Ptr d_decin = b.ws("decin.d", BT * D * Cl, adt);
     {
@@ -1321,7 +1322,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // GEMMs (N <= 128: latency-bound tiles that stream at ~2 TB/s) 45-85 us per launch - more than the pass, which streams at 4-5 TB/s.
     // So by default only the layers whose producers all run on the wide-tile kernel are fused (bf16, C % 256 == 0).
     // SEFD_BN_FUSE=0: none; SEFD_BN_FUSE=2: every layer (the per-op tests run the epilogue of all three GEMM kernels that way).
-    const int bn_fuse_mode = getenv("SEFD_BN_FUSE") ? atoi(getenv("SEFD_BN_FUSE")) : 1;
+    const int bn_fuse_mode = tune_str("BN_FUSE") ? atoi(tune_str("BN_FUSE")) : 1;
     const bool bn_fuse = bn_fuse_mode != 0 && !cbn;
     auto bn_fuse_layer = [&](int C, int64_t Rr) { return bn_fuse_mode == 2 || (adt == DT_BF16 && C % 256 == 0 && Rr >= 8192); };
     struct BnbAcc { Ptr part; int rows = 0, cap = 0, ldp = 0; bool on = false; Ptr y, mi; std::string pp; };
@@ -1408,7 +1409,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // The bias gradient needs its own pass over dy then (ones run only) - planned for the mask layer; a conv bias in front of
       // BatchNorm has an identically zero gradient (the sum over all rows of the BatchNorm input gradient vanishes), which the reference
       // computes as rounding noise and this plan leaves at exactly 0.
-      const bool wg_swap = !(getenv("SEFD_WG_SWAP") && atoi(getenv("SEFD_WG_SWAP")) == 0);
+      const bool wg_swap = !(tune_str("WG_SWAP") && atoi(tune_str("WG_SWAP")) == 0);
       b.cur_lane = 1;                           // weight gradients of the decoder: nothing downstream needs them before UNPACK
       if (!wg_swap) for (int par = 0; par < 2; ++par) b.wgrad(R, dec[d].f[par], d_decy[d], dec[d].coef[par], 400 + d, &dec[d].bias);
       else if (!last) {                          // conv biases in front of BatchNorm: UNPACK writes their exact zero
@@ -1448,7 +1449,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // Thin layers: ONE GEMM over dy for the input gradients of both sources (previous layer's output | skip connection): the same runs
       // of dy, C0 + C1 output columns, the second half stored to the second destination (RunGemm::y2 / n2).  The A operand - what bounds
       // these layers - is streamed once instead of twice.  Not when a destination's BatchNorm sums ride in the epilogue (one layer per GEMM).
-      const int dg_maxn = getenv("SEFD_DGRAD_MERGE_MAXN") ? atoi(getenv("SEFD_DGRAD_MERGE_MAXN")) : 128;
+      const int dg_maxn = tune_str("DGRAD_MERGE_MAXN") ? atoi(tune_str("DGRAD_MERGE_MAXN")) : 128;
       const bool dg_merge = nsrc == 2 && C0 == C1 && C0 % 8 == 0 && C0 + C1 <= dg_maxn && !(d > 0 && bnb_dec[d - 1].on) && !bnb_enc[idx - 1].on;
       RunGemm dg_g[2];
       Builder::Coef dg_coef[2];
@@ -1705,7 +1706,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // does not feed an output column is zero - writing the whole [D][Cl] row of d_encz contiguously, instead of 2 x D launches of
       // N = Cl / 2 (M = B*T rows only: 8 x 24 us of latency-bound tiles vs one wide-tile launch; twice the MACs, 65 GFLOP).
       const bool dx_merge = l == 0 && adt == DT_BF16 && (D * Cl) % 256 == 0 && (8 * H) % 64 == 0 &&
-                            !(getenv("SEFD_DX_MERGE") && atoi(getenv("SEFD_DX_MERGE")) == 0);
+                            !(tune_str("DX_MERGE") && atoi(tune_str("DX_MERGE")) == 0);
       if (dx_merge) {
         RunGemm g = Builder::gemm0();
         g.xdt = adt; g.ydt = adt;
@@ -1758,10 +1759,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
     // a caller can start their all-reduce while the encoder backward still runs (sefd_plan_grad_bucket / sefd_plan_run_cb).
     // The folds of the decoder + LSTM weight gradients (3/4 of the 1.2 GB of partial sums of a step) go here, on the weight-gradient lane:
     // a bandwidth-bound pass beside the encoder's input-gradient GEMMs instead of in front of the final UNPACK on the main stream.
-    if (!(getenv("SEFD_SPLITSUM_MID") && atoi(getenv("SEFD_SPLITSUM_MID")) == 0)) b.flush_sums(R, 997, true);
+    if (!(tune_str("SPLITSUM_MID") && atoi(tune_str("SPLITSUM_MID")) == 0)) b.flush_sums(R, 997, true);
     // Without an exchange (one bucket) the same early UNPACK rides the weight-gradient lane (tag 997): the gather of 83 % of the parameters
     // leaves the tail of the main stream (79 us for all of them in front of Adam before); SEFD_UNPACK_MID=0 keeps the single UNPACK.
-    const bool unpack_mid = cfg.grad_buckets < 2 && !(getenv("SEFD_UNPACK_MID") && atoi(getenv("SEFD_UNPACK_MID")) == 0);
+    const bool unpack_mid = cfg.grad_buckets < 2 && !(tune_str("UNPACK_MID") && atoi(tune_str("UNPACK_MID")) == 0);
     if (cfg.grad_buckets >= 2 || unpack_mid) {
       const int64_t lo = b.par("decoder.0.0.real_conv.weight").off;
       b.flush_sums(R, 997, unpack_mid);                      // (nothing pending unless SEFD_SPLITSUM_MID=0)
@@ -1779,12 +1780,12 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm, &bnb_enc[i]);
       // the folds of enc5 .. enc1 go in front of the LAST weight gradient on its lane (its input is the last thing the dgrad chain produces,
       // the lane usually waits for it): the fold in front of the final UNPACK then covers one thin layer
-      if (i == 0 && lane_all && n > 1 && !(getenv("SEFD_SPLITSUM_MID") && atoi(getenv("SEFD_SPLITSUM_MID")) == 0)) b.flush_sums(R, 996, true);
+      if (i == 0 && lane_all && n > 1 && !(tune_str("SPLITSUM_MID") && atoi(tune_str("SPLITSUM_MID")) == 0)) b.flush_sums(R, 996, true);
       b.cur_lane = lane_all ? 1 : 0;             // encoder weight gradients next to the dgrad chain
       // Every encoder conv bias sits in front of a training-mode BatchNorm: its gradient is identically zero (the sum over all rows of the
       // BatchNorm input gradient vanishes; the reference computes rounding noise there).  No bias "ones" run in these GEMMs - it cost a
       // whole 64-column K segment (enc0: 192 -> 128 columns, half the K tiles; enc3: 6 -> 5 wide tiles) - UNPACK writes the exact zero.
-      const bool enc_bias_zero = !(getenv("SEFD_ENC_BIAS_ZERO") && atoi(getenv("SEFD_ENC_BIAS_ZERO")) == 0);
+      const bool enc_bias_zero = !(tune_str("ENC_BIAS_ZERO") && atoi(tune_str("ENC_BIAS_ZERO")) == 0);
       if (enc_bias_zero) {
         b.zero_grad.resize(nparam, 0);
         for (const char* part : {".0.real_conv.bias", ".0.imag_conv.bias"}) {
@@ -1798,7 +1799,7 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]
       // thin layers: both phases in one GEMM over the even phase's runs (see the decoder forward), unless this layer's BatchNorm sums
       // ride in the epilogue (their partial rows have one column per channel)
-      const int merge_maxn = getenv("SEFD_PHASE_MERGE_MAXN") ? atoi(getenv("SEFD_PHASE_MERGE_MAXN")) : 64;
+      const int merge_maxn = tune_str("PHASE_MERGE_MAXN") ? atoi(tune_str("PHASE_MERGE_MAXN")) : 64;
       if (Ci <= merge_maxn && !bnb_enc[i - 1].on) {
         RunGemm g = Builder::gemm0();
         g.x[0] = d_ency[i]; g.xdt = adt; g.ydt = adt;
@@ -2564,10 +2565,10 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     const int I = (int)Wih.shape[1];
     // thousands of rows (the sub-band model) in bf16: row-block kernels (lstm_rows.hip) on a packed bf16 copy of W_hh; their gate
     // slabs are bf16 too - at B * 257 rows those layers are bound by the HBM traffic of exactly these slabs (SEFD_LSTM_SLAB32=1: fp32)
-    const int64_t rows_min = getenv("SEFD_LSTM_ROWS_MIN") ? atoll(getenv("SEFD_LSTM_ROWS_MIN")) : 1024;
-    L.cluster = !gru && adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && getenv("SEFD_LSTM_STEPPED") == nullptr;
+    const int64_t rows_min = tune_str("LSTM_ROWS_MIN") ? atoll(tune_str("LSTM_ROWS_MIN")) : 1024;
+    L.cluster = !gru && adt == DT_BF16 && H > 128 && H <= 512 && H % 64 == 0 && tune_str("LSTM_STEPPED") == nullptr;
     L.rowsk = L.cluster && rows >= rows_min && (H == 256 || H == 384 || H == 512);
-    L.sdt = (L.rowsk && getenv("SEFD_LSTM_SLAB32") == nullptr) ? DT_BF16 : DT_F32;
+    L.sdt = (L.rowsk && tune_str("LSTM_SLAB32") == nullptr) ? DT_BF16 : DT_F32;
     L.gates = b.ws(L.nm + ".gates", (int64_t)TP * rows * 4 * H, L.sdt);
     L.c = b.ws(L.nm + ".c", (int64_t)TP * rows * H, DT_F32);
     L.h = b.ws(L.nm + ".h", (int64_t)TP * rows * H, adt);
@@ -2584,7 +2585,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     // k-step per frame) instead of writing and re-reading a [T x rows x 4H] pre-activation slab (8 GB at B = 64); SEFD_LSTM_XFUSE=0 keeps the GEMM
     // ... and the layers above it (input = the layer below's h, H features): H/32 more k-steps per frame instead of an 8 GB slab + a GEMM
     const bool x32 = xlen == 32 && xfeat == 32 && g.ldw == 64, xh = xlen == H && xfeat == H && g.ldw == H;
-    L.xfuse = L.rowsk && (x32 || xh) && g.Npad == 4 * H && !(getenv("SEFD_LSTM_XFUSE") && atoi(getenv("SEFD_LSTM_XFUSE")) == 0);
+    L.xfuse = L.rowsk && (x32 || xh) && g.Npad == 4 * H && !(tune_str("LSTM_XFUSE") && atoi(tune_str("LSTM_XFUSE")) == 0);
     if (L.xfuse) {
       // the packed W_ih re-ordered to MFMA B-fragment order ([4H][64] with K = 32 zero padded: in its first 4H x 32 slots)
       int32_t* tab = nullptr;
@@ -2625,7 +2626,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         r.xin = r.wpk_x = r.bias = b.none();
         if (L.xfuse) { r.xin = x; r.wpk_x = g.w; r.bias = g.bias; r.xfeat = L.xf; }
         r.hd = r.seed = b.none();
-        if (l == 0 && keep < 1.f && !(getenv("SEFD_LSTM_DROPFUSE") && atoi(getenv("SEFD_LSTM_DROPFUSE")) == 0)) {   // dropout applied while h_t is stored
+        if (l == 0 && keep < 1.f && !(tune_str("LSTM_DROPFUSE") && atoi(tune_str("LSTM_DROPFUSE")) == 0)) {   // dropout applied while h_t is stored
           L.hd_fused = b.ws(L.nm + ".hd", (int64_t)TP * rows * H, adt);
           r.hd = L.hd_fused; r.seed = io_seed; r.keep = keep; r.drop_layer = lid;
           L.dropfused = true;
@@ -2730,7 +2731,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
   if (cfg.training) {
     // lane of the weight-gradient GEMMs: 1 = second stream (api.hip: issued behind the first recurrence kernel of the phase, joined in front of
     // the UNPACK); only when the recurrences are single launches (the per-frame GRU / fp32 formulation has no OP_LSTM_BWD to fork at)
-    int wg_lane = (!gru && adt == DT_BF16 && !(getenv("SEFD_FSN_LANES") && atoi(getenv("SEFD_FSN_LANES")) == 0)) ? 1 : 0;
+    int wg_lane = (!gru && adt == DT_BF16 && !(tune_str("FSN_LANES") && atoi(tune_str("FSN_LANES")) == 0)) ? 1 : 0;
     // data parallel (cfg.grad_buckets >= 2): the sub-band model's weight gradients keep the second lane busy for ~12 ms after the main stream
     // is through (profiles/r03_tuning_notes.md section 8) - the full-band model's gradients (the FRONT of the flat arena, 2/3 of it) are
     // therefore produced ON the main stream, folded and unpacked there without waiting for the lane, and their all-reduce (started by the
@@ -2821,7 +2822,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       // input-gradient GEMM and the NEXT layer's recurrence (343 workgroups of 48 sequences on 256 CUs: its second round leaves 2/3 of the chip idle)
       b.cur_lane = wg_lane;
       b.cur_hold = wg_hold;
-      b.wg_rounds = wg_lane ? (getenv("SEFD_FSN_WG_ROUNDS") ? atoi(getenv("SEFD_FSN_WG_ROUNDS")) : 8) : 1;   // 3 -> 8 with the job-scheduled recurrences (r05 notes): 57.1 -> 56.6 ms
+      b.wg_rounds = wg_lane ? (tune_str("FSN_WG_ROUNDS") ? atoi(tune_str("FSN_WG_ROUNDS")) : 8) : 1;   // 3 -> 8 with the job-scheduled recurrences (r05 notes): 57.1 -> 56.6 ms
       RunGemm fw = L.gx;
       fw.ydt = adt;
       if (gru) set_y(fw, dgates, rows, NG * H, 0);        // the GRU's gradient slab is 3H wide (the forward slab keeps a 4th block for W_hn h + b_hn)
@@ -2831,7 +2832,7 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       // over dgates instead of two (the 1536 x 128 launch for W_ih and the bias, 1.6 ms at B = 64, and its pass over the 9.6 GB gate gradients are gone)
       const int xw = fw.nseg == 1 ? (int)rup(fw.seg[0].len, 64) : 0;
       const bool cat = !gru && L.rowsk && fw.nseg == 1 && fw.seg[0].src == 0 && xw == 64 && H % 64 == 0 && rup(xw + H + 64, 256) == rup(H, 256) &&
-                       !(getenv("SEFD_FSN_WGCAT") && atoi(getenv("SEFD_FSN_WGCAT")) == 0);
+                       !(tune_str("FSN_WGCAT") && atoi(tune_str("FSN_WGCAT")) == 0);
       if (cat) {
         RunGemm fc = fw;
         fc.x[1] = L.h; fc.bstride[1] = 0; fc.tstride[1] = (int)(rows * H); fc.base[1] = 0; fc.rowlen[1] = (int)(rows * H); fc.fstride[1] = H; fc.Tin[1] = TP;
@@ -2888,16 +2889,16 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     { Fsn f = fsn0(); f.in = io_gcrm; f.out = d_sbo; b.push(R, OP_FSN_OUT_BWD, 205).fsn = f; }
     // sub-band head: 2 outputs.  With the row-block kernels the [T x rows x H] fp32 gradient of h (4 GB written by a K = 2 GEMM, read back
     // by the recurrence) is never materialised: the kernel computes dh = d_sbo[.., 0] W_fc[0] + d_sbo[.., 1] W_fc[1] as it needs it
-    Ls1.headfuse = Ls1.rowsk && !(getenv("SEFD_LSTM_HEADFUSE") && atoi(getenv("SEFD_LSTM_HEADFUSE")) == 0);
+    Ls1.headfuse = Ls1.rowsk && !(tune_str("LSTM_HEADFUSE") && atoi(tune_str("LSTM_HEADFUSE")) == 0);
     Ptr dh3 = Ls1.headfuse ? b.none() : b.ws("dh3", (int64_t)TP * rs * Hs, DT_F32);       // (not even allocated then: 4.6 GB at B = 64)
     if (Ls1.headfuse) { Ls1.dyo = d_sbo; Ls1.wo = b.pptr("sb_model.fc_output_layer.weight"); }
     fc_backward(fcs, d_sbo, h3, rs, Hs, 2, 2, dh3, 204, "sb_model", Ls1.headfuse);
     // the gradient slab between the two sub-band layers ([T x rows x H]: 4.8 GB in fp32 at B = 64, written by the input-gradient GEMM and read once by
     // the row-block backward of the layer below): bf16 like every other activation gradient of the bf16 plans when nothing but that kernel
     // reads it (the inter-layer dropout fused into it, or no dropout); SEFD_FSN_DH16=0: fp32
-    const bool dh16 = adt == DT_BF16 && Ls1.rowsk && Ls0.rowsk && (Ls0.dropfused || !(keep < 1.f)) && !(getenv("SEFD_FSN_DH16") && atoi(getenv("SEFD_FSN_DH16")) == 0);
+    const bool dh16 = adt == DT_BF16 && Ls1.rowsk && Ls0.rowsk && (Ls0.dropfused || !(keep < 1.f)) && !(tune_str("FSN_DH16") && atoi(tune_str("FSN_DH16")) == 0);
     Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, dh16 ? adt : DT_F32);
-    wg_hold = !(getenv("SEFD_FSN_HOLD") && atoi(getenv("SEFD_FSN_HOLD")) == 0);
+    wg_hold = !(tune_str("FSN_HOLD") && atoi(tune_str("FSN_HOLD")) == 0);
     lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, dh16 ? adt : DT_F32, 203);
     wg_hold = 0;
     if (dh16) Ls0.dhdt = adt;

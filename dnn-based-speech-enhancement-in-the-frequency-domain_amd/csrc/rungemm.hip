@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 namespace sefd {
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
 // ------------------------------------------------------------------------------------------------------------
 // Ring depth of the LDS-DMA pipelines.  SEFD_RG_STAGES / SEFD_WG_STAGES (2..4) override the defaults for tuning runs.
 static int env_stages(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = tune_str(name);
   if (!e) return dflt;
   const int v = atoi(e);
   return v >= 2 && v <= 4 ? v : dflt;
@@ -1110,7 +1111,7 @@ static int env_stages(const char* name, int dflt) {
 // workgroups with a 2-stage ring, so that is the only configuration launched.  SEFD_RG_STAGES keeps the ring depth tunable.
 template <typename TA, int BN>
 static void launch_rungemm_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st, int grid) {
-  static const int stages = env_stages("SEFD_RG_STAGES", 2);
+  static const int stages = env_stages("RG_STAGES", 2);
   if (d.flags & kRunBnBwd) { hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2, kBM, 4, false, true>), dim3(grid), dim3(256), 0, st, d, ab); return; }
   if (stages == 2) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 2>), dim3(grid), dim3(256), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((rungemm_kernel<TA, BN, true, 3>), dim3(grid), dim3(256), 0, st, d, ab);
@@ -1148,8 +1149,8 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 
 // 256 x 256 tile, 8 waves, 4-stage ring of 32 KB = 128 KB: one workgroup per CU (wgrad_tn == 256)
 static void launch_wgrad_wide(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
-  static const int stages = env_stages("SEFD_WG256_STAGES", 2);   // 2, 3 and 4 stages measure the same (+-1 %): 2 x 32 KB leaves LDS to the other stream's kernels
-  static const bool dual = !(getenv("SEFD_WG_DUAL") && atoi(getenv("SEFD_WG_DUAL")) == 0);
+  static const int stages = env_stages("WG256_STAGES", 2);   // 2, 3 and 4 stages measure the same (+-1 %): 2 x 32 KB leaves LDS to the other stream's kernels
+  static const bool dual = !(tune_str("WG_DUAL") && atoi(tune_str("WG_DUAL")) == 0);
   dim3 grid(((d.Npad + 255) / 256) * ((d.ldw + 255) / 256) * d.nsplit);
   if (dual) { hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 4, 256, 512, true>), grid, dim3(512), 0, st, d, ab); return; }
   if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 2, 256, 512>), grid, dim3(512), 0, st, d, ab);
@@ -1160,14 +1161,14 @@ static void launch_wgrad_wide(const RunGemm& d, const ArenaBases& ab, hipStream_
 // 128 x 512 tile for the N = 128 layers (kRunWgWide with Npad == 128): same bytes per MFMA as 256 x 256 would need at N = 256
 static void launch_wgrad_wide128(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   dim3 grid(((d.Npad + 127) / 128) * ((d.ldw + 511) / 512) * d.nsplit);
-  static const bool dual = getenv("SEFD_WG_DUAL") && atoi(getenv("SEFD_WG_DUAL")) == 2;   // measured no gain at N = 128 (783 vs 774 TFLOP/s) for 160 KB of LDS: opt-in
+  static const bool dual = tune_str("WG_DUAL") && atoi(tune_str("WG_DUAL")) == 2;   // measured no gain at N = 128 (783 vs 774 TFLOP/s) for 160 KB of LDS: opt-in
   if (dual) { hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 4, 512, 512, true>), grid, dim3(512), 0, st, d, ab); return; }
   hipLaunchKernelGGL((wgrad_bf16_dma_kernel<128, 2, 512, 512>), grid, dim3(512), 0, st, d, ab);
 }
 
 template <int TN>
 static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
-  static const int stages = env_stages("SEFD_WG_STAGES", 3);   // 3 stages = 48 KiB (128-wide) / 36 KiB: co-resides better with the other stream (13.63 -> 13.24 ms per step vs 4)
+  static const int stages = env_stages("WG_STAGES", 3);   // 3 stages = 48 KiB (128-wide) / 36 KiB: co-resides better with the other stream (13.63 -> 13.24 ms per step vs 4)
   dim3 grid(((d.Npad + TN - 1) / TN) * ((d.ldw + kWgTK - 1) / kWgTK) * d.nsplit);
   if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 2>), grid, dim3(256), 0, st, d, ab);
   else if (stages == 3) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<TN, 3>), grid, dim3(256), 0, st, d, ab);
@@ -1178,7 +1179,7 @@ void launch_wgrad(const RunGemm& d0, const ArenaBases& ab, hipStream_t st) {
   RunGemm d = d0;
 #ifdef SEFD_TUNING
   // wrong-result arm (no partial-sum stores), tuning builds only (-DSEFD_TUNING): the product library has no switch that changes what a launch computes
-  static const int wdbg = getenv("SEFD_WG_DBG") ? atoi(getenv("SEFD_WG_DBG")) : 0;
+  static const int wdbg = tune_str("WG_DBG") ? atoi(tune_str("WG_DBG")) : 0;
   if (wdbg & 8) d.flags |= 1 << 30;
 #endif
   if (d.xdt == DT_BF16 && (d.flags & kRunAligned)) {

@@ -6,6 +6,7 @@
 //   l = l0 + 8 l1:  A[ma] = DFT8_l1(Z) * W64^(l0 ma) ;  X[k0 + 8 ma + 64 mb] = DFT8_l0(A)[mb]
 #include <hip/hip_runtime.h>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include <cstdlib>
 #include "dev_common.h"
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void istft_fft_kernel(const IstftFft d, const 
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st) {
   const int64_t frames = (int64_t)d.B * d.T;
   if (!d.pair) { hipLaunchKernelGGL(stft_fft_single_kernel, dim3((unsigned)((frames + 4 * kStftFPW - 1) / (4 * kStftFPW))), dim3(256), 0, st, d, ab); return; }
-  static const int ppw = getenv("SEFD_STFT_PPW") ? atoi(getenv("SEFD_STFT_PPW")) : 1;
+  static const int ppw = tune_str("STFT_PPW") ? atoi(tune_str("STFT_PPW")) : 1;
   if (ppw == 2) hipLaunchKernelGGL(stft_fft_kernel<2>, dim3((unsigned)((frames + 15) / 16)), dim3(256), 0, st, d, ab);
   else hipLaunchKernelGGL(stft_fft_kernel<1>, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, st, d, ab);
 }

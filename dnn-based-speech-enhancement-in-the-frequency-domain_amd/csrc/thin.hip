@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "sefd_desc.h"
+#include "tuning.h"
 #include "dev_common.h"
 
 namespace sefd {
@@ -242,12 +243,12 @@ __global__ __launch_bounds__(kThinWaves * 64) void rundirect_kernel(const RunGem
 // Chosen by shape: bf16 in / out, LDS-DMA-able (aligned) runs, no accumulate / ReLU, N <= 64 and the packed weights fit LDS next to the
 // staging pieces.  SEFD_DIRECT=0 keeps the tiled kernel (A/B runs); SEFD_DIRECT_MAXK bounds ldw.
 bool launch_rundirect(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
-  static const bool on = !(getenv("SEFD_DIRECT") && atoi(getenv("SEFD_DIRECT")) == 0);
+  static const bool on = !(tune_str("DIRECT") && atoi(tune_str("DIRECT")) == 0);
   // measured (profiles/r03_tuning_notes.md): fragment-shaped loads run at the line rate of the vector memory pipe (32 rows x 32 B per
   // instruction: ~6 TB/s of operand bytes), so the kernel wins only where K is tiny (enc0, the mask layer's input gradient: ldw = 128,
   // 92 -> 64-72 us) and loses from K = 320 on (dec4: 139 -> 255 us); larger K stays on the tiled LDS-DMA kernel
-  static const int maxk = getenv("SEFD_DIRECT_MAXK") ? atoi(getenv("SEFD_DIRECT_MAXK")) : 128;
-  const char* em = getenv("SEFD_DIRECT_MINM");               // read per launch: the per-op test lowers it for one small case
+  static const int maxk = tune_str("DIRECT_MAXK") ? atoi(tune_str("DIRECT_MAXK")) : 128;
+  const char* em = tune_str("DIRECT_MINM");               // read per launch: the per-op test lowers it for one small case
   const int minm = em ? atoi(em) : 65536;
   if (!on || d.xdt != DT_BF16 || d.ydt != DT_BF16 || !(d.flags & kRunAligned) || !(d.flags & kRunYAligned)) return false;
   if ((d.flags & (kRunAccum | kRunRelu | kRunWTile32)) || d.Npad > 64 || d.ldw > maxk || d.M < minm || d.ldw % 8 != 0) return false;

@@ -289,6 +289,7 @@ class _SefdModule(nn.Module):
         # data parallel: plans with two gradient buckets (decoder + LSTM complete before the encoder backward, see ddp.py)
         self._grad_buckets = 2 if (exchange is not None and exchange.active and not sync) else 1
         rt = self._runtime(B, L, inputs.device)
+        rt.plan.tolerate_fault = exchange is not None and exchange.active       # a faulty rank keeps its collectives matched; all ranks raise at the guard check
         optimizer.bind(self)
         self._flat_nbt += 1
         stream = torch.cuda.current_stream().cuda_stream
@@ -379,7 +380,31 @@ class _SefdModule(nn.Module):
                 exchange.all_reduce(self._flat_grad)
             optimizer.grad_scale = exchange.grad_scale
         optimizer.step_flat()
+        if exchange is not None and exchange.active:
+            _dp_guard_tick(self)
         return loss
+
+
+DP_GUARD_EVERY = 16          # data parallel: the all-reduced guard element is looked at on the host every this many steps (one 4-byte read behind a sync)
+
+
+def _check_dp_guard(model):
+    """Data parallel: raises on EVERY rank (the guard element went through the sum all-reduce, so all ranks see the same value at the same step) when
+    a rank's plan gave up or the gradient itself diverged at that element; replicas skipped those updates (sefd_adam_step_guarded_dp)."""
+    guard = getattr(model, "_dp_guard", None)
+    if guard is None or bool(torch.isfinite(guard).all()):
+        return
+    plan = getattr(model, "_status_plan", None)
+    mine = plan is not None and plan.status() != 0
+    raise RuntimeError(("this rank's plan gave up" + plan._RC5) if mine else
+                       "another rank's plan gave up, or the gradient diverged (non-finite guard element of the all-reduced gradient); every replica skipped "
+                       "the update of that step - no rank is left waiting in a collective")
+
+
+def _dp_guard_tick(model):
+    model._dp_steps = getattr(model, "_dp_steps", 0) + 1
+    if model._dp_steps % DP_GUARD_EVERY == 0:
+        _check_dp_guard(model)
 
 
 # ------------------------------------------------------------------------------------------ the models
@@ -474,10 +499,12 @@ class DCCRN(_SefdModule):
         """ConvSTFT 'complex' of a waveform batch in the reference layout: ([B,257,T] real, [B,257,T] imag), no grad."""
         wav = wav.detach().float().contiguous()
         B, L = wav.shape
-        key = ("stft", B, L, str(wav.device))
+        key = ("stft", B, L, str(wav.device), str(self.win_type))
         fe = self._runtimes.get(key)
         if fe is None:
-            plan = Plan(B, L, win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, model="STFT")
+            # the reference forms target / clean spectra with self.stft, i.e. the MODEL's window (models.py:237, 306-308): round 5 built this plan
+            # with the default Hann window whatever win_type was - silently wrong losses for 'hamming' / None (ADVICE r5, goldens dccrn_hamming_direct_mse, _lms)
+            plan = Plan(B, L, win_len=self.win_len, win_inc=self.win_inc, fft_len=self.fft_len, model="STFT", win_type=self.win_type)
             fe = (plan, plan.alloc_arenas(wav.device))
             self._runtimes[key] = fe
         plan, ar = fe
@@ -714,6 +741,7 @@ class FullSubNet(_SefdModule):
         # data parallel: two gradient buckets - the full-band model's range is final while the sub-band weight gradients still run (ddp.py)
         self._grad_buckets = 2 if (exchange is not None and exchange.active) else 1
         plan, ar = self._fsn_runtime(B, T, noisy_mag.device)
+        plan.tolerate_fault = exchange is not None and exchange.active
         optimizer.bind(self)
         stream = torch.cuda.current_stream().cuda_stream
         plan.io(ar, "mag", (B, F, T)).copy_(noisy_mag)
@@ -721,17 +749,19 @@ class FullSubNet(_SefdModule):
         plan.run(PHASE_FWD, ar, stream)
         kind = tfl.LOSS_KINDS[loss_kind or cfg.loss]
         prev_dp = tfl.set_data_parallel(exchange)            # SI-SDR: mean of the row ratios over ALL ranks' rows inside the log
-        if kind == 0:
-            crm = plan.io(ar, "crm", (B, F * T * 2))
-            ws, loss = tfl.loss_forward_raw(0, crm, cirm.view(B, -1), stream)
-            tfl.loss_backward_raw(0, crm, cirm.view(B, -1), ws, None, plan.io(ar, "grad_crm", (B, F * T * 2)), stream)
-        else:
-            # model.loss(cIRM, cRM) (trainer.py:107): in all three the cIRM sits in the kernels' `est` role and the network output in
-            # the `tgt` role (sdr(s1 = cRM, s2 = cIRM), si_snr(s1 = cIRM, s2 = cRM), si_sdr(reference = cRM, estimation = cIRM))
-            crm = plan.io(ar, "crm", (B * F * T, 2))
-            ws, loss = tfl.loss_rows_forward_raw(kind, cirm.view(-1, 2), crm, stream)
-            tfl.loss_rows_backward_raw(kind, cirm.view(-1, 2), crm, ws, None, None, plan.io(ar, "grad_crm", (B * F * T, 2)), stream)
-        tfl.set_data_parallel(prev_dp)
+        try:
+            if kind == 0:
+                crm = plan.io(ar, "crm", (B, F * T * 2))
+                ws, loss = tfl.loss_forward_raw(0, crm, cirm.view(B, -1), stream)
+                tfl.loss_backward_raw(0, crm, cirm.view(B, -1), ws, None, plan.io(ar, "grad_crm", (B, F * T * 2)), stream)
+            else:
+                # model.loss(cIRM, cRM) (trainer.py:107): in all three the cIRM sits in the kernels' `est` role and the network output in
+                # the `tgt` role (sdr(s1 = cRM, s2 = cIRM), si_snr(s1 = cIRM, s2 = cRM), si_sdr(reference = cRM, estimation = cIRM))
+                crm = plan.io(ar, "crm", (B * F * T, 2))
+                ws, loss = tfl.loss_rows_forward_raw(kind, cirm.view(-1, 2), crm, stream)
+                tfl.loss_rows_backward_raw(kind, cirm.view(-1, 2), crm, ws, None, None, plan.io(ar, "grad_crm", (B * F * T, 2)), stream)
+        finally:
+            tfl.set_data_parallel(prev_dp)                   # an exception in the loss kernels must not leave the exchange set for a later validation loss
         bucket = plan.grad_bucket_range() if self._grad_buckets == 2 else None
         if bucket is not None:
             op, lo, hi = bucket
@@ -750,4 +780,6 @@ class FullSubNet(_SefdModule):
                 exchange.all_reduce(self._flat_grad)
             optimizer.grad_scale = exchange.grad_scale
         optimizer.step_flat()
+        if exchange is not None and exchange.active:
+            _dp_guard_tick(self)
         return loss

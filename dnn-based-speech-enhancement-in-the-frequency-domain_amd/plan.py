@@ -183,6 +183,10 @@ class Plan:
 
     # ---- per-plan status word (a kernel that had to give up - the cluster LSTM's bounded hand-over waits - sets it)
     owner = None                 # weakref to the model this plan belongs to: running the plan makes it the model's `_status_plan`
+    # Data parallel (set by train_step under an active exchange): a plan whose status word is set does NOT raise from run / run_cb - the rank keeps
+    # taking part in every collective of the step (its poisoned gradient element makes all replicas skip the update) and ALL ranks raise together at the
+    # next guard check (models._check_dp_guard).  Raising here, on one rank, mid-epoch, left the others blocked in their next all-reduce.
+    tolerate_fault = False
 
     def _mark(self):
         o = self.owner() if self.owner is not None else None
@@ -224,7 +228,7 @@ class Plan:
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _ctx: fn()) if fn is not None else None
         rc = self.lib.sefd_plan_run_flags(self.h, phase, ptrs, C.c_void_p(stream), flags, at if fn is not None else -1, cb, None)
-        if rc != 0:
+        if rc != 0 and not (rc == -5 and self.tolerate_fault):
             raise RuntimeError(f"sefd_plan_run_cb failed ({rc})" + (self._RC5 if rc == -5 else ""))
 
     def run_timed(self, phase, arenas, stream=0):
@@ -241,5 +245,5 @@ class Plan:
         self._mark()
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         rc = self.lib.sefd_plan_run(self.h, phase, first, last, ptrs, C.c_void_p(stream))
-        if rc != 0:
+        if rc != 0 and not (rc == -5 and self.tolerate_fault):
             raise RuntimeError(f"sefd_plan_run failed ({rc})" + (self._RC5 if rc == -5 else ""))

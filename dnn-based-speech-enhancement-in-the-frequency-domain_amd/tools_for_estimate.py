@@ -21,8 +21,12 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in SRCS + HDRS):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB_PATH] + SRCS, check=True)
+    from . import build as _b
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB_PATH] + SRCS
+    digest = _b.source_digest(SRCS + HDRS, " ".join(cmd[:-len(SRCS)]))        # contents, not mtimes (build.source_digest)
+    if force or not _b.stamp_current(LIB_PATH, digest):
+        subprocess.run(cmd, check=True)
+        _b.write_stamp(LIB_PATH, digest)
     return LIB_PATH
 
 

@@ -63,9 +63,9 @@ def check_step_status(model):
     if plan.status() != 0:
         raise RuntimeError("checkpoint not written" + plan._RC5)
     guard = getattr(model, "_dp_guard", None)
-    if guard is not None and bool(torch.isnan(guard).any()):
+    if guard is not None and not bool(torch.isfinite(guard).all()):
         raise RuntimeError("checkpoint not written: another rank's plan gave up during the last step (its status word reached this rank "
-                           "through the gradient all-reduce); every replica skipped that update")
+                           "through the gradient all-reduce), or the gradient diverged at the guard element; every replica skipped that update")
 
 
 def load_checkpoint(path, model, optimizer, map_location=None):

@@ -203,6 +203,16 @@ int32_t sefd_adam_step_guarded_dp(float* param, const float* grad, float* exp_av
 int32_t sefd_plan_status(const sefd_plan* p, int32_t clear);
 int32_t sefd_plan_status_set(const sefd_plan* p);
 
+/* ---- tuning table ------------------------------------------------------------------------------------
+ * The planner's and the launchers' tuning knobs (tile thresholds, ring depths, lane placement, ...: INTEGRATION.md section 6) live in ONE process-wide
+ * table, not in the environment: a plan is a function of its sefd_model_config and of this table at the moment sefd_plan_create runs.  The table is
+ * filled once from the single environment variable SEFD_TUNING="KNOB=value,KNOB=value" (read the first time the table is consulted) and by these
+ * calls.  value NULL unsets a knob; sefd_tuning_get returns NULL for a knob that is not set (then the built-in default applies).  The reference has
+ * no counterpart (its behaviour is fixed by config.py); nothing here changes results beyond floating-point summation order. */
+void sefd_tuning_set(const char* knob, const char* value);
+const char* sefd_tuning_get(const char* knob);
+void sefd_tuning_clear(void);
+
 #ifdef __cplusplus
 }
 #endif

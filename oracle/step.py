@@ -29,7 +29,7 @@ def dccrn_loss(cfg: DCCRNConfig, loss_kind, perceptual, outputs, targets):
         return main
     if perceptual == "LMS":
         nfreq = cfg.fft_len // 2 + 1
-        cs = conv_stft(targets, cfg.win_len, cfg.win_inc, cfg.fft_len)
+        cs = conv_stft(targets, cfg.win_len, cfg.win_inc, cfg.fft_len, cfg.win_type)      # self.stft(target): the MODEL's window (models.py:306-308)
         clean_mags = torch.sqrt(cs[:, :nfreq] ** 2 + cs[:, nfreq:] ** 2 + 1e-7)
         est_mags = torch.sqrt(o_r ** 2 + o_i ** 2 + 1e-7)
         return (main + lms_loss(clean_mags, est_mags)) / 2

@@ -137,7 +137,7 @@ def dccrn_case(cfg, models, name, kernel_num, rnn_units, mask, loss, perceptual,
     print(f"dccrn_{name}: loss {float(lossv):.6f} |wav|max {float(wav.abs().max()):.4f}")
 
 
-def dccrn_direct_case(cfg, models, name, kernel_num, rnn_units, loss, B, L):
+def dccrn_direct_case(cfg, models, name, kernel_num, rnn_units, loss, B, L, win_type="hann"):
     """dccrn_direct_train (trainer.py:121-150): spectral mapping, loss = (loss(real) + loss(imag)) / 2."""
     cfg.dccrn_kernel_num = list(kernel_num)
     cfg.masking_mode = "Direct(None make)"
@@ -145,7 +145,7 @@ def dccrn_direct_case(cfg, models, name, kernel_num, rnn_units, loss, B, L):
     cfg.perceptual = False
     cfg.lstm = "complex"
     cfg.skip_type = True
-    m = models.DCCRN(rnn_units=rnn_units, masking_mode="Direct(None make)")
+    m = models.DCCRN(rnn_units=rnn_units, masking_mode="Direct(None make)", win_type=win_type)
     fill_state_dict_(m)
     m.train()
     x, y = test_signals(B, L)
@@ -375,6 +375,10 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "hamming":       # ConvSTFT(win_type='hamming'): any scipy.signal.get_window name (tools_for_model.py:19-20)
         dccrn_case(cfg, models, "hamming_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False, 2, 4000, store_taps=False, win_type="hamming")
+        # ... and the two paths where the TARGET spectrum comes from the model's own ConvSTFT (models.py:237, 306-308): spectral mapping and the LMS joint loss
+        dccrn_direct_case(cfg, models, "hamming_direct_mse", (16, 32, 32, 64, 64, 64), 128, "MSE", 2, 4000, win_type="hamming")
+        dccrn_case(cfg, models, "hamming_E_sisnr_lms", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", "LMS", 2, 4000, store_taps=False, win_type="hamming")
+        cfg.perceptual = False
         return
     if len(sys.argv) > 1 and sys.argv[1] == "rectwin":       # ConvSTFT(win_type=None): rectangular window (tools_for_model.py:17-18)
         dccrn_case(cfg, models, "rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False, 2, 4000, store_taps=False, win_type=None)

@@ -15,12 +15,28 @@ SIM_SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
 SIM_LIB = os.path.join(HERE, "hostsim", "_build", "libhostsim.so")
 
 
-def ensure_built():
-    sefd_build.build()
+SIM_CMD = ["g++", "-O3", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-o", SIM_LIB, SIM_SRC]
+
+
+def build_sim(force=False):
     desc = os.path.join(sefd_build.CSRC, "sefd_desc.h")
-    if (not os.path.exists(SIM_LIB) or os.path.getmtime(SIM_LIB) < max(os.path.getmtime(SIM_SRC), os.path.getmtime(desc))):
+    digest = sefd_build.source_digest([SIM_SRC, desc], " ".join(SIM_CMD[:-2]))      # contents, not mtimes (build.source_digest)
+    if force or not sefd_build.stamp_current(SIM_LIB, digest):
         os.makedirs(os.path.dirname(SIM_LIB), exist_ok=True)
-        subprocess.run(["g++", "-O3", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-o", SIM_LIB, SIM_SRC], check=True)
+        subprocess.run(SIM_CMD, check=True)
+        sefd_build.write_stamp(SIM_LIB, digest)
+
+
+_built = False
+
+
+def ensure_built():
+    global _built
+    if _built:                               # once per process: the digests read every source file
+        return
+    sefd_build.build()
+    build_sim()
+    _built = True
 
 
 _sim = None

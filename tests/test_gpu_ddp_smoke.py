@@ -120,3 +120,87 @@ def test_sisdr_loss_kernels_sharded_over_two_ranks_equal_global_batch():
         for tag in ("wave", "rows"):
             el, eg = res[rank][tag]
             assert el < 1e-5 and eg < 1e-4, (rank, tag, el, eg)
+
+
+def _fault_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.ddp import GradientExchange
+    from sefd_amd.optim import Adam
+    from oracle.weights import fill_state_dict_, test_signals
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg.dccrn_kernel_num, cfg.masking_mode, cfg.loss, cfg.act_dtype = [16, 32, 32, 64, 64, 64], "E", "SI-SNR", "fp32"
+        m = models.DCCRN(rnn_units=128, masking_mode="E")
+        fill_state_dict_(m)
+        m = m.to("cuda").train()
+        ex = GradientExchange()
+        opt = Adam(m.parameters(), lr=1e-3)
+        x, y = test_signals(4, 4000)
+        x, y = x[rank * 2:rank * 2 + 2].cuda(), y[rank * 2:rank * 2 + 2].cuda()
+        models.DP_GUARD_EVERY = 3                      # look at the all-reduced guard element every third step
+        raised_at, msg, before = None, "", None
+        for step in range(1, 8):
+            if step == 2 and rank == 1:
+                torch.cuda.synchronize()
+                m._status_plan.status_set()            # a kernel of THIS rank's plan "gives up" in the middle of the epoch
+            if step == 2:
+                torch.cuda.synchronize()
+                before = m._flat_param.clone()
+            try:
+                m.train_step(x, y, opt, exchange=ex)
+            except RuntimeError as e:
+                raised_at, msg = step, str(e)
+                break
+        torch.cuda.synchronize()
+        q.put((rank, raised_at, msg, bool(torch.equal(m._flat_param, before))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plan_fault_in_the_middle_of_an_epoch_stops_every_rank_at_the_same_step():
+    """the status word is sticky and sefd_plan_run returns -5 while it is set.  Raising from the faulty rank's NEXT train_step left
+    the healthy ranks blocked in their next all-reduce.  Now the faulty rank keeps its collectives matched (its poisoned gradient element makes every
+    replica skip the updates) and ALL ranks raise together at the next guard check.  Two gloo ranks on the box's GPU; rank 1's word is set before step 2;
+    the guard is looked at every third step: both ranks raise IN step 3, nobody hangs, and no parameter moved after step 1."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fault_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "a rank hung or died"
+    res = {r: (at, msg, same) for r, at, msg, same in (q.get(timeout=5) for _ in range(2))}
+    assert res[0][0] == 3 and res[1][0] == 3, res
+    assert "another rank" in res[0][1] and "this rank's plan gave up" in res[1][1], res
+    assert res[0][2] and res[1][2], "an update was applied after the fault"
+
+
+def test_rccl_two_ranks_when_the_box_has_two_gpus():
+    """the first box with more than one GPU validates itself - plain `python bench.py --gpus 2` over RCCL (bench.py launches its
+    ranks), two ranks, two buckets, and the final loss of the same seed equals the two-rank gloo run (the collectives differ, the arithmetic does not).
+    Skipped on the one-GPU boxes of the builder's pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SEFD_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and len(d["config"]["per_rank_ms"]) == 2 and d["config"]["collective"].startswith("RCCL world 2")
+    r2 = subprocess.run(cmd, cwd=ROOT, env=dict(env, SEFD_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    d2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert abs(d["final_loss"] - d2["final_loss"]) < 2e-3 * max(1.0, abs(d2["final_loss"])), (d["final_loss"], d2["final_loss"])

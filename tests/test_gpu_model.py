@@ -8,7 +8,7 @@ import torch
 from oracle.dccrn import DCCRNConfig, dccrn_state_shapes, is_trainable
 from oracle.step import dccrn_train_step
 from oracle.weights import fill_state_dict_, formula_state_dict, test_signals as make_signals
-from util import load_golden, rel_err, rel_l2, sub
+from util import knobs, load_golden, rel_err, rel_l2, sub
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -327,11 +327,13 @@ def test_lms_loss_kernel_vs_oracle():
     assert rel_l2(emd.grad.cpu(), em2.grad) < TOL
 
 
-def test_dccrn_lms_joint_step_against_reference_golden():
-    """model_perceptual_train (trainer.py:45-82): loss = (SI-SNR + LMS) / 2, forward called without targets."""
-    g = load_golden("dccrn_small_E_sisnr_lms")
+@pytest.mark.parametrize("name,win", [("small_E_sisnr_lms", "hanning"), ("hamming_E_sisnr_lms", "hamming")])
+def test_dccrn_lms_joint_step_against_reference_golden(name, win):
+    """model_perceptual_train (trainer.py:45-82): loss = (SI-SNR + LMS) / 2, forward called without targets.  The clean spectrum is self.stft(target):
+    the MODEL's window (round 5 took Hann whatever win_type was)."""
+    g = load_golden("dccrn_" + name)
     from sefd_amd import config as cfg
-    m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR")
+    m = make_model((16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", win_type=win)
     cfg.perceptual = "LMS"
     try:
         m.train()
@@ -445,10 +447,12 @@ def test_fullsubnet_fused_train_step_and_dropout():
     assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0]
 
 
-def test_dccrn_direct_mode_against_reference_golden():
-    """masking_mode 'Direct(None make)' + dccrn_direct_train's loss (trainer.py:135-138) on spectra [B, 257, T] (T = 43: unaligned rows)."""
-    g = load_golden("dccrn_small_direct_mse")
-    m = make_model((16, 32, 32, 64, 64, 64), 128, "Direct(None make)", "MSE")
+@pytest.mark.parametrize("name,win", [("small_direct_mse", "hanning"), ("hamming_direct_mse", "hamming")])
+def test_dccrn_direct_mode_against_reference_golden(name, win):
+    """masking_mode 'Direct(None make)' + dccrn_direct_train's loss (trainer.py:135-138) on spectra [B, 257, T] (T = 43: unaligned rows); the target
+    spectra come from the model's own ConvSTFT, window included."""
+    g = load_golden("dccrn_" + name)
+    m = make_model((16, 32, 32, 64, 64, 64), 128, "Direct(None make)", "MSE", win_type=win)
     m.train()
     x, y = make_signals(2, 4000)
     o_r, t_r, o_i, t_i, wav = m(x.cuda(), y.cuda())
@@ -561,6 +565,34 @@ def test_bf16_dccrn_step_against_reference_golden(name, kn, ru, mask, loss):
     assert rec["grad_cosine"] > BF16_GRAD_COS and rec["grad_norm_ratio_worst"] < BF16_GRAD_WORST, rec
 
 
+def test_bf16_prelu_slope_gradient_error_is_noise_that_averages_out():
+    """the bf16 plan's PReLU-slope gradients are far off the fp32 goldens at B = 2 (0.6-0.9 relative: every term of a slope's sum carries
+    the 2^-9 rounding of the stored y and dz, the sum is ~100x smaller than its terms).  The claim that this is zero-mean NOISE - not a bias of the kernels -
+    is checked here: against the model's OWN fp32 plan on the same inputs the error must fall as the number of summed elements grows
+    (B = 2 -> 8 -> 32 at L = 16 000: 16x the elements, ~1/4 of the error expected from independent roundings) and be small at B = 32.
+    Measure: rms over the 11 slope scalars of |g_bf16 - g_fp32| / |g_fp32|."""
+    kn, ru = (32, 64, 128, 256, 256, 256), 256
+    res = {}
+    for B in (2, 8, 32):
+        x, y = make_signals(B, 16000)
+        x, y = x.cuda(), y.cuda()
+        grads = {}
+        for dt in ("fp32", "bf16"):
+            m = make_model(kn, ru, "E", "SI-SNR", dtype=dt)
+            m.train()
+            _, _, wav = m(x, y)
+            m.loss(wav, y).backward()
+            grads[dt] = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters() if k.endswith(".2.weight")}
+            del m
+            torch.cuda.empty_cache()
+        rel = {k: float((grads["bf16"][k] - v).abs().sum() / v.abs().sum()) for k, v in grads["fp32"].items()}
+        res[B] = dict(rms=float(np.sqrt(np.mean([e * e for e in rel.values()]))), worst=max(rel.values()), worst_name=max(rel, key=rel.get), per_slope=rel)
+    _bf16_record("prelu_slope_vs_own_fp32_plan", {str(b): r for b, r in res.items()})
+    assert len(res[2]["per_slope"]) >= 10
+    assert res[32]["rms"] <= 0.2 and res[32]["worst"] <= 0.35, res
+    assert res[32]["rms"] <= 0.5 * res[2]["rms"] and res[8]["rms"] <= 0.85 * res[2]["rms"], res          # ~1/sqrt(elements): 1/4 and 1/2 expected
+
+
 def test_bf16_full_length_clip_against_reference_golden():
     g = load_golden("dccrn_default_C_sisnr_full")
     m = make_model((32, 64, 128, 256, 256, 256), 256, "C", "SI-SNR", dtype="bf16")
@@ -607,13 +639,13 @@ def test_bf16_crn_step_against_reference_golden():
 
 @pytest.mark.parametrize("row_block", [False, True])
 def test_bf16_fullsubnet_step_against_reference_golden(row_block, monkeypatch):
-    """row_block=True: the planner's row threshold is lowered (SEFD_LSTM_ROWS_MIN=64; the golden has B = 2 -> 514 sub-band rows, the bench
+    """row_block=True: the planner's row threshold is lowered (knob LSTM_ROWS_MIN=64; the golden has B = 2 -> 514 sub-band rows, the bench
     B = 64 -> 16 448) so that the sub-band model runs on the row-block kernels of lstm_rows.hip - fused input projections, bf16 gate slabs,
     the 2-output head's gradient formed in the backward kernel - i.e. the kernels the FullSubNet bench line times, against the reference."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models, tools_for_model as tools
     if row_block:
-        monkeypatch.setenv("SEFD_LSTM_ROWS_MIN", "64")
+        knobs.set("LSTM_ROWS_MIN", "64")
     g = load_golden("fsn_default_mse")
     B, L = int(g["g/meta/B"]), int(g["g/meta/L"])
     cfg.loss, cfg.act_dtype = "MSE", "bf16"
@@ -735,11 +767,11 @@ def test_bf16_dccrn_perceptual_at_bench_size(perceptual):
 def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     """Every kernel is deterministic, so the gradients of one fused step must be BIT-identical whether the phase runs in its two-lane schedule
     (weight gradients, folds, early UNPACK, chunked LSTM forward on the second stream; FullSubNet: held weight gradients) or in program order on
-    one stream (SEFD_NO_OVERLAP=1).  A missing dependency between the lanes shows up here as a mismatch.  Sizes large enough that kernels of the
+    one stream (knob NO_OVERLAP=1).  A missing dependency between the lanes shows up here as a mismatch.  Sizes large enough that kernels of the
     two streams really overlap (DCCRN B = 8 x 3 s, FullSubNet B = 16 x 3 s); lr = 0 keeps the parameters of the two runs equal.
     (Round 3: this test is what exposed the run-to-run differences of FullSubNet's row-block forward recurrence - lstm_rows.hip, note above
     mfma_settle - which had nothing to do with the lanes: two runs of the SAME schedule differed.)
-    "fullsubnet_hoisted" (SEFD_LSTM_XFUSE=0): the row-block forward kernel WITHOUT the fused input projection (XF = 0: pre-activations of the
+    "fullsubnet_hoisted" (knob LSTM_XFUSE=0): the row-block forward kernel WITHOUT the fused input projection (XF = 0: pre-activations of the
     hoisted GEMM ride in the accumulators' initial value) and the row-block backward kernels behind it - run-to-run bit-reproducibility of the
     variant the default configuration does not launch."""
     import sefd_amd  # noqa: F401
@@ -752,7 +784,7 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     else:
         cfg.loss, cfg.act_dtype = "MSE", "bf16"
         if which == "fullsubnet_hoisted":
-            monkeypatch.setenv("SEFD_LSTM_XFUSE", "0")     # read when the plan is built (first step below)
+            knobs.set("LSTM_XFUSE", "0")     # read when the plan is built (first step below)
         try:
             torch.manual_seed(0)
             m = models.FullSubNet().to("cuda").train()
@@ -764,16 +796,16 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     grads, losses = [], []
     for rep, single in enumerate((False, True, False)):
         if single:
-            monkeypatch.setenv("SEFD_NO_OVERLAP", "1")
+            knobs.set("NO_OVERLAP", "1")
         else:
-            monkeypatch.delenv("SEFD_NO_OVERLAP", raising=False)
+            knobs.unset("NO_OVERLAP")
         if which == "fullsubnet" and rep > 0:              # same dropout masks: the step counter behind the mask hash goes back by one
             plan, ar = next(v for k, v in m._runtimes.items() if k[0] == "fsn")
             plan.view(ar, "io.seed").view(torch.int32)[:1].sub_(1)
         losses.append(float(m.train_step(x, y, opt)))
         torch.cuda.synchronize()
         grads.append(m._flat_grad.clone())
-    monkeypatch.delenv("SEFD_NO_OVERLAP", raising=False)
+    knobs.unset("NO_OVERLAP")
     assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
     assert losses[0] == losses[1] == losses[2], losses
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
@@ -784,8 +816,8 @@ def test_paired_subband_layers_equal_two_launches(monkeypatch):
     """FullSubNet's two sub-band LSTM layers run as ONE launch of (layer, time chunk, row block) jobs (lstm_rows.hip lstm_fwd_rows_pair_kernel: a
     job starts behind the flags of the jobs it reads from, on whatever CU is free), and the backward recurrences as (time chunk, row block) jobs
     that hand the recurrent gradient and the cell-state carry through memory (lstm_bwd_rows_jobs_kernel) - schedules, not different computations:
-    loss and gradients of a fused step are BIT-identical to whole-sequence workgroups in one launch per layer (SEFD_ROWS_PAIR=0,
-    SEFD_ROWS_BWD_CHUNKS=1).  B = 16: 4 112 rows = 86 blocks per layer, every job resident at once, so the waits are real; the bench size
+    loss and gradients of a fused step are BIT-identical to whole-sequence workgroups in one launch per layer (knob ROWS_PAIR=0,
+    knob ROWS_BWD_CHUNKS=1).  B = 16: 4 112 rows = 86 blocks per layer, every job resident at once, so the waits are real; the bench size
     (B = 64: 343 blocks on 256 CUs) is the many-rounds case."""
     import sefd_amd  # noqa: F401
     from sefd_amd import config as cfg, models
@@ -802,22 +834,22 @@ def test_paired_subband_layers_equal_two_launches(monkeypatch):
         grads, losses = [], []
         for rep, pair in enumerate((True, False, True)):
             if pair:
-                monkeypatch.delenv("SEFD_ROWS_PAIR", raising=False)
+                knobs.unset("ROWS_PAIR")
                 if B == 16:
-                    monkeypatch.setenv("SEFD_ROWS_BWD_CHUNKS", "3")     # B = 64 (343 blocks > 256 CUs) chunks the backward by default
+                    knobs.set("ROWS_BWD_CHUNKS", "3")     # B = 64 (343 blocks > 256 CUs) chunks the backward by default
                 else:
-                    monkeypatch.delenv("SEFD_ROWS_BWD_CHUNKS", raising=False)
+                    knobs.unset("ROWS_BWD_CHUNKS")
             else:
-                monkeypatch.setenv("SEFD_ROWS_PAIR", "0")
-                monkeypatch.setenv("SEFD_ROWS_BWD_CHUNKS", "1")
+                knobs.set("ROWS_PAIR", "0")
+                knobs.set("ROWS_BWD_CHUNKS", "1")
             if rep > 0:                                        # same dropout masks: the step counter behind the mask hash goes back by one
                 plan, ar = next(v for k, v in m._runtimes.items() if k[0] == "fsn" and k[1] == B)
                 plan.view(ar, "io.seed").view(torch.int32)[:1].sub_(1)
             losses.append(float(m.train_step(x, y, opt)))
             torch.cuda.synchronize()
             grads.append(m._flat_grad.clone())
-        monkeypatch.delenv("SEFD_ROWS_PAIR", raising=False)
-        monkeypatch.delenv("SEFD_ROWS_BWD_CHUNKS", raising=False)
+        knobs.unset("ROWS_PAIR")
+        knobs.unset("ROWS_BWD_CHUNKS")
         assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
         assert losses[0] == losses[1] == losses[2], (B, losses)
         assert torch.equal(grads[0], grads[1]), (B, float((grads[0] - grads[1]).abs().max()))

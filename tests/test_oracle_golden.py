@@ -97,6 +97,7 @@ CASES = [
     ("cbn_E_sisnr", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", False),          # DCCRN(use_cbn=True): ComplexBatchNorm
     ("rectwin_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False),      # win_type=None: rectangular window
     ("hamming_C_sisnr", (16, 32, 32, 64, 64, 64), 128, "C", "SI-SNR", False),      # win_type='hamming': a scipy.signal.get_window name (tools_for_model.py:19-20)
+    ("hamming_E_sisnr_lms", (16, 32, 32, 64, 64, 64), 128, "E", "SI-SNR", "LMS"),   # ... with the LMS joint loss: the clean spectrum comes from the model's own (Hamming) ConvSTFT
 ]
 
 
@@ -182,10 +183,11 @@ def test_dccrn_full_length_forward():
     assert abs(float(-ol.si_snr(wav, y)) - float(g["g/loss"])) < 1e-4
 
 
-def test_dccrn_direct_mode_against_reference():
-    """Spectral mapping ('Direct(None make)', models.py:232-250) + dccrn_direct_train loss (trainer.py:135-138)."""
-    g = load_golden("dccrn_small_direct_mse")
-    cfg = DCCRNConfig(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128, masking_mode="Direct(None make)")
+@pytest.mark.parametrize("name,win", [("small_direct_mse", "hanning"), ("hamming_direct_mse", "hamming")])
+def test_dccrn_direct_mode_against_reference(name, win):
+    """Spectral mapping ('Direct(None make)', models.py:232-250) + dccrn_direct_train loss (trainer.py:135-138); the target spectra use the model's window."""
+    g = load_golden("dccrn_" + name)
+    cfg = DCCRNConfig(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128, masking_mode="Direct(None make)", win_type=win)
     P = oracle_params(cfg)
     x, y = make_signals(2, 4000)
     Pg = {k: (v.clone().requires_grad_(True) if is_trainable(k) else v) for k, v in P.items()}

@@ -11,7 +11,7 @@ from oracle.losses import main_loss
 from oracle.weights import formula_state_dict, test_signals as make_signals
 from simutil import (ARENA_PARAM, PHASE_BWD, PHASE_FWD, Plan, act_to_nchw, fill_params, read_params, sim_run, spec_to_ref)
 from sefd_amd.plan import ARENA_GRAD, ARENA_STATE
-from util import rel_err
+from util import knobs, rel_err
 
 SMALL = dict(kernel_num=(16, 32, 32, 64, 64, 64), rnn_units=128)
 
@@ -90,9 +90,9 @@ def test_bf16_wide_lstm_is_one_recurrence_op_per_layer_and_equals_the_per_step_p
     plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
     kinds = [plan.op_info(PHASE_FWD, i)["kind"] for i in range(plan.num_ops(PHASE_FWD))]
     assert kinds.count(1) < 40                                  # no per-frame GEMMs
-    monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+    knobs.set("LSTM_STEPPED", "1")
     ref = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
-    monkeypatch.delenv("SEFD_LSTM_STEPPED")
+    knobs.unset("LSTM_STEPPED")
     assert plan.num_ops(PHASE_FWD) < ref.num_ops(PHASE_FWD) - 2 * (plan.T - 1)
     o1, g1 = _run_plan(plan, P, x, gw)
     o2, g2 = _run_plan(ref, P, x, gw)
@@ -127,7 +127,7 @@ def test_hostsim_any_scipy_window():
 
 
 def test_hostsim_forced_per_step_lstm_matches_too(monkeypatch):
-    monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+    knobs.set("LSTM_STEPPED", "1")
     _check_plan_vs_oracle("E", "SI-SNR", SMALL, 2, 4000)
 
 
@@ -146,7 +146,7 @@ def test_chunked_lstm_pipeline_plan_equals_unchunked(monkeypatch):
     x, _ = make_signals(B, L)
     outs = []
     for chunks in ("1", "8"):
-        monkeypatch.setenv("SEFD_LSTM_CHUNKS", chunks)
+        knobs.set("LSTM_CHUNKS", chunks)
         plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **SMALL)
         n_lstm = sum(plan.op_info(PHASE_FWD, i)["kind"] == 9 for i in range(plan.num_ops(PHASE_FWD)))
         assert n_lstm == 2 * int(chunks), n_lstm
@@ -170,8 +170,8 @@ def test_wide_wgrad_tile_only_changes_the_row_splits(monkeypatch):
     gw = torch.randn(B, L) * 1e-3
     res, nwide = [], []
     for on in ("0", "1"):
-        monkeypatch.setenv("SEFD_WG256", on)
-        monkeypatch.setenv("SEFD_WG256_MINM", "64")
+        knobs.set("WG256", on)
+        knobs.set("WG256_MINM", "64")
         plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
         nwide.append(sum(1 for i in range(plan.num_ops(PHASE_BWD)) if plan.op_info(PHASE_BWD, i)["kind"] == 2 and plan.op_info(PHASE_BWD, i)["flags"] & 32))
         res.append(_run_plan(plan, P, x, gw)[1])
@@ -198,9 +198,9 @@ def test_folds_and_early_unpack_are_a_pure_reschedule(monkeypatch):
     gw = torch.randn(B, L) * 1e-3
     res, shape = [], []
     for multi, mid in (("0", "0"), ("1", "1")):
-        monkeypatch.setenv("SEFD_SPLITSUM_MULTI", multi)
-        monkeypatch.setenv("SEFD_SPLITSUM_MID", mid)
-        monkeypatch.setenv("SEFD_UNPACK_MID", mid)
+        knobs.set("SPLITSUM_MULTI", multi)
+        knobs.set("SPLITSUM_MID", mid)
+        knobs.set("UNPACK_MID", mid)
         plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **SMALL)
         w = _op_words(plan, PHASE_BWD)
         shape.append(([tuple(r[2:]) for r in w if r[0] == 20], [tuple(r[2:]) for r in w if r[0] == 4]))     # SPLITSUM = 20, UNPACK = 4: (lane, join)
@@ -237,8 +237,8 @@ def test_tiled_weight_layout_is_a_pure_relayout(monkeypatch):
     x, _ = make_signals(B, L)
     outs = []
     for wide in ("0", "1"):
-        monkeypatch.setenv("SEFD_CG256", wide)
-        monkeypatch.setenv("SEFD_CG256_MINM", "64")
+        knobs.set("CG256", wide)
+        knobs.set("CG256_MINM", "64")
         plan = Plan(B, L, masking_mode="C", act_dtype="bf16", **kw)
         import ctypes as C
         n, sz = plan.num_ops(PHASE_FWD), plan.lib.sefd_op_size()
@@ -473,10 +473,10 @@ def test_fsn_bf16_cluster_lstm_plan_equals_the_per_step_plan(monkeypatch):
     cfg0, P0 = cfg, P
     for stepped in (False, True, "rows"):
         if stepped is True:
-            monkeypatch.setenv("SEFD_LSTM_STEPPED", "1")
+            knobs.set("LSTM_STEPPED", "1")
         if stepped == "rows":                                   # sub-band model on the row-block kernels' ops: packed W_hh, bf16 gate slabs
-            monkeypatch.delenv("SEFD_LSTM_STEPPED")
-            monkeypatch.setenv("SEFD_LSTM_ROWS_MIN", "64")
+            knobs.unset("LSTM_STEPPED")
+            knobs.set("LSTM_ROWS_MIN", "64")
             hid = (256, 256)
             cfg = FSNConfig(fb_hidden=hid[0], sb_hidden=hid[1])
             P = formula_state_dict(fsn_state_shapes(cfg))
@@ -490,7 +490,7 @@ def test_fsn_bf16_cluster_lstm_plan_equals_the_per_step_plan(monkeypatch):
         plan.io(ar, "grad_crm", (B, 257, T, 2)).copy_(gc)
         sim_run(plan, PHASE_BWD, ar)
         outs.append((plan.io(ar, "crm", (B, 257, T, 2)).clone(), read_params(plan, ar, ARENA_GRAD)))
-    monkeypatch.delenv("SEFD_LSTM_ROWS_MIN")
+    knobs.unset("LSTM_ROWS_MIN")
     assert rel_err(outs[0][0], outs[1][0]) < 5e-3
     _grads_close(outs[0][1], outs[1][1], 3e-2)
     assert rel_err(outs[0][0], fsn_forward(P0, mag, cfg0)) < 3e-2

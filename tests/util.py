@@ -7,6 +7,22 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+class knobs:
+    """Tuning knobs for a test: the library's process-wide table (sefd_amd.tuning), cleared after every test by conftest."""
+
+    @staticmethod
+    def set(name, value):
+        import sefd_amd  # noqa: F401
+        from sefd_amd import tuning
+        tuning.set(name, value)
+
+    @staticmethod
+    def unset(*names):
+        import sefd_amd  # noqa: F401
+        from sefd_amd import tuning
+        tuning.unset(*names)
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}

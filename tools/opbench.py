@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-op timing of the MFMA GEMMs of one DCCRN train step (HIP events, each op alone on the stream).
 
-    python tools/opbench.py [--batch 32] [--large] [--env SEFD_CG256=0] ...   prints one line per RUNGEMM / WGRAD op
-    python tools/opbench.py --ab "SEFD_CG256=0" "SEFD_CG256=3"               A/B: one child process per environment, side by side
+    python tools/opbench.py [--batch 32] [--large] [--ab "CG256=0"] ...   prints one line per RUNGEMM / WGRAD op
+    python tools/opbench.py --ab "CG256=0" "CG256_MINM=64"               A/B: one child process per environment, side by side
 """
 import argparse
 import json
@@ -75,9 +75,10 @@ def main():
     res = []
     for e in envs:
         env = dict(os.environ)
-        for kv in e.split():
-            k, v = kv.split("=", 1)
-            env[k] = v
+        # "CG256=0 WG256=0" (an optional SEFD_ prefix is dropped): the child's tuning table, through the one variable the library reads (SEFD_TUNING)
+        knobs = [kv[5:] if kv.startswith("SEFD_") else kv for kv in e.split()]
+        if knobs:
+            env["SEFD_TUNING"] = ",".join(knobs)
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--batch", str(args.batch)] + (["--large"] if args.large else [])
         if args.tags:
             cmd += ["--tags"] + [str(t) for t in args.tags]
