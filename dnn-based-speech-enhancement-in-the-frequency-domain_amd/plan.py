@@ -228,7 +228,13 @@ class Plan:
         ptrs = (C.c_void_p * ARENA_COUNT)(*[C.c_void_p(a.data_ptr()) for a in arenas])
         cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _ctx: fn()) if fn is not None else None
         rc = self.lib.sefd_plan_run_flags(self.h, phase, ptrs, C.c_void_p(stream), flags, at if fn is not None else -1, cb, None)
-        if rc != 0 and not (rc == -5 and self.tolerate_fault):
+        if rc == -5 and self.tolerate_fault:
+            # the status word was set before this run: nothing was launched and the callback was not called - but the OTHER ranks call theirs (the
+            # first bucket's all-reduce), so this rank must too, or the collectives no longer match
+            if fn is not None:
+                fn()
+            return
+        if rc != 0:
             raise RuntimeError(f"sefd_plan_run_cb failed ({rc})" + (self._RC5 if rc == -5 else ""))
 
     def run_timed(self, phase, arenas, stream=0):
