@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsefd_hip.so")
-SOURCES = ["api.hip", "kernels.hip", "rungemm.hip", "cgemm256.hip", "lstm_bf16.hip", "lstm_cluster.hip", "lstm_rows.hip", "bn.hip", "cbn.hip", "lms.hip", "pmsqe.hip", "mix.hip", "fsn.hip", "stft_fft.hip", "thin.hip", "plan.cpp", "tuning.cpp"]
+SOURCES = ["api.hip", "kernels.hip", "rungemm.hip", "cgemm256.hip", "enc0.hip", "lstm_bf16.hip", "lstm_cluster.hip", "lstm_rows.hip", "bn.hip", "cbn.hip", "lms.hip", "pmsqe.hip", "mix.hip", "fsn.hip", "stft_fft.hip", "thin.hip", "plan.cpp", "tuning.cpp"]
 
 
 def _headers():

@@ -183,9 +183,20 @@ __device__ __forceinline__ void bnb_accum(const BnbCol& c, float slope, float dz
   s2 += bn > 0.f ? 0.f : bn * dz;
 }
 
+// Key of the per-stream scratch caches of the launchers (ticket words, carry buffers, finalize scratch): (device, stream) - the null / default stream
+// handle is the same value on every device, so a process that runs plans on two GPUs through it must not get the first device's buffers on the second.
+struct StreamKey {
+  int dev; hipStream_t st;
+  bool operator==(const StreamKey& o) const { return dev == o.dev && st == o.st; }
+};
+struct StreamKeyHash { size_t operator()(const StreamKey& k) const { return (size_t)(uintptr_t)k.st * 31u + (size_t)k.dev; } };
+inline StreamKey stream_key(hipStream_t st) { int dev = 0; (void)hipGetDevice(&dev); return StreamKey{dev, st}; }
+
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 void launch_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 bool launch_cgemm256(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
+bool launch_enc0_fwd(const RunGemm& d, const ArenaBases& ab, hipStream_t st);        // first encoder layer on the fp32 spectrum (enc0.hip)
+bool launch_enc0_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st);
 bool launch_rundirect(const RunGemm& d, const ArenaBases& ab, hipStream_t st);       // thin layers, N <= 64 (thin.hip)
 void launch_misc(const Op& op, const ArenaBases& ab, hipStream_t st);
 void launch_stft_fft(const StftFft& d, const ArenaBases& ab, hipStream_t st);

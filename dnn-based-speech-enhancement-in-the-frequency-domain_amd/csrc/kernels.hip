@@ -852,9 +852,10 @@ struct FinScratch { double* sums; unsigned* tickets; };
 static FinScratch fin_scratch(hipStream_t st) {
   // one scratch per stream: finalize launches on one stream are ordered, launches on different streams never share a buffer
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, FinScratch> map;
+  static std::unordered_map<StreamKey, FinScratch, StreamKeyHash> map;        // per (device, stream): dev_common.h StreamKey
   std::lock_guard<std::mutex> lk(mu);
-  auto it = map.find(st);
+  const StreamKey key = stream_key(st);
+  auto it = map.find(key);
   if (it != map.end()) return it->second;
   FinScratch f{};
   // + one double per channel group and one ticket for the second level of the slope gradient (bn_bwd_finalize2_kernel)
@@ -865,7 +866,7 @@ static FinScratch fin_scratch(hipStream_t st) {
     f.sums = nullptr; f.tickets = nullptr;
     return f;                                      // not cached: the caller falls back to the one-level kernel
   }
-  map.emplace(st, f);
+  map.emplace(key, f);
   return f;
 }
 

@@ -612,24 +612,25 @@ bool lstm_rows_supported(int H) { return H == 256 || H == 384 || H == 512; }
 static unsigned* pair_sync(hipStream_t st, size_t words) {
   // one buffer per stream (launches on one stream are ordered); zeroed in front of every launch by the caller
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, unsigned*> map;
+  static std::unordered_map<StreamKey, unsigned*, StreamKeyHash> map;        // per (device, stream): dev_common.h StreamKey
   constexpr size_t kWords = 1 << 18;
   if (words > kWords) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
-  auto it = map.find(st);
+  const StreamKey key = stream_key(st);
+  auto it = map.find(key);
   if (it != map.end()) return it->second;
   unsigned* p = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&p), kWords * sizeof(unsigned)) != hipSuccess) return nullptr;
-  map.emplace(st, p);
+  map.emplace(key, p);
   return p;
 }
 
 // carry of the chunked backward jobs (recurrent gradient + cell-state carry of every row block): one buffer per stream, grown on demand
 static float* rows_carry(hipStream_t st, size_t floats) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, std::pair<float*, size_t>> map;
+  static std::unordered_map<StreamKey, std::pair<float*, size_t>, StreamKeyHash> map;
   std::lock_guard<std::mutex> lk(mu);
-  auto& e = map[st];
+  auto& e = map[stream_key(st)];
   if (e.second >= floats) return e.first;
   if (e.first) { (void)hipStreamSynchronize(st); (void)hipFree(e.first); e = {nullptr, 0}; }
   float* p = nullptr;

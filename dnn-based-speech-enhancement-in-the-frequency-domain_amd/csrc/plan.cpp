@@ -737,7 +737,11 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   }
   // encoder input: spectrogram with the 2 channels padded to CP (aligned 16-byte runs for the thin first layer), act dtype
   const int CP = 8;
-  {
+  // bf16 plans (round 6): the first layer reads the fp32 spectrum itself - no padded copy (64 MB written and read per step at B = 32), K = 20 instead of
+  // 128 mostly-zero columns; kernels: enc0.hip.  ENC0_DIRECT=0: the padded copy and the generic kernels (A/B runs)
+  const bool enc0_direct = adt == DT_BF16 && spec_fft && NS == 258 && KS == 5 && Fe[1] == 128 && (ch[1] == 16 || ch[1] == 32 || ch[1] == 64) &&
+                           !(tune_str("ENC0_DIRECT") && atoi(tune_str("ENC0_DIRECT")) == 0);
+  if (!enc0_direct) {
     spec_lp = b.ws("xin", (int64_t)B * T * NS * CP, adt);
     const bool fuse_pad = !(tune_str("SPECPAD_FUSE") && atoi(tune_str("SPECPAD_FUSE")) == 0);
     if (spec_fft && fuse_pad && NS == 258) {      // the FFT kernel writes the padded copy beside the spectrogram (no SPECPAD pass: 48 us at B = 32)
@@ -752,19 +756,21 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
   struct Layer { RunGemm f[2]; Builder::Coef coef[2]; std::function<void(int, int32_t*)> bias; bool has_bias_fn; Ptr y, z, mi; int C, Fq; int64_t R; };
   std::vector<Layer> enc(n), dec(n);
   std::vector<Ptr> encz(n), ency(n), enc_mi(n);
-  Ptr prev = spec_lp;
+  Ptr prev = enc0_direct ? spec : spec_lp;
   for (int i = 0; i < n; ++i) {
     const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
-    const int Cib = i == 0 ? CP : Ci;             // channels of the input BUFFER (first layer: padded)
+    const bool direct0 = i == 0 && enc0_direct;
+    const int Cib = i == 0 ? (direct0 ? 2 : CP) : Ci;             // channels of the input BUFFER (first layer: padded, or the spectrum's (re, im) pairs)
     const std::string nm = "enc" + std::to_string(i);
     const std::string pp = "encoder." + std::to_string(i);
     const ParamInfo &Wr = b.par(pp + ".0.real_conv.weight"), &Wi = b.par(pp + ".0.imag_conv.weight");
     const ParamInfo &br = b.par(pp + ".0.real_conv.bias"), &bi = b.par(pp + ".0.imag_conv.bias");
     RunGemm g = Builder::gemm0();
     g.x[0] = prev;
-    g.xdt = adt;
+    g.xdt = direct0 ? DT_F32 : adt;
     g.ydt = adt;
-    if (i == 0) { g.bstride[0] = (int64_t)T * NS * CP; g.tstride[0] = NS * CP; g.base[0] = 2 * CP; }
+    if (direct0) g.flags |= kRunEnc0;
+    if (i == 0) { g.bstride[0] = (int64_t)T * NS * Cib; g.tstride[0] = NS * Cib; g.base[0] = 2 * Cib; }
     else { g.bstride[0] = (int64_t)T * Fi * Ci; g.tstride[0] = Fi * Ci; g.base[0] = 0; }
     g.rowlen[0] = Fi * Cib; g.fstride[0] = 2 * Cib; g.Tin[0] = T;
     g.M = B * T * Fo; g.Tout = T; g.Fo = Fo;

@@ -1141,6 +1141,7 @@ static void launch_rungemm_t(const RunGemm& d, const ArenaBases& ab, hipStream_t
 }
 
 void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (launch_enc0_fwd(d, ab, st)) return;                  // first encoder layer of the bf16 plans, on the fp32 spectrum (enc0.hip)
   if (launch_cgemm256(d, ab, st)) return;                  // wide-tile kernel for the N >= 128 bf16 layers (cgemm256.hip)
   if (launch_rundirect(d, ab, st)) return;                 // direct-operand kernel for the thin bf16 layers (thin.hip)
   if (d.xdt == DT_BF16) launch_rungemm_t<bf16_t>(d, ab, st);
@@ -1176,6 +1177,7 @@ static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t
 }
 
 void launch_wgrad(const RunGemm& d0, const ArenaBases& ab, hipStream_t st) {
+  if (launch_enc0_wgrad(d0, ab, st)) return;               // ... and its weight gradient
   RunGemm d = d0;
 #ifdef SEFD_TUNING
   // wrong-result arm (no partial-sum stores), tuning builds only (-DSEFD_TUNING): the product library has no switch that changes what a launch computes

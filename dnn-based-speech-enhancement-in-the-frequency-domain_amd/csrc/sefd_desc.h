@@ -96,6 +96,7 @@ constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chu
 constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw / 32][Npad][32]: the B operand of one 32-deep K tile is ONE
                                  // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
 constexpr int kRunBnBwd = 64;    // epilogue accumulates BatchNorm-backward partial sums against the layer's forward output (fields bnb_*); `stats` rows are [3][Npad]
+constexpr int kRunEnc0 = 512;    // first encoder layer of a bf16 plan read from the fp32 spectrum itself (xdt = fp32, ydt = bf16, runs of 10 floats): enc0.hip
 constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`
 static inline int64_t w_index(int flags, int ldw, int Npad, int n, int k) {
