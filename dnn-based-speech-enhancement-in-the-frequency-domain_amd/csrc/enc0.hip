@@ -132,10 +132,39 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(const RunGemm d, const Ar
   }
 }
 
+// operands of step s (32 rows) of the weight-gradient kernel, as whole 16-byte chunks: dy rows (32 x CO bf16) and float4 number fo0 + lane of the
+// frames t - 1, t (lanes 0..34: floats 4 fo0 .. 4 fo0 + 139)
+template <int CO> struct Enc0Regs { uint4 dy0, dy1, dy2, dy3; float4 x0, x1; };
+template <int CO>
+__device__ __forceinline__ Enc0Regs<CO> enc0_wg_fetch(const RunGemm& d, const float* x, const uint16_t* dy, int T, int s, int lane) {
+  uint4 dyv[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  float4 xv[2];
+  constexpr int CPR = CO / 8;
+  const int frame = s >> 2, fo0 = (s & 3) * 32;
+  const int b = frame / T, t = frame - b * T;
+  const uint16_t* dyr = dy + (int64_t)b * d.y_bstride + (int64_t)t * d.y_tstride + d.y_off;
+#pragma unroll
+  for (int i = 0; i < CO / 16; ++i) {
+    const int c = lane + 64 * i, row = c / CPR, c8 = c - row * CPR;
+    dyv[i] = *reinterpret_cast<const uint4*>(dyr + (int64_t)(fo0 + row) * d.y_fstride + c8 * 8);
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int tt = t - 1 + f, q4 = fo0 + lane;
+    xv[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < 35 && tt >= 0 && q4 >= 1 && q4 < 129) xv[f] = *reinterpret_cast<const float4*>(x + (int64_t)b * d.bstride[0] + (int64_t)tt * d.tstride[0] + 4 * q4);
+  }
+  return Enc0Regs<CO>{dyv[0], dyv[1], dyv[2], dyv[3], xv[0], xv[1]};
+}
+
 template <int CO>
 __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int NB = (CO + 31) / 32;
+  constexpr int NDY = CO / 16;                               // 16-byte chunks of a 32-row dy tile per lane (32 rows x CO x 2 B / 1 KB)
+  constexpr int CPR = CO / 8;                                // chunks per row
   __shared__ float red[3][NB][16][64];                       // accumulators of waves 1..3
+  __shared__ __attribute__((aligned(16))) uint16_t dys[4][32 * CO];      // per wave: the step's 32 rows of dy
+  __shared__ __attribute__((aligned(16))) float xs[4][2][144];           // per wave: floats 4 fo0 .. 4 fo0 + 139 of frames t - 1 and t
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int sp = blockIdx.x;
   const int T = d.Tout;
@@ -151,30 +180,33 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
   // B operand column of this lane: k' = lane & 31 -> (kw, j); columns 20..31 multiply zeros
-  const int kq = lane & 31, kw = kq >= 10 ? 1 : 0, j = kq - 10 * kw;
+  const int kq = lane & 31, kw = kq >= 10 ? 1 : 0, j = kq - 10 * kw, hh = lane >> 5;
   const bool kok = kq < 20;
-  for (int s = st0 + wid; s < st1; s += 4) {                 // a step = 32 consecutive rows = a quarter of one frame (Fo = 128)
-    const int frame = s >> 2, fo0 = (s & 3) * 32;
-    const int b = frame / T, t = frame - b * T;
-    const int tt = t - 1 + kw;
-    const float* xf = x + (int64_t)b * d.bstride[0] + (int64_t)tt * d.tstride[0];
-    const uint16_t* dyr = dy + (int64_t)b * d.y_bstride + (int64_t)t * d.y_tstride + d.y_off;
-    float av[NB][16], bvv[16];
+  // A step = 32 consecutive rows = a quarter of one frame (Fo = 128).  Its operands travel global -> registers as whole 16-byte chunks (the first
+  // version gathered every MFMA operand with its own 2- / 4-byte load: 32 load instructions per 16 MFMAs, 156 us at B = 32) -> the wave's private
+  // LDS tile -> MFMA operand reads; the next step's chunks are in flight while this one multiplies.
+  if (st0 >= st1) {}                                         // (an empty split still writes its zero block below)
+  Enc0Regs<CO> rg = enc0_wg_fetch<CO>(d, x, dy, T, min(st0 + wid, max(st1, 1) - 1), lane);
+  for (int s = st0 + wid; s < st1; s += 4) {
+    *reinterpret_cast<uint4*>(&dys[wid][lane * 8]) = rg.dy0;
+    if (NDY > 1) *reinterpret_cast<uint4*>(&dys[wid][(lane + 64) * 8]) = rg.dy1;
+    if (NDY > 2) { *reinterpret_cast<uint4*>(&dys[wid][(lane + 128) * 8]) = rg.dy2; *reinterpret_cast<uint4*>(&dys[wid][(lane + 192) * 8]) = rg.dy3; }
+    if (lane < 35) {
+      *reinterpret_cast<float4*>(&xs[wid][0][4 * lane]) = rg.x0;
+      *reinterpret_cast<float4*>(&xs[wid][1][4 * lane]) = rg.x1;
+    }
+    rg = enc0_wg_fetch<CO>(d, x, dy, T, min(s + 4, st1 - 1), lane);       // (the last iteration re-fetches a step it does not use: no conditional copy of the arrays)
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      const int fo = fo0 + 2 * p + (lane >> 5);
-      const int idx = 4 * fo + j;
-      bvv[p] = (kok && tt >= 0 && idx >= 4 && idx < 516) ? xf[idx] : 0.f;
+      const int r = 2 * p + hh;                              // row of the step this lane feeds into the contraction
+      const float bv = kok ? xs[wid][kw][4 * r + j] : 0.f;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int n = nb * 32 + (lane & 31);
-        av[nb][p] = n < d.N ? bf2f(dyr[(int64_t)fo * d.y_fstride + n]) : 0.f;
+        const float av = n < CO ? bf2f(dys[wid][r * CO + n]) : 0.f;
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nb][p], bvv[p], acc[nb], 0, 0, 0);
   }
   if (wid > 0) {
 #pragma unroll
@@ -209,7 +241,7 @@ bool launch_enc0_fwd(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 }
 
 bool launch_enc0_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
-  if (!enc0_form(d) || d.ydt != DT_BF16) return false;
+  if (!enc0_form(d) || d.ydt != DT_BF16 || d.y_fstride % 8 != 0 || d.y_off % 8 != 0) return false;
   const dim3 grid((unsigned)d.nsplit);
   if (d.N <= 16) hipLaunchKernelGGL(enc0_wgrad_kernel<16>, grid, dim3(256), 0, st, d, ab);
   else if (d.N <= 32) hipLaunchKernelGGL(enc0_wgrad_kernel<32>, grid, dim3(256), 0, st, d, ab);
