@@ -28,7 +28,8 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}      # dense MFMA peak by operand dtype (MI3
 PEAK_HBM_GBS = 8000.0
 K_RUNGEMM, K_WGRAD, K_LSTM_FWD, K_LSTM_BWD, K_STFT, K_ISTFT = 1, 2, 9, 10, 37, 39
 F_WTILE32 = 16                           # RunGemm flag of the wide-tile kernel (csrc/sefd_desc.h kRunWTile32)
-PMC_ROUND = "r05"
+F_ENC0 = 512                             # ... of the first encoder layer on the fp32 spectrum (kRunEnc0, csrc/enc0.hip): K = 20, bound by HBM, not by the matrix pipe
+PMC_ROUND = "r06"
 PMC_SUMMARY = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_pmc_traffic.json")       # default workload; main() switches to <round>_pmc_traffic_<model>.json
 PMC_DEFAULT_BATCH = {"dccrn": 32, "dccrn_large": 64, "fullsubnet": 64}       # the batch each committed summary was collected at
 ALGO_GB_PER_UTT = 0.28                   # minimal fused activation traffic of one bf16 training step
@@ -96,6 +97,8 @@ def pmc_step_total():
 
 def _op_class(info):
     k = info["kind"]
+    if k in (K_RUNGEMM, K_WGRAD) and info["flags"] & F_ENC0:
+        return ("enc0_direct", 0)
     if k == K_RUNGEMM:
         return ("cgemm256" if info["flags"] & F_WTILE32 else "rungemm", info["dtype"])
     if k == K_WGRAD:
@@ -158,8 +161,8 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
             a["launches"] += 1
     detail = {}
     for (name, dt), v in agg.items():
-        label = f"{name}_{'bf16' if dt else 'f32'}" if name not in ("stft_fft", "istft_fft") else name
-        if name in ("stft_fft", "istft_fft"):
+        label = f"{name}_{'bf16' if dt else 'f32'}" if name not in ("stft_fft", "istft_fft", "enc0_direct") else name
+        if name in ("stft_fft", "istft_fft", "enc0_direct"):
             gbs = v["bytes"] / (v["ms_situ"] * 1e-3) / 1e9 if v["ms_situ"] > 0 else 0.0
             gbi = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
             detail[label] = dict(bound="hbm", gb_s=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4), gb_s_isolated=round(gbi, 1),
@@ -167,7 +170,8 @@ def roofline(plan, arenas, pmc_ok=True, reps=20, insitu_reps=100, algo_stft_byte
                                  launches=v["launches"], bytes_per_launch=int(v["bytes"] / max(v["launches"], 1)))
             if name == "stft_fft" and algo_stft_bytes:
                 # the SURVEY 8d figure (fp32 samples in + [514, T] fp32 spectrum out per utterance = 1.185 MB at 3 s): what the transform has to
-                # move; bytes_per_launch above is what THIS kernel moves (it also writes the channel-padded bf16 copy the first conv reads)
+                # move; bytes_per_launch above is what THIS kernel moves (through round 5 it also wrote a channel-padded bf16 copy for the first conv;
+                # since round 6 that layer reads the fp32 spectrum: the class "enc0_direct")
                 ga = algo_stft_bytes * v["launches"] / (v["ms_situ"] * 1e-3) / 1e9 if v["ms_situ"] > 0 else 0.0
                 detail[label].update(algorithmic_bytes_per_launch=int(algo_stft_bytes), gb_s_algorithmic=round(ga, 1), frac_algorithmic=round(ga / PEAK_HBM_GBS, 4))
         else:
@@ -216,8 +220,8 @@ def cpu_baseline(L, kn, ru):
         ts.append(time.time() - t0)
     med = sorted(ts)[len(ts) // 2]
     out = dict(value=round(Bc / med, 3), unit="utt/s", cores=torch.get_num_threads(), kind="port",
-               sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc}, 1 warm-up + {nsteps} timed steps "
-                      f"(median {med:.2f} s/step, min {min(ts):.2f}), fp32")
+               sample=f"oracle DCCRN train step (CPU PyTorch restatement of trainer.py:23-39), B={Bc} ONLY (B = 32: --cpu-b32, two more minutes), "
+                      f"1 warm-up + {nsteps} timed steps (median {med:.2f} s/step, min {min(ts):.2f}), fp32")
     # (B = 32 on the CPU takes 22 s per step - 1.43 utt/s, profiles/r04_bench_default.json; BASELINE.md section 4's median of >= 5 steps would
     # add two minutes to the default run, so the B = 4 protocol above is the one reported; `--cpu-b32` times it with the same protocol)
     if CPU_B32:

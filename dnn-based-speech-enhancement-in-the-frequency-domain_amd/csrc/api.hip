@@ -108,6 +108,7 @@ int32_t sefd_plan_op_info(const sefd_plan* h, int phase, int i, int64_t* o) {
     o[6] = 2 * (int64_t)g.M * g.N * K;                                     // algorithmic flops (true K, true N)
     // algorithmic bytes: every source element once is not well defined for overlapping runs; report A-row + y + w traffic
     o[7] = (int64_t)g.M * g.N * esize(g.ydt) + (int64_t)g.N * K * esize(g.xdt);
+    if (g.flags & kRunEnc0) o[7] += (int64_t)(g.M / g.Fo) * g.tstride[0] * 4;     // first encoder layer on the spectrum: + every frame of it, once (HBM-bound kernels: enc0.hip)
   } else if (op.kind == OP_LSTM_FWD || op.kind == OP_LSTM_BWD) {            // recurrent gate GEMM: rows x 4H x H per launch
     const LstmRec& r = op.lstm;
     const int64_t steps = op.kind == OP_LSTM_FWD && r.t1 > 0 ? r.t1 - r.t0 : r.T;

@@ -1,4 +1,4 @@
-# Round-5 final artefacts on one GPU box: whole -m gpu suite, smoke, bench lines (default with roofline + CPU baseline, B64, large, fullsubnet, PMSQE),
+# Round-6 final artefacts on one GPU box: whole -m gpu suite, smoke, bench lines (default with roofline + CPU baseline, B64, large, fullsubnet, PMSQE),
 # kernel stats + timeline + PMC traffic (separate --pmc passes) for the default step and for the two other models.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/fin_tests.log 2>&1; echo "rc=$?" >> $O/fin_tests.log; tail -4 $O/fin_tests.log | cut -c1-200
@@ -16,12 +16,12 @@ pmc() {   # $1 = tag, $2.. = bench args ; two counter passes -> $O/fin_pmc_$1.js
   cp $O/fin_prof_$tag/k_kernel_stats.csv $O/fin_kernel_stats_$tag.csv 2>/dev/null
 }
 pmc default
-cp $O/fin_pmc_default.json profiles/r05_pmc_traffic.json 2>/dev/null     # the bench line below reads the traffic of THIS build's kernels
+cp $O/fin_pmc_default.json profiles/r06_pmc_traffic.json 2>/dev/null     # the bench line below reads the traffic of THIS build's kernels
 python tools/timeline.py $O/fin_prof_default/k_kernel_trace.csv 1 v > $O/fin_timeline_default.txt 2>&1
 pmc dccrn_large --model dccrn_large
-cp $O/fin_pmc_dccrn_large.json profiles/r05_pmc_traffic_dccrn_large.json 2>/dev/null
+cp $O/fin_pmc_dccrn_large.json profiles/r06_pmc_traffic_dccrn_large.json 2>/dev/null
 pmc fullsubnet --model fullsubnet
-cp $O/fin_pmc_fullsubnet.json profiles/r05_pmc_traffic_fullsubnet.json 2>/dev/null
+cp $O/fin_pmc_fullsubnet.json profiles/r06_pmc_traffic_fullsubnet.json 2>/dev/null
 TIMELINE_MARK=fsn_in_kernel:1 python tools/timeline.py $O/fin_prof_fullsubnet/k_kernel_trace.csv 1 v > $O/fin_timeline_fullsubnet.txt 2>&1
 find $O -name "k_kernel_trace.csv" -size +20M -delete 2>/dev/null
 timeout 900 python bench.py > $O/fin_bench_default.log 2>&1; tail -1 $O/fin_bench_default.log | cut -c1-250
