@@ -468,8 +468,15 @@ void finalize_rungemms(Builder& b, Plan* P) {
   for (auto* ops : {&P->fwd, &P->bwd}) {
     std::vector<Pack> packs;
     std::vector<Op> rest;
+    // The first encoder layer on the spectrum (kRunEnc0) keeps its own two tiny PACK launches (2 048 + 32 elements) on the main stream: as part of the
+    // phase's PACKMULTI (48 us on the second stream, joined by the first GEMM) it held the first layer back until 70 us into the step although the STFT
+    // in front of it ends at 17 us (profiles/r06_timeline.txt); the join moves to the second layer's GEMM
+    int64_t own_w = -1, own_b = -1;
+    for (Op& op : *ops)
+      if (op.kind == OP_RUNGEMM && (op.g.flags & kRunEnc0)) { own_w = op.g.w.off; own_b = op.g.bias.arena >= 0 ? op.g.bias.off : -1; break; }
     for (Op& op : *ops) {
-      if (op.kind == OP_PACK) packs.push_back(op.pack); else rest.push_back(op);
+      const bool own = op.kind == OP_PACK && op.pack.dst.arena == A_WS && (op.pack.dst.off == own_w || op.pack.dst.off == own_b);
+      if (op.kind == OP_PACK && !own) packs.push_back(op.pack); else rest.push_back(op);
     }
     if (packs.size() < 2) continue;
     Op m;
@@ -492,6 +499,7 @@ void finalize_rungemms(Builder& b, Plan* P) {
     for (size_t i = 1; i < P->fwd.size(); ++i) {
       Op& op = P->fwd[i];
       if (op.lane != 0) continue;
+      if (op.kind == OP_RUNGEMM && (op.g.flags & kRunEnc0)) continue;                     // reads its own PACK launches, not the PACKMULTI's output
       if (op.kind == OP_RUNGEMM || op.kind == OP_LSTM_FWD || op.kind == OP_WGRAD) { op.join = 1; first = i; break; }
     }
     if (first > 0) {
