@@ -132,38 +132,46 @@ __global__ __launch_bounds__(256) void enc0_fwd_kernel(const RunGemm d, const Ar
   }
 }
 
-// operands of step s (32 rows) of the weight-gradient kernel, as whole 16-byte chunks: dy rows (32 x CO bf16) and float4 number fo0 + lane of the
-// frames t - 1, t (lanes 0..34: floats 4 fo0 .. 4 fo0 + 139)
-template <int CO> struct Enc0Regs { uint4 dy0, dy1, dy2, dy3; float4 x0, x1; };
-template <int CO>
-__device__ __forceinline__ Enc0Regs<CO> enc0_wg_fetch(const RunGemm& d, const float* x, const uint16_t* dy, int T, int s, int lane) {
-  uint4 dyv[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-  float4 xv[2];
+// operands of step s (32 rows) of the weight-gradient kernel, as whole 16-byte chunks: dy rows (32 x CO bf16; FUSE: dz0, dz1 and the forward output y,
+// same index) and float4 number fo0 + lane of the frames t - 1, t (lanes 0..34: floats 4 fo0 .. 4 fo0 + 139)
+template <int CO, bool FUSE> struct Enc0Regs { uint4 dy[CO / 16]; uint4 dz1[FUSE ? CO / 16 : 1]; uint4 yf[FUSE ? CO / 16 : 1]; float4 x0, x1; };
+template <int CO, bool FUSE>
+__device__ __forceinline__ Enc0Regs<CO, FUSE> enc0_wg_fetch(const RunGemm& d, const float* x, const uint16_t* dy, const uint16_t* dz1, const uint16_t* yf, int T, int s, int lane) {
   constexpr int CPR = CO / 8;
+  Enc0Regs<CO, FUSE> r;
   const int frame = s >> 2, fo0 = (s & 3) * 32;
   const int b = frame / T, t = frame - b * T;
-  const uint16_t* dyr = dy + (int64_t)b * d.y_bstride + (int64_t)t * d.y_tstride + d.y_off;
+  const int64_t rowbase = (int64_t)b * d.y_bstride + (int64_t)t * d.y_tstride + d.y_off;
 #pragma unroll
   for (int i = 0; i < CO / 16; ++i) {
     const int c = lane + 64 * i, row = c / CPR, c8 = c - row * CPR;
-    dyv[i] = *reinterpret_cast<const uint4*>(dyr + (int64_t)(fo0 + row) * d.y_fstride + c8 * 8);
+    const int64_t o = rowbase + (int64_t)(fo0 + row) * d.y_fstride + c8 * 8;
+    r.dy[i] = *reinterpret_cast<const uint4*>(dy + o);
+    if constexpr (FUSE) {
+      r.dz1[i] = dz1 ? *reinterpret_cast<const uint4*>(dz1 + o) : make_uint4(0, 0, 0, 0);
+      r.yf[i] = *reinterpret_cast<const uint4*>(yf + o);
+    }
   }
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int tt = t - 1 + f, q4 = fo0 + lane;
-    xv[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < 35 && tt >= 0 && q4 >= 1 && q4 < 129) xv[f] = *reinterpret_cast<const float4*>(x + (int64_t)b * d.bstride[0] + (int64_t)tt * d.tstride[0] + 4 * q4);
+  const int q4 = fo0 + lane;
+  r.x0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.x1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < 35 && q4 >= 1 && q4 < 129) {
+    const float* xb = x + (int64_t)b * d.bstride[0] + 4 * q4;
+    if (t >= 1) r.x0 = *reinterpret_cast<const float4*>(xb + (int64_t)(t - 1) * d.tstride[0]);
+    r.x1 = *reinterpret_cast<const float4*>(xb + (int64_t)t * d.tstride[0]);
   }
-  return Enc0Regs<CO>{dyv[0], dyv[1], dyv[2], dyv[3], xv[0], xv[1]};
+  return r;
 }
 
-template <int CO>
+// FUSE (kRunDyFromBn): the step's dy tile is formed from dz0 (+ dz1) and the layer's forward output through the BatchNorm + PReLU backward and kept in
+// fp32; otherwise the stored bf16 dy is the operand
+template <int CO, bool FUSE>
 __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int NB = (CO + 31) / 32;
-  constexpr int NDY = CO / 16;                               // 16-byte chunks of a 32-row dy tile per lane (32 rows x CO x 2 B / 1 KB)
+  constexpr int NDY = CO / 16;                               // 16-byte chunks of a 32-row bf16 tile per lane (32 rows x CO x 2 B / 1 KB)
   constexpr int CPR = CO / 8;                                // chunks per row
   __shared__ float red[3][NB][16][64];                       // accumulators of waves 1..3
-  __shared__ __attribute__((aligned(16))) uint16_t dys[4][32 * CO];      // per wave: the step's 32 rows of dy
+  __shared__ __attribute__((aligned(16))) float dys[4][32 * CO];         // per wave: the step's 32 rows of dy as fp32
   __shared__ __attribute__((aligned(16))) float xs[4][2][144];           // per wave: floats 4 fo0 .. 4 fo0 + 139 of frames t - 1 and t
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int sp = blockIdx.x;
@@ -173,7 +181,24 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
   const int st0 = sp * per, st1 = min(nsteps, (sp + 1) * per);
   const float* x = reinterpret_cast<const float*>(rp(ab, d.x[0]));
   const uint16_t* dy = reinterpret_cast<const uint16_t*>(rp(ab, d.y));
+  const uint16_t* dz1 = (FUSE && d.bnb_dz1.arena >= 0) ? reinterpret_cast<const uint16_t*>(rp(ab, d.bnb_dz1)) : nullptr;
+  const uint16_t* yf = FUSE ? reinterpret_cast<const uint16_t*>(rp(ab, d.bnb_y)) : nullptr;
   float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)sp * d.Npad * d.ldw;
+  // FUSE: the 8 channels of this lane's chunks are the same in every step (64 % CPR == 0): their BatchNorm constants live in registers
+  float pm[8], pis[8], pg[8], pb[8], t0[8], t1[8], slope = 0.f;
+  if constexpr (FUSE) {
+    const float* mi = reinterpret_cast<const float*>(rp(ab, d.bnb_mi));
+    const float* ga = reinterpret_cast<const float*>(rp(ab, d.bnb_gamma));
+    const float* be = reinterpret_cast<const float*>(rp(ab, d.bnb_beta));
+    const float* tot = reinterpret_cast<const float*>(rp(ab, d.bnb_totals));
+    slope = *reinterpret_cast<const float*>(rp(ab, d.bnb_slope));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = (lane % CPR) * 8 + e;
+      pm[e] = mi[n]; pis[e] = mi[d.N + n]; pg[e] = ga[n]; pb[e] = be[n];
+      t0[e] = tot[n] * d.bnb_inv_count; t1[e] = tot[d.N + n] * d.bnb_inv_count;
+    }
+  }
   f32x16 acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
@@ -184,18 +209,39 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
   const bool kok = kq < 20;
   // A step = 32 consecutive rows = a quarter of one frame (Fo = 128).  Its operands travel global -> registers as whole 16-byte chunks (the first
   // version gathered every MFMA operand with its own 2- / 4-byte load: 32 load instructions per 16 MFMAs, 156 us at B = 32) -> the wave's private
-  // LDS tile -> MFMA operand reads; the next step's chunks are in flight while this one multiplies.
-  if (st0 >= st1) {}                                         // (an empty split still writes its zero block below)
-  Enc0Regs<CO> rg = enc0_wg_fetch<CO>(d, x, dy, T, min(st0 + wid, max(st1, 1) - 1), lane);
+  // LDS tile -> MFMA operand reads; the next step's chunks are in flight while this one multiplies.  (The last iteration re-fetches a step it does
+  // not use: a conditional copy of the register struct went to scratch.)
+  Enc0Regs<CO, FUSE> rg = enc0_wg_fetch<CO, FUSE>(d, x, dy, dz1, yf, T, min(st0 + wid, max(st1, 1) - 1), lane);
   for (int s = st0 + wid; s < st1; s += 4) {
-    *reinterpret_cast<uint4*>(&dys[wid][lane * 8]) = rg.dy0;
-    if (NDY > 1) *reinterpret_cast<uint4*>(&dys[wid][(lane + 64) * 8]) = rg.dy1;
-    if (NDY > 2) { *reinterpret_cast<uint4*>(&dys[wid][(lane + 128) * 8]) = rg.dy2; *reinterpret_cast<uint4*>(&dys[wid][(lane + 192) * 8]) = rg.dy3; }
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const uint32_t gw[4] = {rg.dy[i].x, rg.dy[i].y, rg.dy[i].z, rg.dy[i].w};
+      float o[8];
+      if constexpr (FUSE) {
+        const uint32_t zw[4] = {rg.dz1[i].x, rg.dz1[i].y, rg.dz1[i].z, rg.dz1[i].w}, yw[4] = {rg.yf[i].x, rg.yf[i].y, rg.yf[i].z, rg.yf[i].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int sh = 16 * (e & 1);
+          float dz = bf2f((uint16_t)(gw[e >> 1] >> sh));
+          if (dz1) dz += bf2f((uint16_t)(zw[e >> 1] >> sh));
+          const float xh = (bf2f((uint16_t)(yw[e >> 1] >> sh)) - pm[e]) * pis[e];
+          const float bn = pg[e] * xh + pb[e];
+          const float dbn = bn > 0.f ? dz : slope * dz;
+          o[e] = pg[e] * pis[e] * (dbn - t0[e] - xh * t1[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f((uint16_t)(gw[e >> 1] >> (16 * (e & 1))));
+      }
+      float* dst = &dys[wid][(lane + 64 * i) * 8];
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
     if (lane < 35) {
       *reinterpret_cast<float4*>(&xs[wid][0][4 * lane]) = rg.x0;
       *reinterpret_cast<float4*>(&xs[wid][1][4 * lane]) = rg.x1;
     }
-    rg = enc0_wg_fetch<CO>(d, x, dy, T, min(s + 4, st1 - 1), lane);       // (the last iteration re-fetches a step it does not use: no conditional copy of the arrays)
+    rg = enc0_wg_fetch<CO, FUSE>(d, x, dy, dz1, yf, T, min(s + 4, st1 - 1), lane);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const int r = 2 * p + hh;                              // row of the step this lane feeds into the contraction
@@ -203,7 +249,7 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int n = nb * 32 + (lane & 31);
-        const float av = n < CO ? bf2f(dys[wid][r * CO + n]) : 0.f;
+        const float av = n < CO ? dys[wid][r * CO + n] : 0.f;
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
       }
     }
@@ -243,9 +289,16 @@ bool launch_enc0_fwd(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 bool launch_enc0_wgrad(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   if (!enc0_form(d) || d.ydt != DT_BF16 || d.y_fstride % 8 != 0 || d.y_off % 8 != 0) return false;
   const dim3 grid((unsigned)d.nsplit);
-  if (d.N <= 16) hipLaunchKernelGGL(enc0_wgrad_kernel<16>, grid, dim3(256), 0, st, d, ab);
-  else if (d.N <= 32) hipLaunchKernelGGL(enc0_wgrad_kernel<32>, grid, dim3(256), 0, st, d, ab);
-  else hipLaunchKernelGGL(enc0_wgrad_kernel<64>, grid, dim3(256), 0, st, d, ab);
+  const bool fuse = (d.flags & kRunDyFromBn) != 0;
+#define SEFD_E0W(CO)                                                                                              \
+  do {                                                                                                            \
+    if (fuse) hipLaunchKernelGGL((enc0_wgrad_kernel<CO, true>), grid, dim3(256), 0, st, d, ab);                   \
+    else hipLaunchKernelGGL((enc0_wgrad_kernel<CO, false>), grid, dim3(256), 0, st, d, ab);                       \
+  } while (0)
+  if (d.N <= 16) SEFD_E0W(16);
+  else if (d.N <= 32) SEFD_E0W(32);
+  else SEFD_E0W(64);
+#undef SEFD_E0W
   return true;
 }
 

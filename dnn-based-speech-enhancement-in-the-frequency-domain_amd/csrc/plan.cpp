@@ -115,7 +115,7 @@ struct Builder {
   static RunGemm gemm0() {
     RunGemm g;
     std::memset(&g, 0, sizeof(g));
-    g.x[0].arena = g.x[1].arena = g.w.arena = g.bias.arena = g.y.arena = g.stats.arena = g.y2.arena = A_NONE;
+    g.x[0].arena = g.x[1].arena = g.w.arena = g.bias.arena = g.y.arena = g.stats.arena = g.y2.arena = g.bnb_dz1.arena = g.bnb_totals.arena = A_NONE;
     g.nsplit = 1;
     return g;
   }
@@ -423,7 +423,9 @@ void finalize_rungemms(Builder& b, Plan* P) {
       if (op->kind != OP_RUNGEMM || op->g.w.arena != A_WS) continue;
       const RunGemm& g = op->g;
       const bool e = wide && (g.flags & kRunAligned) && g.xdt == DT_BF16 && g.Npad % 256 == 0 && g.ldw % 64 == 0 && g.M >= wide_minm && g.n2 == 0 &&
-                     (((g.M + 255) / 256) * (int64_t)(g.Npad / 256) >= wide_mintiles || g.ldw > 1024);
+                     ((((g.M + 255) / 256) * (int64_t)(g.Npad / 256) >= wide_mintiles && (g.ldw >= 256 || tune_str("CG256_MINM"))) || g.ldw > 1024);
+      // (... and at least four 64-deep K tiles: the layer-1 LSTM input GEMMs of the chunked forward - M 7 744, N 1024, K 128, 124 tiles - are all prologue and
+      //  epilogue on the persistent 256 x 256 tile: 32 us each against 18 us on the 128-row kernel, round 6; the tests that lower MINM run small cases on purpose)
       auto it = elig.find(g.w.off);
       if (it == elig.end()) elig[g.w.off] = e; else it->second = it->second && e;
     }
@@ -1363,8 +1365,10 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       g.stats = b.mk(A_WS, a.part.off + (int64_t)a.rows * 3 * a.ldp * 4);
       a.rows += rows;
     };
+    BnBwdApply last_bnb;                         // the BnBwdApply of the most recent bn_bwd (the fused first-layer weight gradient reads its totals)
+    std::memset(&last_bnb, 0, sizeof(last_bnb));
     auto bn_bwd = [&](int tag, Ptr y, Ptr dz0, Ptr dz1, Ptr mi, const std::string& pp, int C, int64_t Rr, int64_t rpb, int skip, Ptr dy,
-                      const std::string& nm, const BnbAcc* fused) {
+                      const std::string& nm, const BnbAcc* fused, bool no_apply = false) {
       int64_t rpbk = std::max<int64_t>(64, (Rr + 2047) / 2048);
       const int nblk = (int)((Rr + rpbk - 1) / rpbk);
       if (cbn) {                                  // `mi` is the layer's coefficient table (cbn_fwd)
@@ -1401,7 +1405,8 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       a.dgamma = b.pptr(pp + ".1.weight", A_GRAD); a.dbeta = b.pptr(pp + ".1.bias", A_GRAD); a.dslope = b.pptr(pp + ".2.weight", A_GRAD);
       a.count = (double)Rr;
       b.push(R, OP_BN_BWD_FINALIZE, tag).bnb = a;
-      b.push(R, OP_BN_BWD_APPLY, tag).bnb = a;
+      if (!no_apply) b.push(R, OP_BN_BWD_APPLY, tag).bnb = a;
+      last_bnb = a;
     };
 
     // ---- decoder backward
@@ -1791,11 +1796,15 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
       const int Ci = ch[i], Co = ch[i + 1], Fi = Fe[i], Fo = Fe[i + 1];
       const std::string nm = "enc" + std::to_string(i);
       const std::string pp = "encoder." + std::to_string(i);
-      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm, &bnb_enc[i]);
+      // First layer on the spectrum (enc0.hip): it has no input gradient, so its BatchNorm input gradient dy is read by the weight gradient alone -
+      // BN_BWD_APPLY is not planned, the weight-gradient kernel takes dz through the BatchNorm + PReLU backward as it loads it (kRunDyFromBn) and runs on
+      // the MAIN stream right behind BN_BWD_FINALIZE: apply (117 us) -> fold -> weight gradient (52 us) was the serial tail of the step.  ENC0_BNFUSE=0: off
+      const bool dy_fused = i == 0 && (enc[0].f[0].flags & kRunEnc0) && !cbn && !(tune_str("ENC0_BNFUSE") && atoi(tune_str("ENC0_BNFUSE")) == 0);
+      bn_bwd(100 + i, ency[i], d_encz[i], cfg.skip ? d_skip[i] : b.none(), enc_mi[i], pp, Co, enc[i].R, (int64_t)T * Fo, 0, d_ency[i], nm, &bnb_enc[i], dy_fused);
       // the folds of enc5 .. enc1 go in front of the LAST weight gradient on its lane (its input is the last thing the dgrad chain produces,
       // the lane usually waits for it): the fold in front of the final UNPACK then covers one thin layer
       if (i == 0 && lane_all && n > 1 && !(tune_str("SPLITSUM_MID") && atoi(tune_str("SPLITSUM_MID")) == 0)) b.flush_sums(R, 996, true);
-      b.cur_lane = lane_all ? 1 : 0;             // encoder weight gradients next to the dgrad chain
+      b.cur_lane = (lane_all && !dy_fused) ? 1 : 0;             // encoder weight gradients next to the dgrad chain
       // Every encoder conv bias sits in front of a training-mode BatchNorm: its gradient is identically zero (the sum over all rows of the
       // BatchNorm input gradient vanishes; the reference computes rounding noise there).  No bias "ones" run in these GEMMs - it cost a
       // whole 64-column K segment (enc0: 192 -> 128 columns, half the K tiles; enc3: 6 -> 5 wide tiles) - UNPACK writes the exact zero.
@@ -1807,7 +1816,20 @@ Plan* build_dccrn_plan(const ModelConfig& cfg) {
           for (int64_t e = 0; e < pb.numel; ++e) b.zero_grad[pb.off + e] = 1;
         }
       }
-      b.wgrad(R, enc[i].f[0], d_ency[i], enc[i].coef[0], 100 + i, enc_bias_zero ? nullptr : &enc[i].bias);
+      b.wgrad(R, enc[i].f[0], dy_fused ? d_encz[i] : d_ency[i], enc[i].coef[0], 100 + i, enc_bias_zero ? nullptr : &enc[i].bias);
+      if (dy_fused) {
+        for (size_t q = R.size(); q-- > 0;)
+          if (R[q].kind == OP_WGRAD && R[q].tag == 100 + i) {
+            RunGemm& g = R[q].g;
+            g.flags |= kRunDyFromBn;
+            g.bnb_dz1 = cfg.skip ? d_skip[i] : b.none();
+            g.bnb_y = ency[i]; g.bnb_mi = enc_mi[i];
+            g.bnb_gamma = b.pptr(pp + ".1.weight"); g.bnb_beta = b.pptr(pp + ".1.bias"); g.bnb_slope = b.pptr(pp + ".2.weight");
+            g.bnb_bstride = g.y_bstride; g.bnb_tstride = g.y_tstride; g.bnb_fstride = g.y_fstride; g.bnb_off = g.y_off;
+            g.bnb_totals = last_bnb.totals; g.bnb_inv_count = (float)(1.0 / last_bnb.count);
+            break;
+          }
+      }
       b.cur_lane = 0;
       if (i == 0) continue;
       // dx[ci,f,t] = sum W[co,ci,kh,kw] dy[co,(f+2-kh)/2, t+1-kw]  -> two sub-pixel phases over dy [B][T][Fo][Co]

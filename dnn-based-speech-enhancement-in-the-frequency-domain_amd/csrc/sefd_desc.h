@@ -81,6 +81,15 @@ struct RunGemm {
   // upstream gradient produces the input gradients of BOTH sources of a decoder layer: previous layer's output and the skip connection)
   int32_t n2;
   Ptr y2;
+  // kRunDyFromBn (WGRAD of the first encoder layer, enc0.hip): the upstream-gradient operand is not a stored tensor.  `y` points at dz0, the gradient with
+  // respect to the layer's BatchNorm + PReLU OUTPUT (bnb_dz1: a second component that is added, the skip connection's; A_NONE = none), and each element is
+  // taken through the layer's BatchNorm + PReLU backward on the way in:  xh = (yf - mean) * invstd, bn = gamma * xh + beta, dbn = bn > 0 ? dz : slope * dz,
+  // dy = gamma * invstd * (dbn - t0 * inv_count - xh * t1 * inv_count)  with yf = bnb_y at the SAME index as dz, (t0, t1) = bnb_totals[0..C), [C..2C)
+  // (what BN_BWD_APPLY would store, in fp32): the layer has no input gradient, so nothing else reads dy - the 127 MB store, its read back and the
+  // BN_BWD_APPLY launch on the step's serial tail are gone.
+  Ptr bnb_dz1, bnb_totals;
+  float bnb_inv_count;
+  int32_t pad2_;
 };
 static inline void fastdiv_make(uint32_t d, uint32_t* m, uint32_t* s) {
   if (d <= 1) { *m = 0; *s = 0; return; }
@@ -96,6 +105,7 @@ constexpr int kRunYAligned = 8;  // bf16 output whose rows are whole 16-byte chu
 constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw / 32][Npad][32]: the B operand of one 32-deep K tile is ONE
                                  // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
 constexpr int kRunBnBwd = 64;    // epilogue accumulates BatchNorm-backward partial sums against the layer's forward output (fields bnb_*); `stats` rows are [3][Npad]
+constexpr int kRunDyFromBn = 1024; // WGRAD: upstream gradient formed on the fly from dz through the BatchNorm + PReLU backward (fields bnb_*, bnb_dz1, bnb_totals)
 constexpr int kRunEnc0 = 512;    // first encoder layer of a bf16 plan read from the fp32 spectrum itself (xdt = fp32, ydt = bf16, runs of 10 floats): enc0.hip
 constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`

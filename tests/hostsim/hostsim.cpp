@@ -175,7 +175,18 @@ void wgrad(const RunGemm& d, const AB& ab) {
         for (int j = 0; j < d.seg[s].len; ++j) arow[d.seg[s].koff + j] = a_elem(d, ab, d.seg[s], b, u, fo, j);
       const int64_t o = (int64_t)b * d.y_bstride + (int64_t)u * d.y_tstride + (int64_t)fo * d.y_fstride + d.y_off;
       for (int n = n0; n < n1; ++n) {
-        const double g = ld(dy, d.ydt, o + n);
+        double g = ld(dy, d.ydt, o + n);
+        if (d.flags & kRunDyFromBn) {                // `y` is dz0: through the layer's BatchNorm + PReLU backward on the way in (sefd_desc.h)
+          float dz = (float)g;
+          if (d.bnb_dz1.arena >= 0) dz += ld(rp(ab, d.bnb_dz1), d.ydt, o + n);
+          const float* mi = (const float*)rp(ab, d.bnb_mi);
+          const float* tot = (const float*)rp(ab, d.bnb_totals);
+          const float ga = ((const float*)rp(ab, d.bnb_gamma))[n], be = ((const float*)rp(ab, d.bnb_beta))[n], sl = *(const float*)rp(ab, d.bnb_slope);
+          const float xh = (ld(rp(ab, d.bnb_y), d.ydt, o + n) - mi[n]) * mi[d.N + n];
+          const float bn = ga * xh + be;
+          const float dbn = bn > 0.f ? dz : sl * dz;
+          g = (double)(ga * mi[d.N + n] * (dbn - tot[n] * d.bnb_inv_count - xh * (tot[d.N + n] * d.bnb_inv_count)));
+        }
         if (g == 0.0) continue;
         double* a = &acc[(size_t)n * d.ldw];
         for (int k = 0; k < d.ldw; ++k) a[k] += g * arow[k];
