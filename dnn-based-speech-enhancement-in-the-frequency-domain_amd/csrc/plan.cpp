@@ -250,6 +250,12 @@ struct Builder {
     int tk = kWgTK;
     if (narrow && wide_on && g.Npad % 256 == 0 && g.ldw >= 384 && g.M >= wide_minm) { tn = 256; tk = 256; g.flags |= kRunWgWide; }
     else if (narrow && wide_on && g.Npad == 128 && g.ldw >= 1024 && g.M >= wide_minm) { tn = 128; tk = 512; g.flags |= kRunWgWide; }
+    // a bias ones run that would open a k tile of its own (the data columns fill whole 256-wide tiles): the kernel forms the bias with a constant ones
+    // operand in the workgroups of k tile 0 instead (kRunOnesMfma, rungemm.hip); ONES_MFMA=0 keeps the run a DMA'd column
+    if ((g.flags & kRunWgWide) && tn == 256 && bias && g.nseg >= 2 && g.seg[g.nseg - 1].src < 0 && g.seg[g.nseg - 1].koff == g.ldw - 64 &&
+        (g.ldw - 64) % 256 == 0 && !(tune_str("ONES_MFMA") && atoi(tune_str("ONES_MFMA")) == 0))
+      g.flags |= kRunOnesMfma;
+    const int64_t ldk = (g.flags & kRunOnesMfma) ? g.ldw - 64 : g.ldw;    // columns the k tiles cover
     // wg_rounds > 1 (FullSubNet): that many dispatch rounds of shorter workgroups - the launch shares the chip with a recurrence whose
     // second round leaves 2/3 of the CUs idle, and a workgroup that needs the whole kernel's duration on its CU cannot use such a hole
     // SEFD_WG_ROUNDS / SEFD_WGW_ROUNDS (tuning): rounds of every weight-gradient GEMM / of the wide-tile ones when the model did not set its own
@@ -258,12 +264,12 @@ struct Builder {
     // main stream's 160 KB-LDS GEMMs need whole CUs, and 220 instead of 250 workgroups leave every XCD four - DCCRN default 10.60 -> 10.50 ms per step
     // (slots 160 / 192 / 208 / 216 / 224 / 232 / 240 / 248: 10.59 / 10.55 / 10.53 / 10.50 / 10.50 / 10.61 / 10.61 / 10.59, profiles/r05_tuning_notes.md);
     // DCCRN-large's launches (20 / 40 tiles, or 5 tiles of 19 000-row workgroups) LOSE 0.3-0.7 ms that way and keep 256.  SEFD_WGW_SLOTS overrides.
-    const int tiles_w = std::max(1, (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk));
+    const int tiles_w = std::max(1, (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(ldk, tk) / tk));
     const bool short_wg = wg_rounds <= 1 && tiles_w <= 10 && (int64_t)g.M * tiles_w < (int64_t)8192 * 256;
     const int wide_slots = tune_str("WGW_SLOTS") ? atoi(tune_str("WGW_SLOTS")) : (short_wg ? 224 : 256);
     const int nscale = tune_str("WGN_SCALE") ? atoi(tune_str("WGN_SCALE")) : 100;      // tuning: percent of the slots of the narrow-tile launches
     const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : (tn == 128 ? 512 : tn == 64 ? 768 : 1024) * nscale / 100) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
-    const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(g.ldw, tk) / tk);   // tiles that hold real rows
+    const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(ldk, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
     ns = std::max(1, std::min(ns, std::max(1, steps / 4)));
@@ -2869,7 +2875,11 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
       const int xw = fw.nseg == 1 ? (int)rup(fw.seg[0].len, 64) : 0;
       const bool cat = !gru && L.rowsk && fw.nseg == 1 && fw.seg[0].src == 0 && xw == 64 && H % 64 == 0 && rup(xw + H + 64, 256) == rup(H, 256) &&
                        !(tune_str("FSN_WGCAT") && atoi(tune_str("FSN_WGCAT")) == 0);
-      if (cat) {
+      // The upper layer: [h1_t | h2_{t-1}] = 2 H = 768 columns = three whole 256-wide k tiles in ONE GEMM over dgates (W_ih and W_hh apart: 384 (+ 64 ones)
+      // and 384 columns = 2 + 2 tiles, a quarter of them padding, and two passes over the gate gradients); the bias comes from the ones MFMA of k tile 0
+      const bool cat2 = !cat && !gru && L.rowsk && fw.nseg == 1 && fw.seg[0].src == 0 && fw.seg[0].len == H && fw.seg[0].dt == 0 && (2 * H) % 256 == 0 &&
+                        !(tune_str("FSN_WGCAT2") && atoi(tune_str("FSN_WGCAT2")) == 0) && !(tune_str("ONES_MFMA") && atoi(tune_str("ONES_MFMA")) == 0);
+      if (cat || cat2) {
         RunGemm fc = fw;
         fc.x[1] = L.h; fc.bstride[1] = 0; fc.tstride[1] = (int)(rows * H); fc.base[1] = 0; fc.rowlen[1] = (int)(rows * H); fc.fstride[1] = H; fc.Tin[1] = TP;
         fc.seg[fc.nseg++] = Seg{1, -1, 0, H, 0};           // h_{t-1}

@@ -859,7 +859,10 @@ __device__ __forceinline__ bf16x8 tr_frag_swz(const uint16_t* tile, int col0, in
 // bytes through L2 -> LDS per MFMA, which is what bounds the 128 x 128 tile - 64 B/clk/CU at the MFMA rate, the DMA stream's ceiling)
 // DUAL (needs S == 4): two 32-row steps per barrier - stages i, i+1 are multiplied while i+2, i+3 fly; the barrier, the vmcnt wait and
 // the DMA issue burst are paid once per 64 rows (the row splits, i.e. the partial sums, stay those of the 32-row steps)
-template <int TN, int S, int TK = kWgTK, int NTHR = 256, bool DUAL = false>
+// ONESM (kRunOnesMfma, 256 x 256 tile): the bias "ones" run - the LAST 64 packed columns - is not a k tile of its own (a whole tile's DMA stream and MFMAs for
+// one column): the k tiles cover ldw - 64 columns and the workgroups of k tile 0 multiply their dy fragments with a constant ones operand, two extra
+// MFMAs per wave and step, no extra bytes ([h1 | h2 | ones] = 832 columns of FullSubNet's upper sub-band layer: 3 tiles instead of 4)
+template <int TN, int S, int TK = kWgTK, int NTHR = 256, bool DUAL = false, bool ONESM = false>
 __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, const ArenaBases ab) {
   constexpr int RS = kWgRows, NW = NTHR / 64;
   // wave grid: 2 (n) x 2 (k) for the 128 / 64 / 32 wide n tiles, 1 x 4 for the 16 wide one (thin layers: N <= 16, e.g. the mask
@@ -873,7 +876,8 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int ntile, ktile, split;
-  wgrad_block((d.Npad + TN - 1) / TN, (d.ldw + TK - 1) / TK, d.nsplit, ntile, ktile, split);
+  const int ldk = ONESM ? d.ldw - 64 : d.ldw;      // columns the k tiles cover
+  wgrad_block((d.Npad + TN - 1) / TN, (ldk + TK - 1) / TK, d.nsplit, ntile, ktile, split);
   const uint16_t* x0 = reinterpret_cast<const uint16_t*>(rp(ab, d.x[0]));
   const uint16_t* x1 = d.x[1].arena >= 0 ? reinterpret_cast<const uint16_t*>(rp(ab, d.x[1])) : x0;
   const uint16_t* dy = reinterpret_cast<const uint16_t*>(rp(ab, d.y));
@@ -883,8 +887,13 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
   if (ntile * TN >= d.N) {                         // n tile made of padding rows only (N = 8 in a 32-row packed matrix): zeros
     for (int i = tid; i < TN * TK; i += NTHR) {
       const int n = ntile * TN + i / TK, k = ktile * TK + i % TK;
-      if (n < d.Npad && k < d.ldw) part[(int64_t)n * d.ldw + k] = 0.f;
+      if (n < d.Npad && k < ldk) part[(int64_t)n * d.ldw + k] = 0.f;
     }
+    if (ONESM && ktile == 0)
+      for (int i = tid; i < TN * 64; i += NTHR) {
+        const int n = ntile * TN + i / 64;
+        if (n < d.Npad) part[(int64_t)n * d.ldw + ldk + i % 64] = 0.f;
+      }
     return;
   }
 
@@ -1028,6 +1037,30 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
 #pragma unroll
     for (int b = 0; b < KB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wn = (wid / WK) * PWN, wk = (wid % WK) * PWK;
+  // ONESM: the WK waves that share a dy fragment range split its NT blocks between them (NT / WK each)
+  constexpr int NBIAS = ONESM ? NT / WK : 1;
+  static_assert(!ONESM || (NT % WK == 0 && WK == 4 && NBIAS == 2), "ones-by-MFMA: 256 x 256 tile of 8 waves");
+  f32x4 bacc[NBIAS];
+#pragma unroll
+  for (int u = 0; u < NBIAS; ++u) bacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kw = __builtin_amdgcn_readfirstlane(wid % WK);
+  const bool bias_wg = ONESM && __builtin_amdgcn_readfirstlane(ktile) == 0;
+  auto bias_mul = [&](const bf16x8* af) {
+    if constexpr (ONESM) {
+      if (bias_wg) {
+        Frag8 o;
+        o.lo = s16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        o.hi = o.lo;
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, o);
+        switch (kw) {                                  // wave-uniform: a scalar branch, the fragment registers stay statically indexed
+          case 0: bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], ones, bacc[1], 0, 0, 0); break;
+          case 1: bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], ones, bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3], ones, bacc[1], 0, 0, 0); break;
+          case 2: bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4], ones, bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[5], ones, bacc[1], 0, 0, 0); break;
+          default: bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[6], ones, bacc[0], 0, 0, 0); bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[7], ones, bacc[1], 0, 0, 0); break;
+        }
+      }
+    }
+  };
 
   // S-stage ring: DMA runs S-1 row steps ahead of the MFMAs; per step one vmcnt wait for the oldest stage + one LDS barrier
   const int nst = step1 - step0;
@@ -1044,6 +1077,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < KB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      bias_mul(af);
     };
     for (int i = 0; i < 2; ++i)
       if (issued < nst) { dma(istage); istage = (istage + 1) & 3; ++issued; }
@@ -1072,6 +1106,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int b = 0; b < KB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    bias_mul(af);
     cstage = cstage + 1 == S ? 0 : cstage + 1;
   }
   }
@@ -1092,8 +1127,23 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
       for (int r = 0; r < 4; ++r) {
         const int n = ntile * TN + wn + a * 16 + 4 * (lane >> 4) + r;
         const int k = ktile * TK + wk + b * 16 + (lane & 15);
-        if (n < d.Npad && k < d.ldw) part[(int64_t)n * d.ldw + k] = acc[a][b][r];
+        if (n < d.Npad && k < ldk) part[(int64_t)n * d.ldw + k] = acc[a][b][r];
       }
+  if constexpr (ONESM) {
+    if (bias_wg) {                                   // every column of the ones product holds the row sum: column 0 is the bias, the run's other 63 are zeros
+#pragma unroll
+      for (int u = 0; u < NBIAS; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = ntile * TN + wn + (kw * NBIAS + u) * 16 + 4 * (lane >> 4) + r;
+          if (n < d.Npad) {
+            float* row = part + (int64_t)n * d.ldw + ldk;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) row[16 * c + (lane & 15)] = (c == 0 && (lane & 15) == 0) ? bacc[u][r] : 0.f;
+          }
+        }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1152,6 +1202,12 @@ void launch_rungemm(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
 static void launch_wgrad_wide(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
   static const int stages = env_stages("WG256_STAGES", 2);   // 2, 3 and 4 stages measure the same (+-1 %): 2 x 32 KB leaves LDS to the other stream's kernels
   static const bool dual = !(tune_str("WG_DUAL") && atoi(tune_str("WG_DUAL")) == 0);
+  if (d.flags & kRunOnesMfma) {                     // the ones run is not a k tile (plan.cpp wgrad())
+    dim3 grid1(((d.Npad + 255) / 256) * ((d.ldw - 64 + 255) / 256) * d.nsplit);
+    if (dual) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 4, 256, 512, true, true>), grid1, dim3(512), 0, st, d, ab);
+    else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 2, 256, 512, false, true>), grid1, dim3(512), 0, st, d, ab);
+    return;
+  }
   dim3 grid(((d.Npad + 255) / 256) * ((d.ldw + 255) / 256) * d.nsplit);
   if (dual) { hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 4, 256, 512, true>), grid, dim3(512), 0, st, d, ab); return; }
   if (stages == 2) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<256, 2, 256, 512>), grid, dim3(512), 0, st, d, ab);

@@ -106,6 +106,7 @@ constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw
                                  // contiguous block, so every LDS-DMA of the wide-tile kernel (cgemm256.hip) moves whole 128-byte lines
 constexpr int kRunBnBwd = 64;    // epilogue accumulates BatchNorm-backward partial sums against the layer's forward output (fields bnb_*); `stats` rows are [3][Npad]
 constexpr int kRunDyFromBn = 1024; // WGRAD: upstream gradient formed on the fly from dz through the BatchNorm + PReLU backward (fields bnb_*, bnb_dz1, bnb_totals)
+constexpr int kRunOnesMfma = 2048;  // WGRAD, 256 x 256 tile: the bias ones run (last 64 packed columns) is no k tile; k tile 0 multiplies dy with a constant ones operand
 constexpr int kRunEnc0 = 512;    // first encoder layer of a bf16 plan read from the fp32 spectrum itself (xdt = fp32, ydt = bf16, runs of 10 floats): enc0.hip
 constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`
