@@ -170,8 +170,11 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
   constexpr int NB = (CO + 31) / 32;
   constexpr int NDY = CO / 16;                               // 16-byte chunks of a 32-row bf16 tile per lane (32 rows x CO x 2 B / 1 KB)
   constexpr int CPR = CO / 8;                                // chunks per row
-  __shared__ float red[3][NB][16][64];                       // accumulators of waves 1..3
-  __shared__ __attribute__((aligned(16))) float dys[4][32 * CO];         // per wave: the step's 32 rows of dy as fp32
+  // per wave: the step's 32 rows of dy as fp32; after the loop the same bytes carry the accumulators of waves 1..3 to wave 0 (red[3][NB][16][64])
+  constexpr int SMF = 128 * CO > 3072 * NB ? 128 * CO : 3072 * NB;
+  __shared__ __attribute__((aligned(16))) float smf[SMF];
+  float (*dys)[32 * CO] = reinterpret_cast<float (*)[32 * CO]>(smf);
+  float (*red)[NB][16][64] = reinterpret_cast<float (*)[NB][16][64]>(smf);
   __shared__ __attribute__((aligned(16))) float xs[4][2][144];           // per wave: floats 4 fo0 .. 4 fo0 + 139 of frames t - 1 and t
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int sp = blockIdx.x;
@@ -185,7 +188,9 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
   const uint16_t* yf = FUSE ? reinterpret_cast<const uint16_t*>(rp(ab, d.bnb_y)) : nullptr;
   float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)sp * d.Npad * d.ldw;
   // FUSE: the 8 channels of this lane's chunks are the same in every step (64 % CPR == 0): their BatchNorm constants live in registers
-  float pm[8], pis[8], pg[8], pb[8], t0[8], t1[8], slope = 0.f;
+  // per channel: bn = ca y + cc (BatchNorm output, only its sign is used), dy = ca dbn - c0 - c1 y, with ca = gamma invstd, cc = beta - ca mean,
+  // c1 = ca invstd t1, c0 = ca t0 - c1 mean (t0, t1: the layer's two backward totals / count) - the apply kernel's formula with the constants folded
+  float ca[8], cc[8], c0[8], c1[8], slope = 0.f;
   if constexpr (FUSE) {
     const float* mi = reinterpret_cast<const float*>(rp(ab, d.bnb_mi));
     const float* ga = reinterpret_cast<const float*>(rp(ab, d.bnb_gamma));
@@ -195,8 +200,9 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int n = (lane % CPR) * 8 + e;
-      pm[e] = mi[n]; pis[e] = mi[d.N + n]; pg[e] = ga[n]; pb[e] = be[n];
-      t0[e] = tot[n] * d.bnb_inv_count; t1[e] = tot[d.N + n] * d.bnb_inv_count;
+      const float mean = mi[n], is = mi[d.N + n];
+      ca[e] = ga[n] * is; cc[e] = be[n] - ca[e] * mean;
+      c1[e] = ca[e] * is * (tot[d.N + n] * d.bnb_inv_count); c0[e] = ca[e] * (tot[n] * d.bnb_inv_count) - c1[e] * mean;
     }
   }
   f32x16 acc[NB];
@@ -224,10 +230,9 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
           const int sh = 16 * (e & 1);
           float dz = bf2f((uint16_t)(gw[e >> 1] >> sh));
           if (dz1) dz += bf2f((uint16_t)(zw[e >> 1] >> sh));
-          const float xh = (bf2f((uint16_t)(yw[e >> 1] >> sh)) - pm[e]) * pis[e];
-          const float bn = pg[e] * xh + pb[e];
-          const float dbn = bn > 0.f ? dz : slope * dz;
-          o[e] = pg[e] * pis[e] * (dbn - t0[e] - xh * t1[e]);
+          const float yv = bf2f((uint16_t)(yw[e >> 1] >> sh));
+          const float dbn = fmaf(ca[e], yv, cc[e]) > 0.f ? dz : slope * dz;
+          o[e] = fmaf(-c1[e], yv, fmaf(ca[e], dbn, -c0[e]));
         }
       } else {
 #pragma unroll
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const RunGemm d, const 
       }
     }
   }
+  __syncthreads();                                           // every wave is done with its dy tile: the bytes change hands
   if (wid > 0) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)

@@ -268,7 +268,10 @@ struct Builder {
     const bool short_wg = wg_rounds <= 1 && tiles_w <= 10 && (int64_t)g.M * tiles_w < (int64_t)8192 * 256;
     const int wide_slots = tune_str("WGW_SLOTS") ? atoi(tune_str("WGW_SLOTS")) : (short_wg ? 224 : 256);
     const int nscale = tune_str("WGN_SCALE") ? atoi(tune_str("WGN_SCALE")) : 100;      // tuning: percent of the slots of the narrow-tile launches
-    const int slots = (g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : (tn == 128 ? 512 : tn == 64 ? 768 : 1024) * nscale / 100) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
+    // the first encoder layer's kernel on the spectrum (enc0.hip; 21 KB of LDS and <= 124 registers: up to 4 workgroups per CU).  Row splits
+    // 512 / 768 / 1024 / 2048: 10.267 / 10.282 / 10.285 / 10.315 ms per step (three alternating runs each): the launch is not grid-bound, fewer partials fold faster
+    const int enc0_slots = tune_str("ENC0_WG_SLOTS") ? atoi(tune_str("ENC0_WG_SLOTS")) : 512;
+    const int slots = ((g.flags & kRunEnc0) ? enc0_slots : g.xdt == DT_BF16 ? ((g.flags & kRunWgWide) ? wide_slots : (tn == 128 ? 512 : tn == 64 ? 768 : 1024) * nscale / 100) : 768) * std::max(1, wg_rounds > 1 ? wg_rounds : env_rounds);
     const int tiles = (int)(rup(std::min(g.N, g.Npad), tn) / tn * rup(ldk, tk) / tk);   // tiles that hold real rows
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
@@ -2944,7 +2947,9 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
     // reads it (the inter-layer dropout fused into it, or no dropout); SEFD_FSN_DH16=0: fp32
     const bool dh16 = adt == DT_BF16 && Ls1.rowsk && Ls0.rowsk && (Ls0.dropfused || !(keep < 1.f)) && !(tune_str("FSN_DH16") && atoi(tune_str("FSN_DH16")) == 0);
     Ptr dh2d = b.ws("dh2d", (int64_t)TP * rs * Hs, dh16 ? adt : DT_F32);
-    wg_hold = !(tune_str("FSN_HOLD") && atoi(tune_str("FSN_HOLD")) == 0);
+    // round 6: with the upper layer's ONE weight-gradient GEMM (cat2, 3 k tiles) starting beside the input-gradient GEMM is 0.12 ms per step better than
+    // waiting for the lower layer's recurrence (54.15 vs 54.28 ms, twice, one box); FSN_HOLD=1 restores the hold
+    wg_hold = tune_str("FSN_HOLD") && atoi(tune_str("FSN_HOLD")) == 1;
     lstm_backward(Ls1, dh3, true, dh2d, Hs, 0, Hs, dh16 ? adt : DT_F32, 203);
     wg_hold = 0;
     if (dh16) Ls0.dhdt = adt;

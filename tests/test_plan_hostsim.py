@@ -215,17 +215,45 @@ def test_folds_and_early_unpack_are_a_pure_reschedule(monkeypatch):
 
 
 def test_fsn_weight_gradients_ride_the_second_lane():
-    """FullSubNet bf16 plan: the weight-gradient GEMMs of the recurrent layers are lane-1 ops; the ones of the upper sub-band layer wait for the next
-    recurrence launch (Op::join == kOpHold = 2) instead of starting beside the input-gradient GEMM in between.  fp32 (per-frame formulation) stays single-lane."""
-    plan = Plan(2, 9, act_dtype="bf16", model="FullSubNet", fsn=dict(fb_hidden=256, sb_hidden=192, keep=0.2))
-    w = _op_words(plan, PHASE_BWD)
-    wg = [tuple(r[1:]) for r in w if r[0] == 2]                 # WGRAD: (tag, lane, join)
-    lane1 = [t for t in wg if t[1] == 1]
-    assert len(lane1) == 8, wg                                  # 4 layers x (W_ih, W_hh)
-    assert sorted(t[0] for t in lane1 if t[2] == 2) == [203, 203], wg       # upper sub-band layer: held
-    assert any(r[0] == 10 for r in w)                           # the recurrences are single OP_LSTM_BWD launches (what the lane forks at)
+    """FullSubNet bf16 plan: the weight-gradient GEMMs of the recurrent layers are lane-1 ops.  Knob FSN_HOLD=1 (the default until round 6): the ones of the
+    upper sub-band layer wait for the next recurrence launch (Op::join == kOpHold = 2) instead of starting beside the input-gradient GEMM in between.
+    fp32 (per-frame formulation) stays single-lane."""
+    for hold in (None, "1"):
+        if hold:
+            knobs.set("FSN_HOLD", hold)
+        plan = Plan(2, 9, act_dtype="bf16", model="FullSubNet", fsn=dict(fb_hidden=256, sb_hidden=192, keep=0.2))
+        w = _op_words(plan, PHASE_BWD)
+        wg = [tuple(r[1:]) for r in w if r[0] == 2]                 # WGRAD: (tag, lane, join)
+        lane1 = [t for t in wg if t[1] == 1]
+        assert len(lane1) == 8, wg                                  # 4 layers x (W_ih, W_hh)
+        assert sorted(t[0] for t in lane1 if t[2] == 2) == ([203, 203] if hold else []), wg       # upper sub-band layer: held
+        assert any(r[0] == 10 for r in w)                           # the recurrences are single OP_LSTM_BWD launches (what the lane forks at)
     plan32 = Plan(2, 9, act_dtype="fp32", model="FullSubNet", fsn=dict(fb_hidden=64, sb_hidden=32, keep=0.2))
     assert all(r[2] == 0 for r in _op_words(plan32, PHASE_BWD))
+
+
+def test_fsn_upper_subband_layer_has_one_weight_gradient_gemm():
+    """Round 6 (plan.cpp lstm_backward cat2, rungemm.hip kRunOnesMfma = 2048): at the reference sizes (H = 384, row-block kernels) the upper sub-band
+    layer's W_ih and W_hh gradients are ONE GEMM over [h1_t | h2_{t-1} | ones] = 384 + 384 + 64 packed columns; under the 256 x 256 tile the ones run is
+    not a k tile (the flag).  Knob FSN_WGCAT2=0: two GEMMs (K = 384 + ones, K = 384) as before.  The per-op GPU test (FullSubNet, T = 11) and the
+    goldens check the numbers; this checks the planner's shapes."""
+    fsn = dict(fb_hidden=512, sb_hidden=384, keep=0.2)
+
+    def upper(plan):
+        n = plan.num_ops(PHASE_BWD)
+        return [plan.op_info(PHASE_BWD, i) for i in range(n) if plan.op_info(PHASE_BWD, i)["kind"] == 2 and plan.op_info(PHASE_BWD, i)["tag"] == 203]
+
+    knobs.set("LSTM_ROWS_MIN", "64")                                    # 257 rows: the row-block kernels (default: thousands of rows)
+    knobs.set("WG256_MINM", "64")
+    one = upper(Plan(1, 11, act_dtype="bf16", model="FullSubNet", fsn=fsn))
+    assert len(one) == 1 and one[0]["K"] == 2 * 384 + 1 and one[0]["N"] == 4 * 384, one
+    assert one[0]["flags"] & 32 and one[0]["flags"] & 2048, one          # kRunWgWide, kRunOnesMfma
+    knobs.unset("WG256_MINM")
+    small = upper(Plan(1, 11, act_dtype="bf16", model="FullSubNet", fsn=fsn))
+    assert len(small) == 1 and not (small[0]["flags"] & 2048), small     # below the wide tile's row threshold: the ones run is a DMA'd column
+    knobs.set("FSN_WGCAT2", "0")
+    two = upper(Plan(1, 11, act_dtype="bf16", model="FullSubNet", fsn=fsn))
+    assert sorted(o["K"] for o in two) == [384, 385], two
 
 
 def test_tiled_weight_layout_is_a_pure_relayout(monkeypatch):
