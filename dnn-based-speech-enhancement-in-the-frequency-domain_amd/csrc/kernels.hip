@@ -54,7 +54,6 @@ __global__ void packmulti_kernel(const PackMulti m, const ArenaBases ab) {
 // Sum of the nsplit row-split partials of a WGRAD (deterministic order).  A workgroup owns 64 consecutive elements:
 // 16 lanes x float4 along the elements, 16 lanes along the splits (thin layers have 768 splits of only 8 K elements, so
 // parallelism has to come from the split axis), then a fixed-order 16-way combine through LDS.
-constexpr int64_t kSplitWideMin = 65536;      // elements of a block from which a thread walks the splits of its own float4
 __global__ __launch_bounds__(256) void splitsum_kernel(Unpack d, const ArenaBases ab) {
   __shared__ float4 red[16][16];
   float* part = reinterpret_cast<float*>(rp(ab, d.part));
@@ -66,33 +65,6 @@ __global__ __launch_bounds__(256) void splitsum_kernel(Unpack d, const ArenaBase
   }
   const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
   const bool vec = (d.n & 3) == 0 && (d.sstride & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
-  if (vec && d.n >= kSplitWideMin) {
-    // Large blocks (round 6; FullSubNet's 1536 x 832 gradients in 113 splits, DCCRN's 256 x 256-tile launches): a thread owns ONE float4 of 1024 consecutive
-    // elements and walks the splits itself, 16 loads in flight, in the SAME order as the small form below (16 interleaved chains, then chain 0 + 1 + ... + 15:
-    // bit-identical sums).  A wave-load is 1 KB contiguous instead of four 256-byte pieces 16 splits (tens of MB) apart: 475 -> 2xx us for 1.1 GB on the tail.
-    for (int64_t base = (int64_t)blockIdx.x * 1024; base < d.n; base += (int64_t)gridDim.x * 1024) {
-      const int64_t i = base + threadIdx.x * 4;
-      if (i >= d.n) continue;
-      float4 s[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* p = part + i;
-      for (int k0 = 0; k0 < d.nsplit; k0 += 16) {
-        float4 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          v[j] = k0 + j < d.nsplit ? *reinterpret_cast<const float4*>(p + (int64_t)(k0 + j) * d.sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (k0 + j < d.nsplit) { s[j].x += v[j].x; s[j].y += v[j].y; s[j].z += v[j].z; s[j].w += v[j].w; }
-      }
-      float4 t = s[0];
-#pragma unroll
-      for (int j = 1; j < 16; ++j) { t.x += s[j].x; t.y += s[j].y; t.z += s[j].z; t.w += s[j].w; }
-      *reinterpret_cast<float4*>(part + i) = t;
-    }
-    return;
-  }
   for (int64_t base = (int64_t)blockIdx.x * 64; base < d.n; base += (int64_t)gridDim.x * 64) {
     const int64_t i = base + ex * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);

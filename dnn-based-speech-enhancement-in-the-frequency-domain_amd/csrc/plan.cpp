@@ -2970,10 +2970,10 @@ Plan* build_fsn_plan(const ModelConfig& cfg) {
         b.push(R, OP_FSN_NORMBWD, 201).fsn = f; }
       { Fsn f = fsn0(); f.in = dpre; f.aux = fbo; f.aux2 = mu_sb; f.sums = Sm; f.out = d_fb; f.mode = nmode; b.push(R, OP_FSN_SBBWD_APPLY, 200).fsn = f; }
     }
-    if (fsn_buckets) {
-      b.flush_sums(R, 997, true);                          // the sub-band folds: on the lane, behind the weight gradients they fold
-      wg_lane = 0;                                         // full-band weight gradients: main stream
-    }
+    if (fsn_buckets) b.flush_sums(R, 997, true);         // the sub-band folds: on the lane, behind the weight gradients they fold
+    // full-band weight gradients (four 80 us launches): main stream.  Two gradient buckets need them there (no wait for the lane); since round 6 always: at
+    // the end of the lane they ran 0.35 ms past the main stream, which idles beside the 8-workgroup cluster recurrences (FSN_FB_LANE=1: on the lane)
+    if (fsn_buckets || !(tune_str("FSN_FB_LANE") && atoi(tune_str("FSN_FB_LANE")) == 1)) wg_lane = 0;
     Ptr dh1 = b.ws("dh1", (int64_t)TP * B * Hf, DT_F32);
     fc_backward(fcf, d_fb, h1, B, Hf, F, FP, dh1, 102, "fb_model");
     Ptr dh0d = b.ws("dh0d", (int64_t)TP * B * Hf, DT_F32);
