@@ -276,6 +276,12 @@ struct Builder {
     const int steps = (int)((g.M + kWgRows - 1) / kWgRows);
     int ns = std::max(1, slots / tiles);
     ns = std::max(1, std::min(ns, std::max(1, steps / 4)));
+    // N <= 4 outputs over a contiguous array (FullSubNet's sub-band head): the streaming kernel, one workgroup per row split (WGRANK=0: the tiled kernels;
+    // WGRANK_MINM: fewest rows, tests lower it)
+    if (wgrad_rank_form(g) && g.M >= (tune_str("WGRANK_MINM") ? atoll(tune_str("WGRANK_MINM")) : 65536) && !(tune_str("WGRANK") && atoi(tune_str("WGRANK")) == 0)) {
+      g.flags |= kRunRank;
+      ns = std::max(1, std::min(1024, steps / 4));
+    }
     g.nsplit = ns;
     const int64_t sz = (int64_t)g.Npad * g.ldw;
     const int64_t rel = gp_off;

@@ -1147,6 +1147,96 @@ __global__ __launch_bounds__(NTHR) void wgrad_bf16_dma_kernel(const RunGemm d, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// WGRAD, rank-N form (kRunRank; round 6): N <= 4 outputs, K <= 512 inputs, millions of contiguous rows - FullSubNet's sub-band head (models.py:668-672 through
+// SequenceModel's fc_output_layer: 384 -> 2).  On the tiled kernels N = 2 is padded to a 64-wide tile of a non-DMA kernel (dy rows of 4 bytes are no 16-byte
+// chunks): 1.2 ms alone, 3.3 ms beside the recurrence, for a pass over 2.4 GB.  Here a thread owns one 16-byte chunk of the K axis and every RL-th row of the
+// workgroup's split: one 16-byte load of x and one 2 N-byte load of dy per row, 8 N fmas; the row lanes fold through LDS in lane order.  Same split boundaries
+// as the tiled kernels (32-row steps), whole [Npad][ldw] block written.
+template <int NR>
+__global__ __launch_bounds__(256) void wgrad_rank_kernel(const RunGemm d, const ArenaBases ab) {
+  __shared__ float red[2048 * NR];                          // [RL][NR][K] floats: CH * RL <= 256 threads, K = 8 CH
+  __shared__ float redb[256][NR];
+  const int tid = threadIdx.x, split = blockIdx.x;
+  const Seg sg = d.seg[0];
+  const int K = sg.len, CH = K / 8, RL = 256 / CH;           // chunks per row, row lanes
+  const int kc = tid % CH, rl = tid / CH;
+  const bool act = rl < RL;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(rp(ab, d.x[0])) + sg.off + 8 * kc;
+  const uint16_t* dy = reinterpret_cast<const uint16_t*>(rp(ab, d.y)) + d.y_off;
+  float* part = reinterpret_cast<float*>(rp(ab, d.w)) + (int64_t)split * d.Npad * d.ldw;
+  const int nsteps = (d.M + kWgRows - 1) / kWgRows;
+  const int per = (nsteps + d.nsplit - 1) / d.nsplit;
+  const int64_t m0 = (int64_t)split * per * kWgRows, m1 = min((int64_t)d.M, (int64_t)(split + 1) * per * kWgRows);
+  const int fs = d.fstride[0], ys = d.y_fstride;
+  float acc[NR][8], bs[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    bs[n] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[n][e] = 0.f;
+  }
+  auto row = [&](const uint4 xv, const float (&g)[NR]) {
+    const uint32_t w[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xe = bf2f((uint16_t)(w[e >> 1] >> (16 * (e & 1))));
+#pragma unroll
+      for (int n = 0; n < NR; ++n) acc[n][e] = fmaf(g[n], xe, acc[n][e]);
+    }
+#pragma unroll
+    for (int n = 0; n < NR; ++n) bs[n] += g[n];
+  };
+  auto ldy = [&](int64_t m, float (&g)[NR]) {
+#pragma unroll
+    for (int n = 0; n < NR; ++n) g[n] = n < d.N ? bf2f(dy[m * ys + n]) : 0.f;
+  };
+  if (act) {
+    int64_t m = m0 + rl;
+    for (; m + 3 * RL < m1; m += 4 * RL) {                  // four rows in flight
+      uint4 xv[4];
+      float g[4][NR];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { xv[u] = *reinterpret_cast<const uint4*>(x + (m + u * RL) * fs); ldy(m + u * RL, g[u]); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) row(xv[u], g[u]);
+    }
+    for (; m < m1; m += RL) {
+      float g[NR];
+      ldy(m, g);
+      row(*reinterpret_cast<const uint4*>(x + m * fs), g);
+    }
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(rl * NR + n) * K + 8 * kc + e] = acc[n][e];
+      if (kc == 0) redb[rl][n] = bs[n];
+    }
+  }
+  // the split's whole [Npad][ldw] block: zeros where nothing lands
+  for (int i = tid; i < d.Npad * d.ldw; i += 256) part[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < d.N * K; i += 256) {
+    const int n = i / K, k = i - n * K;
+    float v = red[n * K + k];
+    for (int r = 1; r < RL; ++r) v += red[(r * NR + n) * K + k];
+    part[(int64_t)n * d.ldw + sg.koff + k] = v;
+  }
+  if (d.nseg == 2 && tid < d.N) {
+    float v = redb[0][tid];
+    for (int r = 1; r < RL; ++r) v += redb[r][tid];
+    part[(int64_t)tid * d.ldw + d.seg[1].koff] = v;
+  }
+}
+
+static bool launch_wgrad_rank(const RunGemm& d, const ArenaBases& ab, hipStream_t st) {
+  if (!(d.flags & kRunRank) || !wgrad_rank_form(d)) return false;
+  const dim3 grid((unsigned)d.nsplit);
+  if (d.N <= 2) hipLaunchKernelGGL((wgrad_rank_kernel<2>), grid, dim3(256), 0, st, d, ab);
+  else hipLaunchKernelGGL((wgrad_rank_kernel<4>), grid, dim3(256), 0, st, d, ab);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Ring depth of the LDS-DMA pipelines.  SEFD_RG_STAGES / SEFD_WG_STAGES (2..4) override the defaults for tuning runs.
 static int env_stages(const char* name, int dflt) {
   const char* e = tune_str(name);
@@ -1234,6 +1324,7 @@ static void launch_wgrad_dma(const RunGemm& d, const ArenaBases& ab, hipStream_t
 
 void launch_wgrad(const RunGemm& d0, const ArenaBases& ab, hipStream_t st) {
   if (launch_enc0_wgrad(d0, ab, st)) return;               // ... and its weight gradient
+  if (launch_wgrad_rank(d0, ab, st)) return;               // N <= 4 outputs over a contiguous array
   RunGemm d = d0;
 #ifdef SEFD_TUNING
   // wrong-result arm (no partial-sum stores), tuning builds only (-DSEFD_TUNING): the product library has no switch that changes what a launch computes

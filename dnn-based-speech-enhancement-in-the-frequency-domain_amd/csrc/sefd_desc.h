@@ -107,6 +107,7 @@ constexpr int kRunWTile32 = 16;  // packed weights are stored K-tile major, [ldw
 constexpr int kRunBnBwd = 64;    // epilogue accumulates BatchNorm-backward partial sums against the layer's forward output (fields bnb_*); `stats` rows are [3][Npad]
 constexpr int kRunDyFromBn = 1024; // WGRAD: upstream gradient formed on the fly from dz through the BatchNorm + PReLU backward (fields bnb_*, bnb_dz1, bnb_totals)
 constexpr int kRunOnesMfma = 2048;  // WGRAD, 256 x 256 tile: the bias ones run (last 64 packed columns) is no k tile; k tile 0 multiplies dy with a constant ones operand
+constexpr int kRunRank = 4096;      // WGRAD of a layer with N <= 4 outputs over one contiguous bf16 array (wgrad_rank_form below): streamed once by wgrad_rank_kernel (rungemm.hip)
 constexpr int kRunEnc0 = 512;    // first encoder layer of a bf16 plan read from the fp32 spectrum itself (xdt = fp32, ydt = bf16, runs of 10 floats): enc0.hip
 constexpr int kRunWgWide = 32;   // WGRAD: the planner sized the row splits for the 256 x 256 tile of the 8-wave kernel (rungemm.hip launch_wgrad_wide)
 // element index of W[n][k] inside the packed weight buffer of `g`
@@ -491,6 +492,19 @@ SEFD_HD static inline RowsJob rows_bwd_job(int job, int nblk, int C, int T) {
 // Tile geometry shared by planner (padding) and kernels.
 constexpr int kBM = 128;                                   // rows per RUNGEMM block == rows per statistics block
 inline int bk_of(int dt) { return dt == DT_BF16 ? 64 : 32; }   // K-tile in elements: 128 bytes of either dtype
+// WGRAD with N <= 4 outputs over ONE contiguous bf16 [M][fstride] array and a contiguous bf16 [M][y_fstride] gradient (FullSubNet's sub-band head: 2 outputs,
+// 384 inputs, 3.2 M rows): a rank-N update - the planner marks it kRunRank (and sizes the row splits for a streaming kernel), rungemm.hip wgrad_rank_kernel runs it
+inline bool wgrad_rank_form(const RunGemm& g) {
+  if (g.xdt != DT_BF16 || g.ydt != DT_BF16 || g.N < 1 || g.N > 4 || g.nseg < 1 || g.nseg > 2) return false;
+  const Seg& s = g.seg[0];
+  if (s.src != 0 || s.dt != 0 || s.len % 8 != 0 || s.len < 8 || s.len > 512 || s.off % 8 != 0 || s.koff != 0) return false;
+  if (g.nseg == 2 && (g.seg[1].src >= 0 || g.seg[1].koff < s.len)) return false;               // the second run can only be the bias ones run
+  if (g.bstride[0] != 0 || g.base[0] != 0 || g.fstride[0] % 8 != 0 || s.off + s.len > g.fstride[0]) return false;
+  if ((int64_t)g.tstride[0] != (int64_t)g.Fo * g.fstride[0] || (int64_t)g.M != (int64_t)g.Tout * g.Fo || g.Tin[0] != g.Tout) return false;
+  if (g.y_bstride != 0 || (int64_t)g.y_tstride != (int64_t)g.Fo * g.y_fstride || g.y_fstride < g.N || g.y_off < 0) return false;
+  return (g.x[0].off % 16) == 0 && (g.y.off % 2) == 0;
+}
+
 inline int bn_of(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 constexpr int kWgTN = 64, kWgTK = 128, kWgRows = 32;       // WGRAD block tile (n x k) and reduction rows per step
 // n extent of the WGRAD tile of the aligned bf16 kernel: 128 for wide layers, 32 for the thin ones (shared by the planner, which

@@ -72,6 +72,7 @@ def test_every_op_against_host_simulator(model, B, L, mode, kn, ru, dtype):
     knobs.unset("BN_FUSE")
     if model == "FullSubNet" and L == 11 and kn == (512, 384):   # 257 x 11 rows: lower the bar so that the sub-band weight gradients run the 256 x 256 tile
         knobs.set("WG256_MINM", "64")                            # (upper layer: [h1 | h2 | ones] with the bias from the ones MFMA, kRunOnesMfma)
+        knobs.set("WGRANK_MINM", "64")                           # ... and the 2-output head's weight gradient the rank-N streaming kernel (kRunRank)
     direct_all = L in (4001, 2403)
     if L in (4001, 2403):                  # the direct-operand kernel takes GEMMs with M >= 65536 by default
         L -= 1 if L == 4001 else 3

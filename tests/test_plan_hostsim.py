@@ -254,6 +254,13 @@ def test_fsn_upper_subband_layer_has_one_weight_gradient_gemm():
     knobs.set("FSN_WGCAT2", "0")
     two = upper(Plan(1, 11, act_dtype="bf16", model="FullSubNet", fsn=fsn))
     assert sorted(o["K"] for o in two) == [384, 385], two
+    # the 2-output head (tag 204): rank-N streaming kernel (kRunRank = 4096) from WGRANK_MINM rows on, one workgroup per row split
+    def head(plan):
+        return [plan.op_info(PHASE_BWD, i) for i in range(plan.num_ops(PHASE_BWD)) if plan.op_info(PHASE_BWD, i)["kind"] == 2 and plan.op_info(PHASE_BWD, i)["tag"] == 204]
+    h0 = head(Plan(1, 11, act_dtype="bf16", model="FullSubNet", fsn=fsn))
+    knobs.set("WGRANK_MINM", "64")
+    h1 = head(Plan(1, 11, act_dtype="bf16", model="FullSubNet", fsn=fsn))
+    assert len(h0) == 1 and len(h1) == 1 and h0[0]["N"] == 2 and h0[0]["K"] == 385 and not (h0[0]["flags"] & 4096) and (h1[0]["flags"] & 4096), (h0, h1)
 
 
 def test_tiled_weight_layout_is_a_pure_relayout(monkeypatch):
