@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <cstdio>
+#include <map>
 #include "../../include/sefd.h"
 #include "dev_common.h"
 #include "plan.h"
@@ -21,6 +23,12 @@ struct sefd_plan {
   // by a kernel that gave up (cluster LSTM hand-over timeout) until sefd_plan_status(clear = 1)
   mutable int* status = nullptr;
   mutable int* dstatus = nullptr;             // the same word in device memory (what the guarded Adam reads)
+  // knob GRAPH=1 (round 6 experiment, profiles/r06_tuning_notes.md section 12): whole-phase runs replayed as an instantiated hipGraph captured from the
+  // executor's own multi-stream launch sequence; keyed by (phase, flags, stream, arena bases); the first two runs of a key execute normally (lazy
+  // allocations and function attributes happen there, not inside a capture)
+  struct GraphKey { int phase, flags; void* stream; void* arena[A_COUNT]; bool operator<(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; } };
+  struct GraphEntry { int calls = 0; hipGraphExec_t exec = nullptr; bool failed = false; };
+  mutable std::map<GraphKey, GraphEntry> graphs;
 };
 static int* plan_status_word(const sefd_plan* h) {
   if (!h->status) {
@@ -56,6 +64,7 @@ void sefd_plan_destroy(sefd_plan* h) {
   if (h->ev_side2) (void)hipEventDestroy(h->ev_side2);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   if (h->status) (void)hipHostFree(h->status);
   if (h->dstatus) (void)hipFree(h->dstatus);
   delete h->p;
@@ -158,13 +167,44 @@ int32_t sefd_plan_grad_bucket_range(const sefd_plan* h, int32_t* op, int64_t* lo
 static int32_t plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx,
                         std::vector<hipEvent_t>* tev = nullptr, int flags = 0);
 
+static int32_t plan_run_graph(const sefd_plan* h, int phase, void* const* arenas, void* stream, int flags);
+static bool graph_knob() { const char* e = tune_str("GRAPH"); return e && atoi(e) == 1; }      // read per call: the equivalence test flips it
 int32_t sefd_plan_run(const sefd_plan* h, int phase, int first, int last, void* const* arenas, void* stream) {
+  if (h && first <= 0 && last < 0 && graph_knob() && !tune_str("NO_OVERLAP")) return plan_run_graph(h, phase, arenas, stream, 0);
   return plan_run(h, phase, first, last, arenas, stream, -1, nullptr, nullptr);
 }
 int32_t sefd_plan_run_cb(const sefd_plan* h, int phase, void* const* arenas, void* stream, int at, void (*cb)(void*), void* ctx) {
   return plan_run(h, phase, 0, -1, arenas, stream, at, cb, ctx);
 }
+static int32_t plan_run_graph(const sefd_plan* h, int phase, void* const* arenas, void* stream, int flags) {
+  sefd_plan::GraphKey key;
+  std::memset(&key, 0, sizeof(key));
+  key.phase = phase; key.flags = flags; key.stream = stream;
+  for (int a = 0; a < A_COUNT; ++a) key.arena[a] = arenas[a];
+  sefd_plan::GraphEntry& e = h->graphs[key];
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (e.exec) {
+    int* status = plan_status_word(h);
+    if (status && __atomic_load_n(status, __ATOMIC_RELAXED) != 0) return -5;
+    return hipGraphLaunch(e.exec, st) == hipSuccess ? 0 : -2;
+  }
+  if (e.failed || ++e.calls < 3) return plan_run(h, phase, 0, -1, arenas, stream, -1, nullptr, nullptr, nullptr, flags);
+  hipGraph_t g = nullptr;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { e.failed = true; (void)hipGetLastError(); return plan_run(h, phase, 0, -1, arenas, stream, -1, nullptr, nullptr, nullptr, flags); }
+  const int32_t rc = plan_run(h, phase, 0, -1, arenas, stream, -1, nullptr, nullptr, nullptr, flags);
+  const hipError_t ec = hipStreamEndCapture(st, &g);
+  if (rc != 0 || ec != hipSuccess || !g || hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0) != hipSuccess) {
+    e.failed = true; e.exec = nullptr;
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    fprintf(stderr, "sefd: GRAPH=1: capture of phase %d failed (rc %d, %s): running the launch sequence\n", phase, (int)rc, hipGetErrorString(ec));
+    return plan_run(h, phase, 0, -1, arenas, stream, -1, nullptr, nullptr, nullptr, flags);
+  }
+  (void)hipGraphDestroy(g);
+  return hipGraphLaunch(e.exec, st) == hipSuccess ? 0 : -2;
+}
 int32_t sefd_plan_run_flags(const sefd_plan* h, int phase, void* const* arenas, void* stream, int flags, int at, void (*cb)(void*), void* ctx) {
+  if (graph_knob() && h && !cb && !tune_str("NO_OVERLAP")) return plan_run_graph(h, phase, arenas, stream, flags);
   return plan_run(h, phase, 0, -1, arenas, stream, at, cb, ctx, nullptr, flags);
 }
 // Measurement: the whole phase in its REAL two-lane schedule, with a HIP event recorded before and after every op on the stream the op

@@ -833,6 +833,44 @@ def test_two_stream_schedule_equals_program_order(which, monkeypatch):
     assert torch.equal(grads[0], grads[2])
 
 
+@pytest.mark.parametrize("which", ["dccrn", "fullsubnet"])
+def test_graph_replay_equals_launch_sequence(which):
+    """Knob GRAPH=1 (api.hip plan_run_graph, round 6): a whole phase is captured ONCE from the executor's own multi-stream launch sequence into a hipGraph
+    (third run with the same arenas and stream) and replayed afterwards.  Same kernels, same dependencies: loss and gradients of the captured run and of
+    the replays are BIT-identical to the launch sequence.  (Measured: no faster - profiles/r06_tuning_notes.md section 12 - hence opt-in.)"""
+    import sefd_amd  # noqa: F401
+    from sefd_amd import config as cfg, models
+    from sefd_amd.optim import Adam
+    if which == "dccrn":
+        m = make_model((32, 64, 128, 256, 256, 256), 256, "C", "SI-SNR", dtype="bf16")
+        m.train()
+        x, y = _bench_batch(8)
+    else:
+        cfg.loss, cfg.act_dtype = "MSE", "bf16"
+        try:
+            torch.manual_seed(0)
+            m = models.FullSubNet().to("cuda").train()
+        finally:
+            cfg.act_dtype = "fp32"
+        x, y = _bench_batch(16)
+    opt = Adam(m.parameters(), lr=0.0)
+    out = []
+    for rep in range(6):                                   # 0: launch sequence ; 1, 2: warm-up runs of the graph path ; 3: capture + first launch ; 4, 5: replays
+        if rep == 1:
+            knobs.set("GRAPH", "1")
+        if which == "fullsubnet" and rep > 0:              # same dropout masks: the step counter behind the mask hash goes back by one
+            plan, ar = next(v for k, v in m._runtimes.items() if k[0] == "fsn")
+            plan.view(ar, "io.seed").view(torch.int32)[:1].sub_(1)
+        loss = float(m.train_step(x, y, opt))
+        torch.cuda.synchronize()
+        out.append((loss, m._flat_grad.clone()))
+    knobs.unset("GRAPH")
+    assert bool(torch.isfinite(out[0][1]).all()) and float(out[0][1].abs().max()) > 0
+    for rep in range(1, 6):
+        assert out[rep][0] == out[0][0], (rep, out[rep][0], out[0][0])
+        assert torch.equal(out[rep][1], out[0][1]), (rep, float((out[rep][1] - out[0][1]).abs().max()))
+
+
 def test_paired_subband_layers_equal_two_launches(monkeypatch):
     """FullSubNet's two sub-band LSTM layers run as ONE launch of (layer, time chunk, row block) jobs (lstm_rows.hip lstm_fwd_rows_pair_kernel: a
     job starts behind the flags of the jobs it reads from, on whatever CU is free), and the backward recurrences as (time chunk, row block) jobs
