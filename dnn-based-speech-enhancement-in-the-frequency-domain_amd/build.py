@@ -65,8 +65,22 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
+    # one builder at a time across processes (two ranks of a test that both find the library stale compiled into the same object files and broke each
+    # other's translation units): the second one waits, then finds the stamp current
+    import fcntl
+    with open(os.path.join(OBJ, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     heads = _headers()
     jobs = []
     for s in SOURCES:

@@ -22,9 +22,16 @@ def build_sim(force=False):
     desc = os.path.join(sefd_build.CSRC, "sefd_desc.h")
     digest = sefd_build.source_digest([SIM_SRC, desc], " ".join(SIM_CMD[:-2]))      # contents, not mtimes (build.source_digest)
     if force or not sefd_build.stamp_current(SIM_LIB, digest):
+        import fcntl
         os.makedirs(os.path.dirname(SIM_LIB), exist_ok=True)
-        subprocess.run(SIM_CMD, check=True)
-        sefd_build.write_stamp(SIM_LIB, digest)
+        with open(SIM_LIB + ".lock", "w") as lock:          # one builder at a time across processes (the two ranks of a gloo test), like build.build()
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or not sefd_build.stamp_current(SIM_LIB, digest):
+                    subprocess.run(SIM_CMD, check=True)
+                    sefd_build.write_stamp(SIM_LIB, digest)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 _built = False
